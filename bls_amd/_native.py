@@ -1,0 +1,67 @@
+"""Loader / builder for the HIP extension libblsmi.so (the product path; no CPU fallback).
+
+build() compiles bls_amd/csrc/blsmi.hip for gfx950 with hipcc (cross-compiles without a GPU).
+load() dlopens the in-tree library and fails loudly when it is missing or has no device.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(_HERE, "libblsmi.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
+_SOURCES = ["blsmi.hip", "fp.cuh", "tower_fwd.cuh", "tower.cuh", "curve.cuh", "pairing.cuh", "hash.cuh", "consts.cuh",
+            "verify_kernels.inc", "verify_host.inc"]
+
+
+def _stale():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = [os.path.join(CSRC, s) for s in _SOURCES] + [HEADER]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> bls_amd/libblsmi.so (in-tree so that it travels to the GPU box)."""
+    consts = os.path.join(CSRC, "consts.cuh")
+    gen = os.path.join(CSRC, "gen_consts.py")
+    if not os.path.exists(consts) or os.path.getmtime(gen) > os.path.getmtime(consts):
+        subprocess.check_call(["python3", gen])
+    if not force and not _stale():
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
+           "-o", SO_PATH, os.path.join(CSRC, "blsmi.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load():
+    """Return the ctypes handle of libblsmi.so; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NativeError("bls_amd/libblsmi.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _lib = C.CDLL(SO_PATH)
+    _lib.blsmi_version.restype = C.c_char_p
+    return _lib
+
+
+def declared_symbols():
+    """Entry points declared in include/blsmi.h."""
+    import re
+    txt = open(HEADER).read()
+    return sorted(set(re.findall(r"\b(blsmi_[a-z0-9_]+)\s*\(", txt)))

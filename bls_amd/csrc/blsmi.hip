@@ -1,0 +1,503 @@
+// blsmi.hip -- kernels and the C ABI (include/blsmi.h) of libblsmi.so.
+//
+// One (message, public key, signature) / (P, Q) tuple per lane; 64-lane workgroups, one wave per
+// SIMD (the per-lane state of a pairing -- f: 180 words, R: 90, P,Q: 90 -- wants the whole 512-entry
+// register file; the measured cost of running one wave per SIMD is ~25 % on the multiply core, see
+// profiles/r01_ubench2_fmul.log).  HBM traffic is the tuple I/O only (864 B per pairing).
+#include "../../include/blsmi.h"
+#include "pairing.cuh"
+#include "hash.cuh"
+#include <mutex>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+
+using namespace blsmi;
+
+#define WG 64
+#define KERNEL __global__ void __launch_bounds__(WG, 1)
+
+// ------------------------------------------------------------------------------------------------
+// device-side I/O helpers
+// ------------------------------------------------------------------------------------------------
+// internal structure-of-arrays buffers: word (e, j) of tuple t lives at buf[(e*NL + j)*n + t]
+BLSMI_DEV void soa_store(i32* buf, size_t n, size_t t, int e, const FpS& x) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) buf[((size_t)e * NL + j) * n + t] = x.v[j];
+}
+BLSMI_DEV FpS soa_load(const i32* buf, size_t n, size_t t, int e) {
+    FpS x;
+#pragma unroll
+    for (int j = 0; j < NL; j++) x.v[j] = buf[((size_t)e * NL + j) * n + t];
+    return x;
+}
+BLSMI_DEV void soa_store12(i32* buf, size_t n, size_t t, const Fp12S& f) {
+    const FpS* c = reinterpret_cast<const FpS*>(&f);
+#pragma unroll
+    for (int e = 0; e < 12; e++) soa_store(buf, n, t, e, c[e]);
+}
+BLSMI_DEV Fp12S soa_load12(const i32* buf, size_t n, size_t t) {
+    Fp12S f;
+    FpS* c = reinterpret_cast<FpS*>(&f);
+#pragma unroll
+    for (int e = 0; e < 12; e++) c[e] = soa_load(buf, n, t, e);
+    return f;
+}
+// 48-byte big-endian field element at p (4-byte aligned) -> Montgomery
+BLSMI_DEV FpS load_be48(const u8* p) {
+    const u32* w32 = reinterpret_cast<const u32*>(p);
+    u32 w[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) w[j] = __builtin_bswap32(w32[11 - j]);
+    return fp_from_words(w);
+}
+template <int L, int V>
+BLSMI_DEV void store_be48(u8* p, const Fp<L, V>& x) {
+    u32 w[12];
+    fp_to_words(x, w);
+    u32* w32 = reinterpret_cast<u32*>(p);
+#pragma unroll
+    for (int j = 0; j < 12; j++) w32[11 - j] = __builtin_bswap32(w[j]);
+}
+BLSMI_DEV FpS load_m384(const u64* p) {
+    const u32* w32 = reinterpret_cast<const u32*>(p);
+    u32 w[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) w[j] = w32[j];
+    return fp_from_mont384_words(w);
+}
+template <int L, int V>
+BLSMI_DEV void store_m384(u64* p, const Fp<L, V>& x) {
+    u32 w[12];
+    fp_to_mont384_words(x, w);
+    u32* w32 = reinterpret_cast<u32*>(p);
+#pragma unroll
+    for (int j = 0; j < 12; j++) w32[j] = w[j];
+}
+BLSMI_DEV G1Aff load_g1(const u8* p) { G1Aff a; a.x = load_be48(p); a.y = load_be48(p + 48); a.inf = 0; return a; }
+BLSMI_DEV G2Aff load_g2(const u8* p) {
+    G2Aff a; a.x.c0 = load_be48(p); a.x.c1 = load_be48(p + 48); a.y.c0 = load_be48(p + 96); a.y.c1 = load_be48(p + 144); a.inf = 0; return a;
+}
+BLSMI_DEV void store_g1(u8* p, const G1Aff& a) {
+    if (a.inf) { u32* w = reinterpret_cast<u32*>(p); for (int i = 0; i < 24; i++) w[i] = 0; return; }
+    store_be48(p, a.x); store_be48(p + 48, a.y);
+}
+BLSMI_DEV void store_g2(u8* p, const G2Aff& a) {
+    if (a.inf) { u32* w = reinterpret_cast<u32*>(p); for (int i = 0; i < 48; i++) w[i] = 0; return; }
+    store_be48(p, a.x.c0); store_be48(p + 48, a.x.c1); store_be48(p + 96, a.y.c0); store_be48(p + 144, a.y.c1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: pairing
+// ------------------------------------------------------------------------------------------------
+// Miller loop for one pair per tuple; f goes to the internal SoA buffer (or nowhere else).
+KERNEL k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;                                // tail lanes redo the last tuple
+    G1Aff p[1]; G2Aff q[1];
+    p[0] = load_g1(g1 + 96 * tt);
+    q[0] = load_g2(g2 + 192 * tt);
+    Fp12S f;
+    miller_loop<1>(f, p, q);
+    if (t < n) soa_store12(fbuf, n, t, f);
+}
+// mode 0: out = FE(f) as Montgomery-384 limbs; mode 1: out = f itself (no final exponentiation)
+KERNEL k_final_exp(const i32* fbuf, u64* out, size_t n, int mode) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;
+    Fp12S f = soa_load12(fbuf, n, tt);
+    if (mode == 0) final_exponentiation(f);
+    if (t < n) {
+        const FpS* c = reinterpret_cast<const FpS*>(&f);
+        for (int e = 0; e < 12; e++) store_m384(out + 72 * t + 6 * e, c[e]);
+    }
+}
+KERNEL k_fq12_from_m384(const u64* in, i32* fbuf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    for (int e = 0; e < 12; e++) soa_store(fbuf, n, t, e, load_m384(in + 72 * t + 6 * e));
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: unit-level ops for the parity tests
+// ------------------------------------------------------------------------------------------------
+template <int W> struct Rec { FpS e[W]; };
+template <int W> BLSMI_DEV Rec<W> rec_load(const u64* p, size_t t) { Rec<W> r; for (int i = 0; i < W; i++) r.e[i] = load_m384(p + (size_t)6 * (W * t + i)); return r; }
+template <int W> BLSMI_DEV void rec_store(u64* p, size_t t, const Rec<W>& r) { for (int i = 0; i < W; i++) store_m384(p + (size_t)6 * (W * t + i), r.e[i]); }
+template <class T, int W> BLSMI_DEV T& as(Rec<W>& r) { return *reinterpret_cast<T*>(&r); }
+
+KERNEL k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    const FpS x = load_m384(a + 6 * t);
+    FpS y = fp_zero();
+    if (op == BLSMI_OP_FQ_MUL || op == BLSMI_OP_FQ_ADD || op == BLSMI_OP_FQ_SUB) y = load_m384(b + 6 * t);
+    FpS r = fp_zero();
+    bool ok = true;
+    switch (op) {
+        case BLSMI_OP_FQ_MUL: r = fp_store(fp_mul(x, y)); break;
+        case BLSMI_OP_FQ_SQR: r = fp_store(fp_sqr(x)); break;
+        case BLSMI_OP_FQ_ADD: r = fp_store(fp_add(x, y)); break;
+        case BLSMI_OP_FQ_SUB: r = fp_store(fp_sub(x, y)); break;
+        case BLSMI_OP_FQ_NEG: r = fp_store(fp_neg(x)); break;
+        case BLSMI_OP_FQ_INV: r = fp_inv(x); ok = !fp_is_zero(x); break;
+        case BLSMI_OP_FQ_SQRT: r = fp_sqrt(x, ok); break;
+    }
+    store_m384(out + 6 * t, r);
+    if (flag) flag[t] = ok ? 1 : 0;
+}
+KERNEL k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<2> ra = rec_load<2>(a, t), rb = ra, ro;
+    if (op == BLSMI_OP_FQ2_MUL) rb = rec_load<2>(b, t);
+    const Fp2S x = as<Fp2S>(ra), y = as<Fp2S>(rb);
+    Fp2S r = fp2_zero();
+    bool ok = true;
+    switch (op) {
+        case BLSMI_OP_FQ2_MUL: r = fp2_store(fp2_mul(x, y)); break;
+        case BLSMI_OP_FQ2_SQR: r = fp2_store(fp2_sqr(x)); break;
+        case BLSMI_OP_FQ2_INV: r = fp2_store(fp2_inv(x)); ok = !fp2_is_zero(x); break;
+        case BLSMI_OP_FQ2_MUL_NR: r = fp2_store(fp2_mul_nr(x)); break;
+        case BLSMI_OP_FQ2_SQRT: r = fp2_sqrt(x, ok); break;
+    }
+    as<Fp2S>(ro) = r;
+    rec_store<2>(out, t, ro);
+    if (flag) flag[t] = ok ? 1 : 0;
+}
+KERNEL k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<6> ra = rec_load<6>(a, t), rb = ra, ro;
+    if (op == BLSMI_OP_FQ6_MUL) rb = rec_load<6>(b, t);
+    const Fp6S x = as<Fp6S>(ra), y = as<Fp6S>(rb);
+    Fp6S r = fp6_zero();
+    switch (op) {
+        case BLSMI_OP_FQ6_MUL: r = fp6_store(fp6_mul(x, y)); break;
+        case BLSMI_OP_FQ6_SQR: r = fp6_store(fp6_sqr(x)); break;
+        case BLSMI_OP_FQ6_INV: r = fp6_store(fp6_inv(x)); break;
+        case BLSMI_OP_FQ6_FROB1: r = fp6_store(fp6_frob<1>(x)); break;
+    }
+    as<Fp6S>(ro) = r;
+    rec_store<6>(out, t, ro);
+}
+KERNEL k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<12> ra = rec_load<12>(a, t), rb = ra, ro;
+    if (op == BLSMI_OP_FQ12_MUL) rb = rec_load<12>(b, t);
+    const Fp12S x = as<Fp12S>(ra), y = as<Fp12S>(rb);
+    Fp12S r = fp12_one();
+    switch (op) {
+        case BLSMI_OP_FQ12_MUL: r = fp12_store(fp12_mul(x, y)); break;
+        case BLSMI_OP_FQ12_SQR: r = fp12_store(fp12_sqr(x)); break;
+        case BLSMI_OP_FQ12_INV: r = fp12_store(fp12_inv(x)); break;
+        case BLSMI_OP_FQ12_FROB1: r = fp12_store(fp12_frob<1>(x)); break;
+        case BLSMI_OP_FQ12_FROB2: r = fp12_store(fp12_frob<2>(x)); break;
+        case BLSMI_OP_FQ12_FROB3: r = fp12_store(fp12_frob<3>(x)); break;
+        case BLSMI_OP_FQ12_CYCLO_SQR: r = fp12_cyclotomic_sqr(x); break;
+    }
+    as<Fp12S>(ro) = r;
+    rec_store<12>(out, t, ro);
+}
+// Jacobian points as 3 (G1) / 6 (G2) Fq records x,y,z; infinity <=> z == 0 (g1.go:293)
+template <class F, int W>
+BLSMI_DEV void debug_curve(int dbl, const u64* a, const u64* b, u64* out, size_t t) {
+    Rec<W> ra = rec_load<W>(a, t), rb = ra, ro;
+    if (!dbl) rb = rec_load<W>(b, t);
+    Jac<F> p, q, r;
+    p.x = reinterpret_cast<F*>(&ra)[0]; p.y = reinterpret_cast<F*>(&ra)[1]; p.z = reinterpret_cast<F*>(&ra)[2]; p.inf = f_is_zero(p.z) ? -1 : 0;
+    q.x = reinterpret_cast<F*>(&rb)[0]; q.y = reinterpret_cast<F*>(&rb)[1]; q.z = reinterpret_cast<F*>(&rb)[2]; q.inf = f_is_zero(q.z) ? -1 : 0;
+    r = dbl ? jac_double(p) : jac_add(p, q);
+    if (r.inf) r.z = field_consts<F>::zero();
+    reinterpret_cast<F*>(&ro)[0] = r.x; reinterpret_cast<F*>(&ro)[1] = r.y; reinterpret_cast<F*>(&ro)[2] = r.z;
+    rec_store<W>(out, t, ro);
+}
+KERNEL k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
+    else debug_curve<Fp2S, 6>(op == BLSMI_OP_G2_DOUBLE, a, b, out, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels: scalar multiplication, sums
+// ------------------------------------------------------------------------------------------------
+template <class F> BLSMI_DEV Aff<F> load_aff(const u8* p);
+template <> BLSMI_DEV G1Aff load_aff<FpS>(const u8* p) { return load_g1(p); }
+template <> BLSMI_DEV G2Aff load_aff<Fp2S>(const u8* p) { return load_g2(p); }
+BLSMI_DEV void store_aff(u8* p, const G1Aff& a) { store_g1(p, a); }
+BLSMI_DEV void store_aff(u8* p, const G2Aff& a) { store_g2(p, a); }
+
+template <class F, int PB>
+__device__ void mul_batch_body(const u8* pts, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;
+    const Aff<F> p = load_aff<F>(pts + (size_t)PB * tt);
+    const u32* s32 = reinterpret_cast<const u32*>(scalars + 32 * tt);
+    Jac<F> res = jac_zero<F>();
+    for (int w = 7; w >= 0; w--) {                                      // big-endian scalar: word 0 is most significant
+        const u32 kw = __builtin_bswap32(s32[7 - w]);
+        for (int i = 31; i >= 0; i--) {
+            res = jac_double(res);
+            const i32 bit = -(i32)((kw >> i) & 1);
+            const Jac<F> s = jac_add_affine(res, p);
+            res = jac_select(bit, s, res);
+        }
+    }
+    const Aff<F> a = jac_to_affine(res);
+    if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
+}
+KERNEL k_g1_mul(const u8* pts, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, scalars, out, out_inf, n); }
+KERNEL k_g2_mul(const u8* pts, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, scalars, out, out_inf, n); }
+
+// Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
+template <class F> struct jac_words { static constexpr int value = sizeof(F) / sizeof(FpS) * 3; };
+template <class F>
+BLSMI_DEV void jac_soa_store(i32* buf, size_t n, size_t t, const Jac<F>& p) {
+    constexpr int W = jac_words<F>::value;
+    const FpS* c = reinterpret_cast<const FpS*>(&p);
+#pragma unroll
+    for (int e = 0; e < W; e++) soa_store(buf, n, t, e, c[e]);
+    buf[(size_t)W * NL * n + t] = p.inf;
+}
+template <class F>
+BLSMI_DEV Jac<F> jac_soa_load(const i32* buf, size_t n, size_t t) {
+    constexpr int W = jac_words<F>::value;
+    Jac<F> p;
+    FpS* c = reinterpret_cast<FpS*>(&p);
+#pragma unroll
+    for (int e = 0; e < W; e++) c[e] = soa_load(buf, n, t, e);
+    p.inf = buf[(size_t)W * NL * n + t];
+    return p;
+}
+template <class F, int PB>
+__device__ void sum_level0_body(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= half) return;
+    Aff<F> a = load_aff<F>(pts + (size_t)PB * t);
+    if (in_inf && in_inf[t]) a.inf = -1;
+    Jac<F> r = to_jac(a);
+    if (t + half < n) {
+        Aff<F> b = load_aff<F>(pts + (size_t)PB * (t + half));
+        if (in_inf && in_inf[t + half]) b.inf = -1;
+        r = jac_add_affine(r, b);
+    }
+    jac_soa_store(buf, half, t, r);
+}
+KERNEL k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<FpS, 96>(pts, in_inf, buf, n, half); }
+KERNEL k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<Fp2S, 192>(pts, in_inf, buf, n, half); }
+template <class F>
+__device__ void sum_level_body(const i32* src, i32* dst, size_t n, size_t half) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= half) return;
+    Jac<F> r = jac_soa_load<F>(src, n, t);
+    if (t + half < n) r = jac_add(r, jac_soa_load<F>(src, n, t + half));
+    jac_soa_store(dst, half, t, r);
+}
+KERNEL k_g1_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<FpS>(src, dst, n, half); }
+KERNEL k_g2_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<Fp2S>(src, dst, n, half); }
+template <class F, int PB>
+__device__ void sum_final_body(const i32* src, u8* out, i32* out_inf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Aff<F> a = jac_to_affine(jac_soa_load<F>(src, 1, 0));
+    store_aff(out, a);
+    *out_inf = a.inf ? 1 : 0;
+}
+KERNEL k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<FpS, 96>(src, out, out_inf); }
+KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
+
+#include "verify_kernels.inc"
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_mu;
+bool g_ready = false;
+int g_device = 0;
+hipStream_t g_stream = nullptr;
+char g_version[160] = "blsmi 0.1 (uninitialised)";
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
+
+int ensure_init(int device) {
+    if (g_ready) return BLSMI_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
+    if (device < 0 || device >= count) return BLSMI_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(g_version, sizeof g_version, "blsmi 0.1 %s CUs=%d", prop.gcnArchName, prop.multiProcessorCount);
+    g_device = device;
+    g_ready = true;
+    return BLSMI_OK;
+}
+inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
+
+// RAII device buffer
+struct DBuf {
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DBuf() { if (p) (void)hipFree(p); }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+}  // namespace
+
+#define LOCK_AND_INIT() std::lock_guard<std::mutex> lk_(g_mu); { int rc_ = ensure_init(g_device); if (rc_) return rc_; }
+
+#define BLSMI_API extern "C" __attribute__((visibility("default")))
+
+BLSMI_API int blsmi_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ready && device != g_device) return BLSMI_E_ARG;
+    return ensure_init(device);
+}
+BLSMI_API void blsmi_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ready) return;
+    (void)hipStreamSynchronize(g_stream);
+    (void)hipStreamDestroy(g_stream);
+    g_stream = nullptr;
+    g_ready = false;
+}
+BLSMI_API const char* blsmi_version(void) { return g_version; }
+
+// ---- pairing ------------------------------------------------------------------------------------
+static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
+    if (n == 0) return BLSMI_OK;
+    DBuf f;
+    HIPCHK(f.alloc(sizeof(i32) * 12 * NL * n));
+    hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f.as<i32>(), n);
+    hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, f.as<i32>(), (u64*)d_out, n, mode);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));      // the scratch buffer dies with this scope
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_pairing_batch_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, void* stream) {
+    if (n && (!d_g1 || !d_g2 || !d_out)) return BLSMI_E_ARG;
+    LOCK_AND_INIT();
+    return pairing_dev(d_g1, d_g2, d_out, n, stream ? (hipStream_t)stream : g_stream, 0);
+}
+static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n, int mode) {
+    if (n && (!g1 || !g2 || !out)) return BLSMI_E_ARG;
+    LOCK_AND_INIT();
+    if (n == 0) return BLSMI_OK;
+    DBuf a, b, o;
+    HIPCHK(a.alloc(96 * n)); HIPCHK(b.alloc(192 * n)); HIPCHK(o.alloc(576 * n));
+    HIPCHK(hipMemcpyAsync(a.p, g1, 96 * n, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(b.p, g2, 192 * n, hipMemcpyHostToDevice, g_stream));
+    int rc = pairing_dev(a.p, b.p, o.p, n, g_stream, mode);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, o.p, 576 * n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_pairing_batch(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n) { return pairing_host(g1, g2, out, n, 0); }
+BLSMI_API int blsmi_miller_loop_batch(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n) { return pairing_host(g1, g2, out, n, 1); }
+BLSMI_API int blsmi_final_exponentiation_batch(const uint64_t* in, uint64_t* out, size_t n) {
+    if (n && (!in || !out)) return BLSMI_E_ARG;
+    LOCK_AND_INIT();
+    if (n == 0) return BLSMI_OK;
+    DBuf i, f, o;
+    HIPCHK(i.alloc(576 * n)); HIPCHK(o.alloc(576 * n)); HIPCHK(f.alloc(sizeof(i32) * 12 * NL * n));
+    HIPCHK(hipMemcpyAsync(i.p, in, 576 * n, hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(k_fq12_from_m384, dim3(nblocks(n)), dim3(WG), 0, g_stream, i.as<u64>(), f.as<i32>(), n);
+    hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, g_stream, f.as<i32>(), o.as<u64>(), n, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, o.p, 576 * n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return BLSMI_OK;
+}
+
+// ---- unit-level ops -------------------------------------------------------------------------------
+BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flag, size_t n) {
+    int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) ? 3 : 6;
+    if (n && (!a || !out)) return BLSMI_E_ARG;
+    LOCK_AND_INIT();
+    if (n == 0) return BLSMI_OK;
+    const size_t bytes = (size_t)48 * width * n;
+    DBuf da, db, dout, dflag;
+    HIPCHK(da.alloc(bytes)); HIPCHK(db.alloc(bytes)); HIPCHK(dout.alloc(bytes)); HIPCHK(dflag.alloc(n));
+    HIPCHK(hipMemcpyAsync(da.p, a, bytes, hipMemcpyHostToDevice, g_stream));
+    if (b) HIPCHK(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemsetAsync(dflag.p, 1, n, g_stream));
+    dim3 g(nblocks(n)), w(WG);
+    if (op < 16) hipLaunchKernelGGL(k_debug_fq, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
+    else if (op < 32) hipLaunchKernelGGL(k_debug_fq2, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
+    else if (op < 48) hipLaunchKernelGGL(k_debug_fq6, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
+    else if (op < 64) hipLaunchKernelGGL(k_debug_fq12, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
+    else hipLaunchKernelGGL(k_debug_curve, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, g_stream));
+    if (flag) HIPCHK(hipMemcpyAsync(flag, dflag.p, n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return BLSMI_OK;
+}
+
+// ---- scalar multiplication / sums ----------------------------------------------------------------
+template <int PB, class K>
+static int mul_batch(K kernel, const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
+    if (n && (!pts || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
+    LOCK_AND_INIT();
+    if (n == 0) return BLSMI_OK;
+    DBuf dp, ds, dout, dinf;
+    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
+    HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)PB * n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(out_inf, dinf.p, n, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, pts, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, pts, scalars, out, out_inf, n); }
+
+// tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
+template <int PB, int W, class K0, class K1, class K2>
+static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, size_t n, u8* d_out, i32* d_out_inf, hipStream_t s) {
+    const size_t words = (size_t)W * NL + 1;
+    size_t half = (n + 1) / 2;
+    DBuf b0, b1;
+    HIPCHK(b0.alloc(sizeof(i32) * words * half)); HIPCHK(b1.alloc(sizeof(i32) * words * ((half + 1) / 2)));
+    hipLaunchKernelGGL(k0, dim3(nblocks(half)), dim3(WG), 0, s, d_pts, d_inf, b0.as<i32>(), n, half);
+    i32* src = b0.as<i32>(); i32* dst = b1.as<i32>();
+    size_t cur = half;
+    while (cur > 1) {
+        const size_t h = (cur + 1) / 2;
+        hipLaunchKernelGGL(k1, dim3(nblocks(h)), dim3(WG), 0, s, (const i32*)src, dst, cur, h);
+        std::swap(src, dst);
+        cur = h;
+    }
+    hipLaunchKernelGGL(kfinal, dim3(1), dim3(WG), 0, s, (const i32*)src, d_out, d_out_inf);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return BLSMI_OK;
+}
+template <int PB, int W, class K0, class K1, class K2>
+static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t* out, int* out_inf) {
+    if (!out || !out_inf || (n && !pts)) return BLSMI_E_ARG;
+    if (n == 0) { memset(out, 0, PB); *out_inf = 1; return BLSMI_OK; }      // empty sum = infinity (g2pubs/bls.go:166, 181)
+    LOCK_AND_INIT();
+    DBuf dp, di, dout, dflag;
+    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(di.alloc(n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
+    HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
+    if (in_inf) HIPCHK(hipMemcpyAsync(di.p, in_inf, n, hipMemcpyHostToDevice, g_stream));
+    int rc = sum_dev<PB, W>(k0, k1, kfinal, dp.as<u8>(), in_inf ? di.as<u8>() : nullptr, n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    if (rc) return rc;
+    i32 flag = 0;
+    HIPCHK(hipMemcpy(out, dout.p, PB, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost));
+    *out_inf = flag;
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_g1_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[96], int* out_inf) { return sum_host<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, in_inf, n, out, out_inf); }
+BLSMI_API int blsmi_g2_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[192], int* out_inf) { return sum_host<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, in_inf, n, out, out_inf); }
+
+#include "verify_host.inc"
+

@@ -1,0 +1,138 @@
+// curve.cuh -- Jacobian group law on E: y^2 = x^3 + 4 (G1, over Fq) and E': y^2 = x^3 + 4(1+u)
+// (G2, over Fq2), one point per lane.  Same formulas and special cases as the reference
+// (g1.go:343-585, g2.go:389-632): dbl-2009-l, add-2007-bl, madd-2007-bl, MSB-first double-and-add.
+// Infinity is z == 0 exactly as in the reference (g1.go:293, g2.go:331); because lazily reduced
+// values have several representations of 0, an explicit all-ones/zero `inf` mask travels with every
+// point instead of re-testing z.
+#pragma once
+#include "tower.cuh"
+
+namespace blsmi {
+
+template <class F> struct Jac { F x, y, z; i32 inf; };    // F = FpS (G1) or Fp2S (G2); inf = -1 / 0
+template <class F> struct Aff { F x, y; i32 inf; };
+using G1Jac = Jac<FpS>; using G1Aff = Aff<FpS>;
+using G2Jac = Jac<Fp2S>; using G2Aff = Aff<Fp2S>;
+
+template <class F> BLSMI_DEV Jac<F> jac_zero() {                     // g1.go:275, g2.go:313: (0, 1, 0)
+    Jac<F> p; p.x = field_consts<F>::zero(); p.y = field_consts<F>::one(); p.z = field_consts<F>::zero(); p.inf = -1; return p;
+}
+template <class F> BLSMI_DEV Jac<F> to_jac(const Aff<F>& a) {        // g1.go:59-64, g2.go:70-76
+    Jac<F> p; p.x = a.x; p.y = a.y; p.z = field_consts<F>::one(); p.inf = a.inf;
+    return p;
+}
+template <class F> BLSMI_DEV Jac<F> jac_select(i32 m, const Jac<F>& a, const Jac<F>& b) {
+    Jac<F> r; r.x = f_select(m, a.x, b.x); r.y = f_select(m, a.y, b.y); r.z = f_select(m, a.z, b.z); r.inf = (a.inf & m) | (b.inf & ~m); return r;
+}
+
+// g1.go:343-397 / g2.go:389-443.  Doubling infinity returns infinity (z stays 0: nz = 2*y*z).
+template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g) {
+    const F a = f_store(f_sqr(g.x));
+    const F b = f_store(f_sqr(g.y));
+    const F c = f_store(f_sqr(b));
+    const F d = f_store(f_dbl(f_sub(f_sub(f_sqr(f_add(g.x, b)), a), c)));
+    const F e = f_store(f_muls<3>(a));
+    const auto f = f_sqr(e);
+    Jac<F> r;
+    r.z = f_store(f_dbl(f_mul(g.z, g.y)));
+    r.x = f_store(f_sub(f_sub(f, d), d));
+    r.y = f_store(f_sub(f_mul(f_sub(d, r.x), e), f_muls<8>(c)));
+    r.inf = g.inf;
+    return r;
+}
+
+// g1.go:485-559 / g2.go:532-606 (mixed addition).  Special cases as the reference:
+// g infinite -> o; o infinite -> g; same point -> double; opposite points -> z3 = 0 (infinity).
+template <class F> __device__ __noinline__ Jac<F> jac_add_affine(const Jac<F>& g, const Aff<F>& o) {
+    const F z1z1 = f_store(f_sqr(g.z));
+    const F u2 = f_store(f_mul(o.x, z1z1));
+    const F s2 = f_store(f_mul(f_mul(o.y, g.z), z1z1));
+    const F h = f_store(f_sub(u2, g.x));
+    const F rr0 = f_store(f_sub(s2, g.y));
+    const bool h0 = f_is_zero(h);
+    const bool live = (g.inf == 0) & (o.inf == 0);
+    const F hh = f_store(f_sqr(h));
+    const F i = f_store(f_muls<4>(hh));
+    const F j = f_store(f_mul(h, i));
+    const F rr = f_store(f_dbl(rr0));
+    const F v = f_store(f_mul(g.x, i));
+    Jac<F> r;
+    r.x = f_store(f_sub(f_sub(f_sub(f_sqr(rr), j), v), v));
+    r.y = f_store(f_sub(f_mul(f_sub(v, r.x), rr), f_dbl(f_mul(g.y, j))));
+    r.z = f_store(f_sub(f_sub(f_sqr(f_add(g.z, h)), z1z1), hh));
+    r.inf = 0;
+    if (h0 & live) {                                                   // rare: same x
+        if (f_is_zero(rr0)) r = jac_double(g);                         // same point (g1.go:506-509)
+        else r.inf = -1;                                               // opposite points: z3 == 0
+    }
+    r = jac_select(g.inf, to_jac(o), r);                               // g1.go:486-488
+    r = jac_select(o.inf & ~g.inf, g, r);                              // g1.go:489-491
+    return r;
+}
+
+// g1.go:400-482 / g2.go:446-529 (general addition)
+template <class F> __device__ __noinline__ Jac<F> jac_add(const Jac<F>& g, const Jac<F>& o) {
+    const F z1z1 = f_store(f_sqr(g.z));
+    const F z2z2 = f_store(f_sqr(o.z));
+    const F u1 = f_store(f_mul(g.x, z2z2));
+    const F u2 = f_store(f_mul(o.x, z1z1));
+    const F s1 = f_store(f_mul(f_mul(g.y, o.z), z2z2));
+    const F s2 = f_store(f_mul(f_mul(o.y, g.z), z1z1));
+    const F h = f_store(f_sub(u2, u1));
+    const F rr0 = f_store(f_sub(s2, s1));
+    const bool h0 = f_is_zero(h);
+    const bool live = (g.inf == 0) & (o.inf == 0);
+    const F i = f_store(f_sqr(f_dbl(h)));
+    const F j = f_store(f_mul(h, i));
+    const F rr = f_store(f_dbl(rr0));
+    const F v = f_store(f_mul(u1, i));
+    Jac<F> r;
+    r.x = f_store(f_sub(f_sub(f_sub(f_sqr(rr), j), v), v));
+    r.y = f_store(f_sub(f_mul(f_sub(v, r.x), rr), f_dbl(f_mul(s1, j))));
+    r.z = f_store(f_mul(f_sub(f_sub(f_sqr(f_add(g.z, o.z)), z1z1), z2z2), h));
+    r.inf = 0;
+    if (h0 & live) {
+        if (f_is_zero(rr0)) r = jac_double(g);
+        else r.inf = -1;
+    }
+    r = jac_select(g.inf, o, r);
+    r = jac_select(o.inf & ~g.inf, g, r);
+    return r;
+}
+
+// g1.go:322-340 / g2.go:365-386
+template <class F> __device__ __noinline__ Aff<F> jac_to_affine(const Jac<F>& g) {
+    const F zi = f_inv(g.z);
+    const F zi2 = f_store(f_sqr(zi));
+    Aff<F> a;
+    a.x = f_store(f_mul(g.x, zi2));
+    a.y = f_store(f_mul(f_mul(g.y, zi2), zi));
+    a.inf = g.inf;
+    return a;
+}
+template <class F> BLSMI_DEV Aff<F> aff_neg(const Aff<F>& a) { Aff<F> r; r.x = a.x; r.y = f_store(f_neg(a.y)); r.inf = a.inf; return r; }
+
+// MSB-first double-and-add over a 256-bit scalar held as 8 little-endian u32 words per lane
+// (g1.go:67-90, g2.go:79-115).  The reference starts at BitLen(scalar); leading zero bits double the
+// point at infinity, which is a no-op, so iterating all 256 bits gives the same point.
+template <class F> BLSMI_DEV Jac<F> aff_mul_u256(const Aff<F>& p, const u32 k[8]) {
+    Jac<F> res = jac_zero<F>();
+    for (int i = 255; i >= 0; i--) {
+        res = jac_double(res);
+        const i32 bit = -(i32)((k[i >> 5] >> (i & 31)) & 1);
+        const Jac<F> t = jac_add_affine(res, p);
+        res = jac_select(bit, t, res);
+    }
+    return res;
+}
+// multiplication by a public 64-bit constant (ClearH, hash.go:306-309: |x| = 0xd201000000010000)
+template <class F> BLSMI_DEV Jac<F> aff_mul_u64_public(const Aff<F>& p, u64 k) {
+    Jac<F> res = to_jac(p);
+    for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
+        res = jac_double(res);
+        if ((k >> i) & 1) res = jac_add_affine(res, p);
+    }
+    return res;
+}
+
+}  // namespace blsmi

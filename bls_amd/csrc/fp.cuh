@@ -1,0 +1,419 @@
+// fp.cuh -- Fq arithmetic for BLS12-381 on gfx950 (CDNA4), one field element per lane.
+//
+// Replaces, on the device, the reference's L0-L2 layers: MultiplyFQRepr / MontReduce
+// (stub_fallback.go:11-116, primitivefuncs_amd64.s), FQRepr (fqrepr.go) and FQ (fq.go:37-338).
+//
+// MI355X-first representation (NOT the reference's 6 x u64 saturated limbs):
+//   * 15 signed limbs of 27 bits in int32 VGPRs, Montgomery form with R = 2^405.
+//   * products are accumulated column-wise in one int64 accumulator with v_mad_i64_i32.  A column
+//     holds 15 a_i*b_j and 15 m_i*q_j terms; with 27-bit limbs that is 15*(La*Lb+1)*2^54 < 2^63 for
+//     La*Lb <= 33, so there is NO carry chain anywhere in a multiplication.  On gfx950 every
+//     VALU->SGPR->VALU carry hop costs wait states (profiles/r01_ubench*.log): saturated 32-bit
+//     limbs with v_addc chains are the slow design here, v_mad_u64/i64 issues at the plain VALU rate.
+//   * add/sub/neg are 15 independent VALU ops; limbs may grow ("lazy") and are brought back by a
+//     carry-free parallel normalisation.  How far a value may grow is tracked in the TYPE:
+//     Fp<L,V> promises |limb| <= L*(2^27+64) and |value| <= V*q.  Every operation computes its
+//     result bound at compile time and static_asserts the int64/int32 head-room, so a formula that
+//     could overflow does not compile.  R/q = 2^24.3 leaves so much room that values never need
+//     reducing inside the pairing; Montgomery products come back to |value| < 2q by themselves.
+//   * results are made canonical ([0,q), the reference's invariant fq.go:41-45) only where they
+//     leave the device or are compared; canonical values re-packed to 6 x u64 with R = 2^384 are
+//     bit-identical to the reference's in-memory FQ.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace blsmi {
+
+typedef int32_t i32;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef uint8_t u8;
+
+constexpr int NL = 15;                 // limbs
+constexpr int LB = 27;                 // bits per limb
+constexpr i32 MASK = (1 << LB) - 1;
+constexpr int LMAX = 15;               // L*(2^27+64) < 2^31
+constexpr int LPROD_MAX = 33;          // 15*(La*Lb+1)*2^54*(1+eps) < 2^63  <=>  La*Lb <= 33
+constexpr int VPROD_MAX = 1 << 23;     // |a*b|/R <= 2^23 q^2 / 2^405 < 0.41 q: products land in (-0.41q, 1.41q)
+constexpr int VMAX = 1 << 12;          // top limb = value/2^378 stays far inside int32
+#define BLSMI_DEV __device__ __forceinline__
+
+template <int L_, int V_>
+struct Fp {
+    static constexpr int L = L_, V = V_;
+    i32 v[NL];
+};
+using FpS = Fp<1, 128>;                // storage type: (near-)normalised limbs, |value| <= 128 q
+using FpC = Fp<1, 1>;                  // canonical: limbs in [0,2^27), value in [0,q)
+
+}  // namespace blsmi
+#include "tower_fwd.cuh"
+#include "consts.cuh"
+namespace blsmi {
+
+// widen the promised bounds (never narrows)
+template <int L2, int V2, int L, int V>
+BLSMI_DEV Fp<L2, V2> fp_relabel(const Fp<L, V>& a) {
+    static_assert(L2 >= L && V2 >= V, "relabel may only widen bounds");
+    Fp<L2, V2> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = a.v[i];
+    return r;
+}
+
+// Carry-free parallel normalisation: every limb keeps its low 27 bits and receives the (signed)
+// overflow of the limb below.  Value unchanged; limbs 0..13 end in [-16, 2^27+16), top limb signed.
+template <int L, int V>
+BLSMI_DEV Fp<1, V> fp_norm(const Fp<L, V>& x) {
+    static_assert(L <= LMAX, "limb bound exceeded before norm");
+    Fp<1, V> r;
+    if constexpr (L == 1) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = x.v[i];
+    } else {
+        r.v[0] = x.v[0] & MASK;
+#pragma unroll
+        for (int i = 1; i < NL - 1; i++) r.v[i] = (x.v[i] & MASK) + (x.v[i - 1] >> LB);
+        r.v[NL - 1] = x.v[NL - 1] + (x.v[NL - 2] >> LB);
+    }
+    return r;
+}
+template <bool C, int L, int V>
+BLSMI_DEV auto fp_norm_if(const Fp<L, V>& x) {
+    if constexpr (C) return fp_norm(x); else return x;
+}
+
+// ---- add / sub / neg / small multiples: 15 independent VALU ops (fq.go:64-67, 82-87, 121-143) ----
+template <int La, int Va, int Lb, int Vb>
+BLSMI_DEV auto fp_add(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+    if constexpr (La + Lb > LMAX) {
+        if constexpr (La >= Lb) return fp_add(fp_norm(a), fp_norm_if<(1 + Lb > LMAX)>(b));
+        else return fp_add(fp_norm_if<(La + 1 > LMAX)>(a), fp_norm(b));
+    } else {
+        static_assert(Va + Vb <= VMAX, "value bound exceeded: insert fp_reduce");
+        Fp<La + Lb, Va + Vb> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = a.v[i] + b.v[i];
+        return r;
+    }
+}
+template <int La, int Va, int Lb, int Vb>
+BLSMI_DEV auto fp_sub(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+    if constexpr (La + Lb > LMAX) {
+        if constexpr (La >= Lb) return fp_sub(fp_norm(a), fp_norm_if<(1 + Lb > LMAX)>(b));
+        else return fp_sub(fp_norm_if<(La + 1 > LMAX)>(a), fp_norm(b));
+    } else {
+        static_assert(Va + Vb <= VMAX, "value bound exceeded: insert fp_reduce");
+        Fp<La + Lb, Va + Vb> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = a.v[i] - b.v[i];
+        return r;
+    }
+}
+template <int L, int V>
+BLSMI_DEV Fp<L, V> fp_neg(const Fp<L, V>& a) {
+    Fp<L, V> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = -a.v[i];
+    return r;
+}
+template <int K, int L, int V>
+BLSMI_DEV auto fp_muls(const Fp<L, V>& a) {     // multiply by a small positive constant K
+    if constexpr (L * K > LMAX) return fp_muls<K>(fp_norm(a));
+    else {
+        static_assert(V * K <= VMAX, "value bound exceeded: insert fp_reduce");
+        Fp<L * K, V * K> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = a.v[i] * K;
+        return r;
+    }
+}
+template <int L, int V> BLSMI_DEV auto fp_dbl(const Fp<L, V>& a) { return fp_muls<2>(a); }
+
+// ---- Montgomery multiplication (fq.go:70-79 = MultiplyFQRepr + MontReduce + reduceAssign) ----------
+// Product-scanning: column k accumulates a_i*b_(k-i) and m_i*q_(k-i) in ONE int64 (v_mad_i64_i32),
+// m_k = -acc/q mod 2^27 zeroes the low limb, the column is retired by an arithmetic shift.
+// Output: limbs 0..13 in [0,2^27), signed top limb, value in (-0.41q, 1.41q) (|value| <= 2q).
+// Kept out of line (vector-typed arguments travel in VGPRs v0-v29): the ~4 KB body stays hot in
+// the instruction cache while tower code shrinks to call sequences.
+typedef i32 vlimbs __attribute__((ext_vector_type(15)));
+
+__device__ __noinline__ vlimbs fp_mul_core(vlimbs a, vlimbs b) {
+    i32 m[NL];
+    vlimbs r;
+    i64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (i64)a[i] * b[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * C_Q[k - i];
+        m[k] = (i32)((u32)(i32)acc * BLSMI_QINV) & MASK;
+        acc += (i64)m[k] * C_Q[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (i64)a[i] * b[k - i];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C_Q[k - i];
+        r[k - NL] = (i32)acc & MASK;
+        acc >>= LB;
+    }
+    r[NL - 1] = (i32)acc;
+    return r;
+}
+// Squaring (fq.go:151-198): off-diagonal products once, against the doubled operand.
+__device__ __noinline__ vlimbs fp_sqr_core(vlimbs a) {
+    i32 m[NL], a2[NL];
+    vlimbs r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) a2[i] = a[i] * 2;
+    i64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (i64)a[i] * a2[k - i];
+        if (k % 2 == 0) acc += (i64)a[k / 2] * a[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (i64)m[i] * C_Q[k - i];
+        m[k] = (i32)((u32)(i32)acc * BLSMI_QINV) & MASK;
+        acc += (i64)m[k] * C_Q[0];
+        acc >>= LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; 2 * i < k; i++) acc += (i64)a[i] * a2[k - i];
+        if (k % 2 == 0) acc += (i64)a[k / 2] * a[k / 2];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (i64)m[i] * C_Q[k - i];
+        r[k - NL] = (i32)acc & MASK;
+        acc >>= LB;
+    }
+    r[NL - 1] = (i32)acc;
+    return r;
+}
+
+template <int La, int Va, int Lb, int Vb>
+BLSMI_DEV auto fp_mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
+    if constexpr (La * Lb > LPROD_MAX) {
+        if constexpr (La >= Lb) return fp_mul(fp_norm(a), b);
+        else return fp_mul(a, fp_norm(b));
+    } else {
+        static_assert((long long)Va * Vb <= VPROD_MAX, "operand values too large for Montgomery: reduce one first");
+        vlimbs x, y;
+#pragma unroll
+        for (int i = 0; i < NL; i++) { x[i] = a.v[i]; y[i] = b.v[i]; }
+        vlimbs z = fp_mul_core(x, y);
+        Fp<1, 2> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = z[i];
+        return r;
+    }
+}
+template <int L, int V>
+BLSMI_DEV auto fp_sqr(const Fp<L, V>& a) {
+    if constexpr (2 * L * L > LPROD_MAX) return fp_sqr(fp_norm(a));
+    else {
+        static_assert((long long)V * V <= VPROD_MAX, "operand value too large for Montgomery: reduce first");
+        vlimbs x;
+#pragma unroll
+        for (int i = 0; i < NL; i++) x[i] = a.v[i];
+        vlimbs z = fp_sqr_core(x);
+        Fp<1, 2> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.v[i] = z[i];
+        return r;
+    }
+}
+
+// ---- value reduction: subtract round(value/q)*q with exact carries -> value in (-1.01q, 2.01q) ------
+// The quotient is estimated in fp32 from the two top limbs (value / 2^351).
+template <int L, int V>
+BLSMI_DEV Fp<1, 3> fp_reduce(const Fp<L, V>& x) {
+    static_assert(V <= VMAX, "value bound exceeded");
+    Fp<1, V> y = fp_norm(x);
+    const float top = (float)y.v[NL - 1] * 134217728.0f + (float)y.v[NL - 2];
+    const i32 k = (i32)floorf(top * BLSMI_Q_TOP2_INV);
+    Fp<1, 3> r;
+    i64 c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        c += (i64)y.v[i] - (i64)k * C_Q[i];
+        r.v[i] = (i32)c & MASK;
+        c >>= LB;
+    }
+    c += (i64)y.v[NL - 1] - (i64)k * C_Q[NL - 1];
+    r.v[NL - 1] = (i32)c;
+    return r;
+}
+// bring any value into the storage type with the least work
+template <int L, int V>
+BLSMI_DEV FpS fp_store(const Fp<L, V>& x) {
+    if constexpr (V > FpS::V) return fp_relabel<1, FpS::V>(fp_reduce(x));
+    else return fp_relabel<1, FpS::V>(fp_norm(x));
+}
+
+// ---- canonical form [0,q) with limbs in [0,2^27) (the reference's invariant, fq.go:41-45) --------
+// one exact pass adding (addq ? q : 0) - (subq ? q : 0); masks are all-ones / zero
+BLSMI_DEV void limbs_addsub_q(const i32 in[NL], i32 out[NL], i32 addmask, i32 submask) {
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const i32 s = in[i] + (C_Q[i] & addmask) - (C_Q[i] & submask) + c;
+        out[i] = (i < NL - 1) ? (s & MASK) : s;
+        c = s >> LB;
+    }
+}
+template <int L, int V>
+BLSMI_DEV FpC fp_canon(const Fp<L, V>& x) {
+    Fp<1, 3> r = fp_reduce(x);                            // limbs 0..13 in [0,2^27), value in (-1.01q, 2.01q)
+    i32 t[NL], d[NL];
+    limbs_addsub_q(r.v, t, r.v[NL - 1] >> 31, 0);          // + q if negative  -> [0, 2.01q)
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {                // - q while >= q (at most twice)
+        limbs_addsub_q(t, d, 0, -1);
+        const i32 lt = d[NL - 1] >> 31;                    // all-ones iff t < q
+#pragma unroll
+        for (int i = 0; i < NL; i++) t[i] = (t[i] & lt) | (d[i] & ~lt);
+    }
+    FpC o;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o.v[i] = t[i];
+    return o;
+}
+template <int L, int V>
+BLSMI_DEV bool fp_is_zero(const Fp<L, V>& x) {            // fq.go:146-148
+    FpC c = fp_canon(x);
+    i32 o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o |= c.v[i];
+    return o == 0;
+}
+template <int La, int Va, int Lb, int Vb>
+BLSMI_DEV bool fp_eq(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) { return fp_is_zero(fp_sub(a, b)); }   // fq.go:116-118
+
+// lane-wise select without v_cndmask: r = m ? a : b with m all-ones / zero
+template <int L, int V>
+BLSMI_DEV Fp<L, V> fp_select(i32 m, const Fp<L, V>& a, const Fp<L, V>& b) {
+    Fp<L, V> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = (a.v[i] & m) | (b.v[i] & ~m);
+    return r;
+}
+BLSMI_DEV FpS fp_zero() {
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = 0;
+    return r;
+}
+BLSMI_DEV FpS fp_one() { return C_ONE; }
+
+// ---- exponentiation by a fixed public exponent (fq.go:96-113), bits MSB-first from constant memory.
+// The loop is rolled: two call sites, uniform control flow (the exponent is the same for all lanes).
+__device__ __noinline__ vlimbs fp_pow_core(vlimbs a, const u32* ebits, int nbits) {
+    vlimbs res = a;                                        // top bit is always 1
+    for (int i = nbits - 2; i >= 0; i--) {
+        res = fp_sqr_core(res);
+        if ((ebits[i >> 5] >> (i & 31)) & 1) res = fp_mul_core(res, a);
+    }
+    return res;
+}
+template <int L, int V>
+BLSMI_DEV FpS fp_pow_const(const Fp<L, V>& a, const u32* ebits, int nbits) {
+    const FpS base = fp_store(a);                          // L = 1, |value| <= 128 q: products stay valid
+    vlimbs x;
+#pragma unroll
+    for (int i = 0; i < NL; i++) x[i] = base.v[i];
+    const vlimbs z = fp_pow_core(x, ebits, nbits);
+    FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = z[i];
+    return r;
+}
+// Inverse (fq.go:224-266 computes it with a data-dependent binary GCD; the value is the modular
+// inverse, obtained here divergence-free as a^(q-2)).  inverse(0) = 0 (the reference reports failure).
+template <int L, int V>
+BLSMI_DEV FpS fp_inv(const Fp<L, V>& a) { return fp_pow_const(a, C_QM2, BLSMI_QM2_BITS); }
+
+// Square root (fq.go:203-217): a1 = a^((q-3)/4); a0 = a1^2 a; ok iff a0 != -1; root = a1*a.
+template <int L, int V>
+BLSMI_DEV FpS fp_sqrt(const Fp<L, V>& a, bool& ok) {
+    const FpS as = fp_store(a);
+    const FpS a1 = fp_pow_const(as, C_QM3O4, BLSMI_QM3O4_BITS);
+    const auto a0 = fp_mul(fp_sqr(a1), as);
+    ok = !fp_eq(a0, C_NEGONE);
+    return fp_store(fp_mul(a1, as));
+}
+
+// ---- representation changes at the device boundary --------------------------------------------------
+// 12 little-endian u32 words (a 384-bit integer) <-> 15 x 27-bit limbs
+BLSMI_DEV void words_to_limbs(const u32 w[12], i32 l[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int bit = LB * i, j = bit >> 5, sh = bit & 31;
+        u32 x = (j < 12) ? (w[j] >> sh) : 0u;
+        if (sh > 32 - LB && j + 1 < 12) x |= w[j + 1] << (32 - sh);
+        l[i] = (i32)(x & (u32)MASK);
+    }
+}
+BLSMI_DEV void limbs_to_words(const i32 l[NL], u32 w[12]) {   // limbs must be canonical (non-negative, < 2^27)
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const int bit = 32 * j, i = bit / LB, sh = bit % LB;
+        u32 x = (u32)l[i] >> sh;
+        if (i + 1 < NL) x |= (u32)l[i + 1] << (LB - sh);
+        if (2 * LB - sh < 32 && i + 2 < NL) x |= (u32)l[i + 2] << (2 * LB - sh);
+        w[j] = x;
+    }
+}
+// normal-form integer (raw limbs, must be < q else it becomes 0 like FQReprToFQ fq.go:49-56) -> Montgomery
+BLSMI_DEV FpS fp_from_words(const u32 w[12]) {
+    Fp<1, 1> raw;
+    words_to_limbs(w, raw.v);
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) c = (raw.v[i] - C_Q[i] + c) >> LB;
+    const i32 valid = c;                                   // all-ones iff raw < q (raw - q borrows)
+#pragma unroll
+    for (int i = 0; i < NL; i++) raw.v[i] &= valid;
+    return fp_relabel<1, FpS::V>(fp_mul(raw, C_R2));
+}
+// Montgomery -> canonical normal-form integer words
+template <int L, int V>
+BLSMI_DEV void fp_to_words(const Fp<L, V>& a, u32 w[12]) {
+    FpC c = fp_canon(fp_mul(fp_store(a), C_RAW_ONE));
+    limbs_to_words(c.v, w);
+}
+// Montgomery(2^405) -> the reference's in-memory FQ image: canonical x*2^384 mod q as 12 LE u32 (= 6 LE u64)
+template <int L, int V>
+BLSMI_DEV void fp_to_mont384_words(const Fp<L, V>& a, u32 w[12]) {
+    FpC c = fp_canon(fp_mul(fp_store(a), C_TO_M384));
+    limbs_to_words(c.v, w);
+}
+BLSMI_DEV FpS fp_from_mont384_words(const u32 w[12]) {
+    Fp<1, 10> raw;                                         // a 384-bit word may exceed q (2^384 < 10 q)
+    words_to_limbs(w, raw.v);
+    return fp_relabel<1, FpS::V>(fp_mul(raw, C_FROM_M384));
+}
+// big-endian 48-byte field element (g1.go:157-167 wire order) <-> words
+BLSMI_DEV void be48_to_words(const u8* p, u32 w[12]) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        const u8* b = p + 44 - 4 * j;
+        w[j] = ((u32)b[0] << 24) | ((u32)b[1] << 16) | ((u32)b[2] << 8) | (u32)b[3];
+    }
+}
+BLSMI_DEV void words_to_be48(const u32 w[12], u8* p) {
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        u8* b = p + 44 - 4 * j;
+        b[0] = (u8)(w[j] >> 24); b[1] = (u8)(w[j] >> 16); b[2] = (u8)(w[j] >> 8); b[3] = (u8)w[j];
+    }
+}
+
+}  // namespace blsmi

@@ -1,0 +1,122 @@
+/*
+ * blsmi.h -- C ABI of libblsmi.so: MI355X-native batch BLS12-381 engine behind the
+ * g1pubs / g2pubs Verify / VerifyAggregate surface of phoreproject/bls.
+ *
+ * This is the drop-in boundary: the entry points are what a cgo shim in the reference's Go
+ * packages would bind (see INTEGRATION.md for the Go side).  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - Host entry points (no suffix) take HOST pointers, are blocking and re-entrant; the library
+ *     owns device memory and streams.  `_dev` entry points take DEVICE pointers (inputs already
+ *     resident in HBM) plus a hipStream_t passed as void*, enqueue on that stream and return
+ *     without synchronising.
+ *   - Field elements on the wire are 48-byte big-endian normal form, exactly
+ *     G1Affine.SerializeBytes / G2Affine.SerializeBytes of the reference
+ *     (g1.go:157-167: x||y, 96 B; g2.go:172-186: x.c0||x.c1||y.c0||y.c1, 192 B).
+ *   - Fq12 results are 72 little-endian uint64 per element: the reference's in-memory FQ12
+ *     (Montgomery form R = 2^384, coefficient order c0.c0.c0, c0.c0.c1, ... c1.c2.c1 --
+ *     pairing_test.go:9-20), bit for bit.
+ *   - Scalars are 32-byte big-endian (FRRepr.Bytes, frrepr.go:188-195).
+ *   - Return value: 0 on success, negative BLSMI_E_* on error.  Where the reference panics
+ *     (a point at infinity entering MillerLoop, pairing.go:17-26/54) the library never aborts:
+ *     the tuple gets a defined result (verify -> 0 / false, pairing -> 1) -- see each function.
+ */
+#ifndef BLSMI_H
+#define BLSMI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLSMI_OK 0
+#define BLSMI_E_NODEVICE (-1)   /* no usable HIP device */
+#define BLSMI_E_HIP (-2)        /* a HIP runtime call failed */
+#define BLSMI_E_ARG (-3)        /* bad argument (null pointer with n > 0, ...) */
+#define BLSMI_E_NOMEM (-4)
+
+/* Bind the calling process to `device` (>= 0) and create the library's stream and workspace.
+ * Idempotent; every other host entry point calls it lazily with device 0. */
+int blsmi_init(int device);
+void blsmi_shutdown(void);
+/* "gfx950", CU count, and the library version string */
+const char *blsmi_version(void);
+
+/* ---- pairing (replaces bls.Pairing, pairing.go:132-136; BASELINE config 2) -------------------
+ * out[i] = FinalExponentiation(MillerLoop(P_i, Q_i)) for n independent (P_i in G1, Q_i in G2)
+ * affine pairs.  Inputs must be finite curve points (the reference panics on infinity). */
+int blsmi_pairing_batch(const uint8_t *g1_aff /* n*96 */, const uint8_t *g2_aff /* n*192 */,
+                        uint64_t *out_fq12 /* n*72 */, size_t n);
+int blsmi_pairing_batch_dev(const void *d_g1_aff, const void *d_g2_aff, void *d_out_fq12, size_t n, void *stream);
+/* Miller loop only (pairing.go:16-75 with one pair per tuple), same output format */
+int blsmi_miller_loop_batch(const uint8_t *g1_aff, const uint8_t *g2_aff, uint64_t *out_fq12, size_t n);
+/* Final exponentiation only (pairing.go:79-129) on n Fq12 values in the output format */
+int blsmi_final_exponentiation_batch(const uint64_t *in_fq12, uint64_t *out_fq12, size_t n);
+
+/* ---- scalar multiplication and point sums (g1.go:80-90, g2.go:92-102, AggregatePublicKeys /
+ * AggregateSignatures g2pubs/bls.go:165-192; BASELINE config 3) --------------------------------
+ * out[i] = k_i * P_i in affine form; out_inf[i] = 1 when the result is the point at infinity
+ * (its 96/192 bytes are then zero).  in_inf may be NULL (all finite). */
+int blsmi_g1_mul_batch(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
+int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
+/* sum of n points (tree reduction on the device; equals the reference's sequential Jacobian sum
+ * after ToAffine).  *out_inf = 1 for the point at infinity. */
+int blsmi_g1_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t out[96], int *out_inf);
+int blsmi_g2_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t out[192], int *out_inf);
+
+/* ---- hash to curve (HashG1 hash.go:326-331, HashG2 hash.go:405-411, HashG2WithDomain
+ * g2.go:1041-1085) -- messages are concatenated in `msgs`, message i = msgs[off[i] .. off[i+1]) -- */
+int blsmi_hash_g1_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, uint8_t *out /* n*96 */, size_t n);
+int blsmi_hash_g2_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, uint8_t *out /* n*192 */, size_t n);
+int blsmi_hash_g2_with_domain_batch(const uint8_t *msgs32 /* n*32 */, const uint8_t domain[8], uint8_t *out /* n*192 */, size_t n);
+
+/* ---- g2pubs: PublicKey in G2 (192 B affine), Signature in G1 (96 B affine), H: msg -> G1 ------
+ * verify_batch: ok[i] = g2pubs.Verify(msg_i, pk_i, sig_i) (g2pubs/bls.go:159-162) as one byte per
+ * tuple (0/1) and, if ok_bitmap != NULL, packed LSB-first into ceil(n/8) bytes.
+ * inf_flags (may be NULL): bit0 = pk_i is infinity, bit1 = sig_i is infinity -> ok[i] = 0. */
+int blsmi_g2pubs_verify_batch(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks /* n*192 */, const uint8_t *sigs /* n*96 */,
+                              const uint8_t *inf_flags, uint8_t *ok /* n, may be NULL */, uint8_t *ok_bitmap /* ceil(n/8), may be NULL */, size_t n);
+/* (*Signature).VerifyAggregate (g2pubs/bls.go:240-270): one aggregate signature over n (pk_i, msg_i),
+ * including the duplicate-message rejection.  *ok = 0/1. */
+int blsmi_g2pubs_verify_aggregate(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, const uint8_t sig[96], size_t n, int *ok);
+/* (*Signature).VerifyAggregateCommon (g2pubs/bls.go:275-278) */
+int blsmi_g2pubs_verify_aggregate_common(const uint8_t *msg, size_t msg_len, const uint8_t *pks, const uint8_t sig[96], size_t n, int *ok);
+
+/* ---- g1pubs: PublicKey in G1 (96 B), Signature in G2 (192 B), H: msg -> G2 (g1pubs/bls.go) ---- */
+int blsmi_g1pubs_verify_batch(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks /* n*96 */, const uint8_t *sigs /* n*192 */,
+                              const uint8_t *inf_flags, uint8_t *ok, uint8_t *ok_bitmap, size_t n);
+int blsmi_g1pubs_verify_aggregate(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
+int blsmi_g1pubs_verify_aggregate_common(const uint8_t *msg, size_t msg_len, const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
+/* the *WithDomain family (g1pubs/bls.go:171-174, 294-311): 32-byte messages, 8-byte domain */
+int blsmi_g1pubs_verify_with_domain_batch(const uint8_t *msgs32, const uint8_t domain[8], const uint8_t *pks, const uint8_t *sigs,
+                                          const uint8_t *inf_flags, uint8_t *ok, uint8_t *ok_bitmap, size_t n);
+int blsmi_g1pubs_verify_aggregate_with_domain(const uint8_t *msgs32, const uint8_t domain[8], const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
+int blsmi_g1pubs_verify_aggregate_common_with_domain(const uint8_t msg32[32], const uint8_t domain[8], const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
+
+/* device-pointer forms of the verify batches (inputs resident in HBM; ok is n bytes on the device) */
+int blsmi_g2pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
+int blsmi_g1pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
+
+/* ---- wire format (CompressG1/G2, DecompressG1/G2 incl. subgroup check; g1.go:185-249, g2.go:219-295)
+ * err[i]: 0 ok, 1 unexpected compression mode, 2 bad infinity encoding, 3 not on curve, 4 not in subgroup */
+int blsmi_g1_decompress_batch(const uint8_t *in /* n*48 */, int check_subgroup, uint8_t *out /* n*96 */, uint8_t *out_inf, uint8_t *err, size_t n);
+int blsmi_g2_decompress_batch(const uint8_t *in /* n*96 */, int check_subgroup, uint8_t *out /* n*192 */, uint8_t *out_inf, uint8_t *err, size_t n);
+int blsmi_g1_compress_batch(const uint8_t *pts, const uint8_t *in_inf, uint8_t *out /* n*48 */, size_t n);
+int blsmi_g2_compress_batch(const uint8_t *pts, const uint8_t *in_inf, uint8_t *out /* n*96 */, size_t n);
+
+/* ---- unit-level device ops, exported for the parity tests (tests/test_gpu_field.py).  Operands are
+ * arrays of n records of `width` Fq values, each Fq as 6 LE uint64 Montgomery(2^384) limbs. -------- */
+enum blsmi_debug_op {
+    BLSMI_OP_FQ_MUL = 1, BLSMI_OP_FQ_SQR, BLSMI_OP_FQ_ADD, BLSMI_OP_FQ_SUB, BLSMI_OP_FQ_NEG, BLSMI_OP_FQ_INV, BLSMI_OP_FQ_SQRT,
+    BLSMI_OP_FQ2_MUL = 16, BLSMI_OP_FQ2_SQR, BLSMI_OP_FQ2_INV, BLSMI_OP_FQ2_MUL_NR, BLSMI_OP_FQ2_SQRT,
+    BLSMI_OP_FQ6_MUL = 32, BLSMI_OP_FQ6_SQR, BLSMI_OP_FQ6_INV, BLSMI_OP_FQ6_FROB1,
+    BLSMI_OP_FQ12_MUL = 48, BLSMI_OP_FQ12_SQR, BLSMI_OP_FQ12_INV, BLSMI_OP_FQ12_FROB1, BLSMI_OP_FQ12_FROB2, BLSMI_OP_FQ12_FROB3, BLSMI_OP_FQ12_CYCLO_SQR,
+    BLSMI_OP_G1_DOUBLE = 64, BLSMI_OP_G1_ADD, BLSMI_OP_G2_DOUBLE, BLSMI_OP_G2_ADD
+};
+int blsmi_debug_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *flag /* n, may be NULL */, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
