@@ -491,8 +491,8 @@ static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* 
     int rc = sum_dev<PB, W>(k0, k1, kfinal, dp.as<u8>(), in_inf ? di.as<u8>() : nullptr, n, dout.as<u8>(), dflag.as<i32>(), g_stream);
     if (rc) return rc;
     i32 flag = 0;
-    HIPCHK(hipMemcpy(out, dout.p, PB, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpyAsync(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream));
     *out_inf = flag;
     return BLSMI_OK;
 }

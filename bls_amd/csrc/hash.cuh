@@ -1,3 +1,312 @@
-// hash.cuh -- hash-to-curve on the device (placeholder during bring-up; filled in below).
+// hash.cuh -- the reference's draft-era hash-to-curve on the device, one message per lane.
+// Replaces hp/hp2 (hash.go:41-113), optimizedSWUMapHelper (g1.go:628-714), OptimizedSWU2MapHelper
+// (g2.go:933-1031), iso11/iso3 (hash.go:185-303), ClearH/clearH2/psi (hash.go:306-389), HashG1/HashG2
+// (hash.go:326-331, 405-411) and HashG2WithDomain (g2.go:1041-1085).
+// Data-dependent branches of the reference (is g(x0) a square? which sign?) become selects: the
+// control flow is the same for all 64 lanes.  Field divisions that the reference performs one by one
+// are merged where the quotient is the same field element (x_num/x_den and y_num/y_den share one
+// inversion): the hashed point is identical.
 #pragma once
 #include "curve.cuh"
+
+namespace blsmi {
+
+// ---- SHA-256 (the reference uses Go's crypto/sha256, hash.go:4) -------------------------------------
+__constant__ const u32 SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+BLSMI_DEV u32 rotr(u32 x, int n) { return __builtin_rotateright32(x, n); }
+__device__ __noinline__ void sha256_block(u32 h[8], const u32 win[16]) {
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = win[i];
+    u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            const u32 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            const u32 s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3), s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+        }
+        const u32 t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + w[i & 15];
+        const u32 t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+BLSMI_DEV void sha256_init(u32 h[8]) {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a; h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+}
+// digest of (optional 1-byte prefix) || msg[0..len) read bytewise from global memory
+__device__ __noinline__ void sha256_msg(u32 h[8], int has_prefix, u8 prefix, const u8* msg, size_t len) {
+    sha256_init(h);
+    const size_t total = len + (has_prefix ? 1 : 0);
+    const size_t padded = ((total + 8) / 64 + 1) * 64;                   // bytes after padding
+    u32 w[16];
+    for (size_t base = 0; base < padded; base += 64) {
+        for (int i = 0; i < 16; i++) {
+            u32 word = 0;
+            for (int k = 0; k < 4; k++) {
+                const size_t pos = base + 4 * i + k;
+                u32 byte;
+                if (pos < total) byte = has_prefix ? (pos == 0 ? prefix : msg[pos - 1]) : msg[pos];
+                else if (pos == total) byte = 0x80;
+                else if (pos >= padded - 8) byte = (u32)(((u64)total * 8) >> (8 * (padded - 1 - pos))) & 0xff;
+                else byte = 0;
+                word = (word << 8) | byte;
+            }
+            w[i] = word;
+        }
+        sha256_block(h, w);
+    }
+}
+// digest of the 35-byte string  d[0..8) (32 bytes) || b0 || b1 || b2   (m' || i || j of hp/hp2)
+BLSMI_DEV void sha256_35(u32 out[8], const u32 d[8], u32 b0, u32 b1, u32 b2) {
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = d[i];
+    w[8] = (b0 << 24) | (b1 << 16) | (b2 << 8) | 0x80;
+#pragma unroll
+    for (int i = 9; i < 15; i++) w[i] = 0;
+    w[15] = 35 * 8;
+    sha256_init(out);
+    sha256_block(out, w);
+}
+// 64 big-endian bytes (two digests, t = d1 || d2) mod q as a Montgomery element (hash.go:66-71)
+BLSMI_DEV FpS fq_from_two_digests(const u32 d1[8], const u32 d2[8]) {
+    u32 hi[12], lo[12];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { hi[j] = d1[7 - j]; lo[j] = d2[7 - j]; }
+#pragma unroll
+    for (int j = 8; j < 12; j++) { hi[j] = 0; lo[j] = 0; }
+    const FpS h = fp_from_words(hi), l = fp_from_words(lo);
+    return fp_store(fp_add(fp_mul(h, C_TWO256), l));
+}
+// hash.go:41-72 with the digest of (0x01 || msg) computed once (the reference recomputes it per call)
+BLSMI_DEV FpS hp_from_digest(const u32 msg_digest[8], u32 ctr) {
+    u32 d1[8], d2[8];
+    sha256_35(d1, msg_digest, ctr, 1, 1);
+    sha256_35(d2, msg_digest, ctr, 1, 2);
+    return fq_from_two_digests(d1, d2);
+}
+// hash.go:74-113
+BLSMI_DEV Fp2S hp2_from_digest(const u32 msg_digest[8], u32 ctr) {
+    u32 d1[8], d2[8];
+    Fp2S r;
+    sha256_35(d1, msg_digest, ctr, 1, 1); sha256_35(d2, msg_digest, ctr, 1, 2);
+    r.c0 = fq_from_two_digests(d1, d2);
+    sha256_35(d1, msg_digest, ctr, 2, 1); sha256_35(d2, msg_digest, ctr, 2, 2);
+    r.c1 = fq_from_two_digests(d1, d2);
+    return r;
+}
+
+// ---- sign helpers (g1.go:621-626, g2.go:916-931): comparisons are on normal-form values ------------
+// all-ones iff the normal form of x is > (q-1)/2 ; *is_zero = all-ones iff x == 0
+template <int L, int V>
+BLSMI_DEV i32 fp_gt_half(const Fp<L, V>& x, i32* is_zero = nullptr) {
+    const FpC c = fp_canon(fp_mul(fp_store(x), C_RAW_ONE));             // normal form, canonical limbs
+    i32 b = 0, nz = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) { b = (C_QM1O2_RAW.v[i] - c.v[i] + b) >> LB; nz |= c.v[i]; }
+    if (is_zero) *is_zero = nz ? 0 : -1;
+    return b;                                                              // borrow <=> (q-1)/2 < x
+}
+BLSMI_DEV FpS fp_sign(const FpS& x) { return fp_select(fp_gt_half(x), C_NEGONE, C_ONE); }         // g1.go:621-626
+BLSMI_DEV i32 fp2_sign_is_neg(const Fp2S& f) {                                                     // g2.go:916-931: -1 <=> all-ones
+    i32 z1, z0;
+    const i32 g1 = fp_gt_half(f.c1, &z1), g0 = fp_gt_half(f.c0, &z0);
+    return g1 | (z1 & g0);
+}
+
+// ---- G1: simplified SWU to the 11-isogenous curve (g1.go:628-714) ----------------------------------
+__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
+    const FpS tsq = fp_store(fp_sqr(t));
+    const FpS ndc = fp_store(fp_sub(fp_sqr(tsq), tsq));                   // (-1)^2 t^4 + (-1) t^2
+    const i32 ndc0 = fp_is_zero(ndc) ? -1 : 0;
+    // x0 = -B (ndc+1) / (A ndc)      or  B / (-A) when ndc == 0 (g1.go:645-659)
+    const FpS num = fp_select(ndc0, FpS(C_ELLPB), fp_store(fp_mul(fp_neg(C_ELLPB), fp_add(ndc, C_ONE))));
+    const FpS den = fp_select(ndc0, fp_store(fp_neg(C_ELLPA)), fp_store(fp_mul(C_ELLPA, ndc)));
+    const FpS x0 = fp_store(fp_mul(num, fp_inv(den)));
+    const FpS gx0 = fp_store(fp_add(fp_add(fp_mul(fp_sqr(x0), x0), fp_mul(C_ELLPA, x0)), C_ELLPB));
+    bool ok0, ok1;
+    const FpS y0 = fp_sqrt(gx0, ok0);
+    const FpS x1 = fp_store(fp_mul(fp_neg(tsq), x0));                      // (-1) t^2 x0
+    const FpS gx1 = fp_store(fp_add(fp_add(fp_mul(fp_sqr(x1), x1), fp_mul(C_ELLPA, x1)), C_ELLPB));
+    const FpS y1 = fp_sqrt(gx1, ok1);
+    const i32 m0 = ok0 ? -1 : 0;
+    const FpS x = fp_select(m0, x0, x1);
+    const FpS y = fp_select(m0, y0, y1);
+    out.x = x;
+    out.y = fp_store(fp_mul(y, fp_mul(fp_sign(y), fp_sign(t))));          // g1.go:706-711
+    out.inf = 0;
+}
+template <int N>
+BLSMI_DEV FpS horner_fp(const FpS (&c)[N], const FpS& x) {
+    FpS v = c[N - 1];
+    for (int i = N - 2; i >= 0; i--) v = fp_store(fp_add(fp_mul(v, x), c[i]));
+    return v;
+}
+// hash.go:185-206
+__device__ __noinline__ void iso11(G1Aff& out, const G1Aff& p) {
+    const FpS xn = horner_fp(C_XNUM11, p.x), xd = horner_fp(C_XDEN11, p.x), yn = horner_fp(C_YNUM11, p.x), yd = horner_fp(C_YDEN11, p.x);
+    const FpS inv = fp_inv(fp_mul(xd, yd));                                // 1/(xd*yd): xn/xd = xn*yd*inv, yn/yd = yn*xd*inv
+    out.x = fp_store(fp_mul(fp_mul(xn, yd), inv));
+    out.y = fp_store(fp_mul(fp_mul(fp_mul(p.y, yn), xd), inv));
+    out.inf = 0;
+}
+// hash.go:306-321: add the two mapped points, apply the isogeny, clear the cofactor by (|x| + 1)
+__device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2) {
+    G1Aff p1, p2, s;
+    swu_g1_helper(p1, t1);
+    swu_g1_helper(p2, t2);
+    s = jac_to_affine(jac_add_affine(to_jac(p1), p2));
+    iso11(p1, s);
+    out = jac_to_affine(jac_add_affine(aff_mul_u64_public(p1, BLSMI_X_ABS), p1));
+}
+// hash.go:326-331
+__device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len) {
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msg, len);
+    const FpS t1 = hp_from_digest(d, 0), t2 = hp_from_digest(d, 1);
+    swu_map_g1(out, t1, t2);
+}
+
+// ---- G2 (g2.go:933-1031, hash.go:282-411) ---------------------------------------------------------------
+__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
+    Fp2S nqr; nqr.c0 = C_ONE; nqr.c1 = C_ONE;
+    const Fp2S tsq = fp2_store(fp2_sqr(t));
+    const Fp2S nqr_tsq = fp2_store(fp2_mul_nr(tsq));
+    const Fp2S ndc = fp2_store(fp2_add(fp2_sqr(nqr_tsq), nqr_tsq));       // nqr^2 t^4 + nqr t^2
+    const i32 ndc0 = fp2_is_zero(ndc) ? -1 : 0;
+    const Fp2S num = fp2_select(ndc0, Fp2S(C_ELL2PB), fp2_store(fp2_mul(fp2_neg(C_ELL2PB), fp2_add(ndc, fp2_one()))));
+    const Fp2S den = fp2_select(ndc0, fp2_store(fp2_mul_nr(C_ELL2PA)), fp2_store(fp2_mul(C_ELL2PA, ndc)));
+    const Fp2S x0 = fp2_store(fp2_mul(num, fp2_store(fp2_inv(den))));
+    const Fp2S gx0 = fp2_store(fp2_add(fp2_add(fp2_mul(fp2_sqr(x0), x0), fp2_mul(C_ELL2PA, x0)), C_ELL2PB));
+    bool ok0, ok1;
+    const Fp2S s0 = fp2_sqrt(gx0, ok0);
+    const bool good0 = ok0 & fp2_eq(fp2_sqr(s0), gx0);                     // g2.go:977-981
+    const Fp2S x1 = fp2_store(fp2_mul(nqr_tsq, x0));
+    const Fp2S t6 = fp2_store(fp2_sqr(fp2_mul(tsq, t)));
+    Fp2S nqr3 = fp2_store(fp2_mul_nr(fp2_mul_nr(nqr)));                    // nqr^3
+    const Fp2S gx1 = fp2_store(fp2_mul(fp2_mul(nqr3, t6), gx0));
+    const Fp2S s1 = fp2_sqrt(gx1, ok1);
+    const i32 m0 = good0 ? -1 : 0;
+    const Fp2S x = fp2_select(m0, x0, x1);
+    Fp2S y = fp2_select(m0, s0, s1);
+    const i32 flip = fp2_sign_is_neg(t) ^ fp2_sign_is_neg(y);             // signT != signY (g2.go:983-988, 1021-1026)
+    y = fp2_select(flip, fp2_store(fp2_neg(y)), y);
+    out.x = x; out.y = y; out.inf = 0;
+}
+template <int N>
+BLSMI_DEV Fp2S horner_fp2(const Fp2S (&c)[N], const Fp2S& x) {
+    Fp2S v = c[N - 1];
+    for (int i = N - 2; i >= 0; i--) v = fp2_store(fp2_add(fp2_mul(v, x), c[i]));
+    return v;
+}
+// hash.go:282-303
+__device__ __noinline__ void iso3(G2Aff& out, const G2Aff& p) {
+    const Fp2S xn = horner_fp2(C_XNUM3, p.x), xd = horner_fp2(C_XDEN3, p.x), yn = horner_fp2(C_YNUM3, p.x), yd = horner_fp2(C_YDEN3, p.x);
+    const Fp2S inv = fp2_store(fp2_inv(fp2_store(fp2_mul(xd, yd))));
+    out.x = fp2_store(fp2_mul(fp2_mul(xn, yd), inv));
+    out.y = fp2_store(fp2_mul(fp2_mul(fp2_mul(p.y, yn), xd), inv));
+    out.inf = 0;
+}
+// hash.go:341-366
+__device__ __noinline__ void psi(G2Aff& out, const G2Aff& g) {
+    Fp2S qix = fp2_store(fp2_mul(C_IWSC, g.x));
+    qix.c0 = fp_store(fp_mul(qix.c0, C_KQIX));
+    qix.c1 = fp_store(fp_neg(fp_mul(qix.c1, C_KQIX)));
+    const Fp2S qiy = fp2_store(fp2_mul(C_IWSC, g.y));
+    Fp2S q2;
+    q2.c0 = fp_store(fp_mul(fp_add(qiy.c0, qiy.c1), C_KQIY));
+    q2.c1 = fp_store(fp_mul(fp_sub(qiy.c0, qiy.c1), C_KQIY));
+    out.x = fp2_store(fp2_mul_nr(qix));
+    out.y = fp2_store(fp2_mul_nr(q2));
+    out.inf = g.inf;
+}
+// G2Projective.Mul by |x| (g2.go:609-619): double-and-add with the general addition
+BLSMI_DEV G2Jac jac_mul_u64_public(const G2Jac& p, u64 k) {
+    G2Jac res = p;
+    for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
+        res = jac_double(res);
+        if ((k >> i) & 1) res = jac_add(res, p);
+    }
+    return res;
+}
+// hash.go:368-389
+__device__ __noinline__ void clear_h2(G2Aff& out, const G2Aff& p) {
+    G2Jac work = aff_mul_u64_public(p, BLSMI_X_ABS);
+    work = jac_add_affine(work, p);
+    G2Aff mpsi; psi(mpsi, p); mpsi = aff_neg(mpsi);
+    work = jac_add_affine(work, mpsi);
+    work = jac_mul_u64_public(work, BLSMI_X_ABS);
+    work = jac_add_affine(work, mpsi);
+    work = jac_add_affine(work, aff_neg(p));
+    G2Aff p2 = jac_to_affine(jac_double(to_jac(p)));
+    G2Aff pp; psi(pp, p2); psi(p2, pp);
+    work = jac_add_affine(work, p2);
+    out = jac_to_affine(work);
+}
+// hash.go:391-411
+__device__ __noinline__ void hash_g2(G2Aff& out, const u8* msg, size_t len) {
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msg, len);
+    const Fp2S t1 = hp2_from_digest(d, 0), t2 = hp2_from_digest(d, 1);
+    G2Aff p1, p2, s;
+    swu_g2_helper(p1, t1);
+    swu_g2_helper(p2, t2);
+    s = jac_to_affine(jac_add_affine(to_jac(p1), p2));
+    iso3(p1, s);
+    clear_h2(out, p1);
+}
+
+// g2.go:1041-1085: try-and-increment on x0 = (H(m||d||01), H(m||d||02)); favour the y with Parity(),
+// then scale by the 507-bit G2 cofactor (g2.go:130-138).  The loop runs until every lane of the wave
+// has found a square (uniform trip count; finished lanes keep their result).
+__device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, const u8* domain8) {
+    u32 w[16], dre[8], dim[8];
+    for (int tag = 1; tag <= 2; tag++) {                                   // SHA-256 of the 41-byte string m || domain || tag
+        for (int i = 0; i < 8; i++) w[i] = ((u32)msg32[4 * i] << 24) | ((u32)msg32[4 * i + 1] << 16) | ((u32)msg32[4 * i + 2] << 8) | msg32[4 * i + 3];
+        for (int i = 0; i < 2; i++) w[8 + i] = ((u32)domain8[4 * i] << 24) | ((u32)domain8[4 * i + 1] << 16) | ((u32)domain8[4 * i + 2] << 8) | domain8[4 * i + 3];
+        w[10] = ((u32)tag << 24) | 0x800000;
+        w[11] = w[12] = w[13] = w[14] = 0;
+        w[15] = 41 * 8;
+        u32* d = tag == 1 ? dre : dim;
+        sha256_init(d);
+        sha256_block(d, w);
+    }
+    u32 wre[12], wim[12];
+    for (int j = 0; j < 8; j++) { wre[j] = dre[7 - j]; wim[j] = dim[7 - j]; }
+    for (int j = 8; j < 12; j++) { wre[j] = 0; wim[j] = 0; }
+    Fp2S x0; x0.c0 = fp_from_words(wre); x0.c1 = fp_from_words(wim);
+    G2Aff pt; pt.x = x0; pt.y = fp2_one(); pt.inf = 0;
+    i32 done = 0;
+    while (true) {
+        const Fp2S gx = fp2_store(fp2_add(fp2_mul(fp2_sqr(x0), x0), C_B2));
+        bool ok;
+        Fp2S y = fp2_sqrt(gx, ok);
+        const i32 take = (ok ? -1 : 0) & ~done;
+        // favour y with Parity() == true (g2.go:1074-1077): parity(y) <=> y > -y (fq2.go:256-260)
+        const i32 y_gt = fp2_sign_is_neg(y);                               // y > (q-1)/2 lexicographically (c1 first) <=> y > -y
+        y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
+        pt.x = fp2_select(take, x0, pt.x);
+        pt.y = fp2_select(take, y, pt.y);
+        done |= take;
+        if (__all(done != 0)) break;
+        x0 = fp2_store(fp2_add(x0, fp2_one()));
+    }
+    // ScaleByCofactor: MSB-first double-and-add over the public 507-bit cofactor (g2.go:104-115)
+    G2Jac res = to_jac(pt);
+    for (int i = BLSMI_G2_COFACTOR_BITS - 2; i >= 0; i--) {
+        res = jac_double(res);
+        if ((C_G2_COFACTOR[i >> 5] >> (i & 31)) & 1) res = jac_add_affine(res, pt);
+    }
+    out = jac_to_affine(res);
+}
+
+}  // namespace blsmi

@@ -1,0 +1,286 @@
+"""Thin ctypes layer over the C ABI of libblsmi.so (include/blsmi.h).  Host code only: every
+computation happens in the HIP kernels; a missing library or device raises, nothing falls back."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class BlsmiError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "no usable HIP device", -2: "HIP runtime call failed", -3: "bad argument", -4: "out of memory"}
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise BlsmiError("%s failed: %s (%d)" % (what, _ERR.get(rc, "unknown"), rc))
+
+
+def _lib():
+    return _native.load()
+
+
+def _u8(x, nbytes=None):
+    a = np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray, memoryview)) else np.ascontiguousarray(x, dtype=np.uint8).reshape(-1)
+    if nbytes is not None and a.size != nbytes:
+        raise ValueError("expected %d bytes, got %d" % (nbytes, a.size))
+    return a
+
+
+def _p8(a):
+    return a.ctypes.data_as(_u8p) if a is not None and a.size else None
+
+
+def init(device=0):
+    _check(_lib().blsmi_init(int(device)), "blsmi_init")
+
+
+def version():
+    return _lib().blsmi_version().decode()
+
+
+def _msgs(msgs):
+    off = np.zeros(len(msgs) + 1, dtype=np.uint64)
+    if len(msgs):
+        off[1:] = np.cumsum([len(m) for m in msgs])
+    buf = np.frombuffer(b"".join(bytes(m) for m in msgs) or b"\0", dtype=np.uint8)
+    return buf, off
+
+
+# ---- pairing ---------------------------------------------------------------------------------------
+def pairing_batch(g1_aff, g2_aff, n):
+    """n x 96 B G1 affine, n x 192 B G2 affine -> (n, 72) uint64: the reference's in-memory FQ12."""
+    a, b = _u8(g1_aff, 96 * n), _u8(g2_aff, 192 * n)
+    out = np.zeros((n, 72), dtype=np.uint64)
+    _check(_lib().blsmi_pairing_batch(_p8(a), _p8(b), out.ctypes.data_as(_u64p), C.c_size_t(n)), "blsmi_pairing_batch")
+    return out
+
+
+def miller_loop_batch(g1_aff, g2_aff, n):
+    a, b = _u8(g1_aff, 96 * n), _u8(g2_aff, 192 * n)
+    out = np.zeros((n, 72), dtype=np.uint64)
+    _check(_lib().blsmi_miller_loop_batch(_p8(a), _p8(b), out.ctypes.data_as(_u64p), C.c_size_t(n)), "blsmi_miller_loop_batch")
+    return out
+
+
+def final_exponentiation_batch(fq12):
+    x = np.ascontiguousarray(fq12, dtype=np.uint64).reshape(-1, 72)
+    out = np.zeros_like(x)
+    _check(_lib().blsmi_final_exponentiation_batch(x.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p), C.c_size_t(x.shape[0])), "blsmi_final_exponentiation_batch")
+    return out
+
+
+def pairing_batch_dev(d_g1, d_g2, d_out, n, stream=0):
+    """Device-pointer form (ints, e.g. torch.Tensor.data_ptr()); enqueues and synchronises `stream`."""
+    _check(_lib().blsmi_pairing_batch_dev(C.c_void_p(d_g1), C.c_void_p(d_g2), C.c_void_p(d_out), C.c_size_t(n), C.c_void_p(stream)), "blsmi_pairing_batch_dev")
+
+
+def verify_batch_dev(group, d_msgs, d_off, d_pks, d_sigs, d_inf, d_ok, n, stream=0):
+    fn = _lib().blsmi_g2pubs_verify_batch_dev if group == "g2pubs" else _lib().blsmi_g1pubs_verify_batch_dev
+    _check(fn(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_pks), C.c_void_p(d_sigs), C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_batch_dev")
+
+
+# ---- groups ----------------------------------------------------------------------------------------
+def _mul(fn, pb, pts, scalars, n):
+    p, s = _u8(pts, pb * n), _u8(scalars, 32 * n)
+    out = np.zeros(pb * n, dtype=np.uint8)
+    inf = np.zeros(n, dtype=np.uint8)
+    _check(fn(_p8(p), _p8(s), _p8(out), _p8(inf), C.c_size_t(n)), "mul_batch")
+    return out.reshape(n, pb), inf.astype(bool)
+
+
+def g1_mul_batch(pts, scalars, n):
+    return _mul(_lib().blsmi_g1_mul_batch, 96, pts, scalars, n)
+
+
+def g2_mul_batch(pts, scalars, n):
+    return _mul(_lib().blsmi_g2_mul_batch, 192, pts, scalars, n)
+
+
+def _sum(fn, pb, pts, n, in_inf):
+    p = _u8(pts, pb * n) if n else np.zeros(1, np.uint8)
+    f = _u8(in_inf, n) if in_inf is not None else None
+    out = np.zeros(pb, dtype=np.uint8)
+    oinf = C.c_int(0)
+    _check(fn(_p8(p), _p8(f), C.c_size_t(n), _p8(out), C.byref(oinf)), "sum")
+    return (None if oinf.value else out.tobytes())
+
+
+def g1_sum(pts, n, in_inf=None):
+    """Sum of n affine points -> 96 bytes, or None for the point at infinity."""
+    return _sum(_lib().blsmi_g1_sum, 96, pts, n, in_inf)
+
+
+def g2_sum(pts, n, in_inf=None):
+    return _sum(_lib().blsmi_g2_sum, 192, pts, n, in_inf)
+
+
+# ---- hash to curve ---------------------------------------------------------------------------------
+def hash_g1_batch(msgs):
+    buf, off = _msgs(msgs)
+    out = np.zeros((len(msgs), 96), dtype=np.uint8)
+    _check(_lib().blsmi_hash_g1_batch(_p8(buf), off.ctypes.data_as(_u64p), _p8(out.reshape(-1)), C.c_size_t(len(msgs))), "blsmi_hash_g1_batch")
+    return out
+
+
+def hash_g2_batch(msgs):
+    buf, off = _msgs(msgs)
+    out = np.zeros((len(msgs), 192), dtype=np.uint8)
+    _check(_lib().blsmi_hash_g2_batch(_p8(buf), off.ctypes.data_as(_u64p), _p8(out.reshape(-1)), C.c_size_t(len(msgs))), "blsmi_hash_g2_batch")
+    return out
+
+
+def hash_g2_with_domain_batch(msgs32, domain8):
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n)
+    d = _u8(domain8, 8)
+    out = np.zeros((n, 192), dtype=np.uint8)
+    _check(_lib().blsmi_hash_g2_with_domain_batch(_p8(buf), _p8(d), _p8(out.reshape(-1)), C.c_size_t(n)), "blsmi_hash_g2_with_domain_batch")
+    return out
+
+
+# ---- verify ----------------------------------------------------------------------------------------
+def _verify_batch(fn, pkb, sgb, msgs, pks, sigs, inf_flags):
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    p, s = _u8(pks, pkb * n), _u8(sigs, sgb * n)
+    f = _u8(inf_flags, n) if inf_flags is not None else None
+    ok = np.zeros(n, dtype=np.uint8)
+    bitmap = np.zeros((n + 7) // 8, dtype=np.uint8)
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), _p8(p), _p8(s), _p8(f), _p8(ok), _p8(bitmap), C.c_size_t(n)), "verify_batch")
+    return ok.astype(bool), bitmap
+
+
+def g2pubs_verify_batch(msgs, pks, sigs, inf_flags=None):
+    return _verify_batch(_lib().blsmi_g2pubs_verify_batch, 192, 96, msgs, pks, sigs, inf_flags)
+
+
+def g1pubs_verify_batch(msgs, pks, sigs, inf_flags=None):
+    return _verify_batch(_lib().blsmi_g1pubs_verify_batch, 96, 192, msgs, pks, sigs, inf_flags)
+
+
+def g1pubs_verify_with_domain_batch(msgs32, domain8, pks, sigs, inf_flags=None):
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n)
+    d, p, s = _u8(domain8, 8), _u8(pks, 96 * n), _u8(sigs, 192 * n)
+    f = _u8(inf_flags, n) if inf_flags is not None else None
+    ok = np.zeros(n, dtype=np.uint8)
+    _check(_lib().blsmi_g1pubs_verify_with_domain_batch(_p8(buf), _p8(d), _p8(p), _p8(s), _p8(f), _p8(ok), None, C.c_size_t(n)), "verify_with_domain_batch")
+    return ok.astype(bool)
+
+
+def _verify_aggregate(fn, pkb, sgb, msgs, pks, sig):
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    p = _u8(pks, pkb * n) if n else np.zeros(1, np.uint8)
+    s = _u8(sig, sgb)
+    ok = C.c_int(0)
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), _p8(p), _p8(s), C.c_size_t(n), C.byref(ok)), "verify_aggregate")
+    return bool(ok.value)
+
+
+def g2pubs_verify_aggregate(msgs, pks, sig):
+    return _verify_aggregate(_lib().blsmi_g2pubs_verify_aggregate, 192, 96, msgs, pks, sig)
+
+
+def g1pubs_verify_aggregate(msgs, pks, sig):
+    return _verify_aggregate(_lib().blsmi_g1pubs_verify_aggregate, 96, 192, msgs, pks, sig)
+
+
+def g1pubs_verify_aggregate_with_domain(msgs32, domain8, pks, sig):
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n) if n else np.zeros(1, np.uint8)
+    d, p, s = _u8(domain8, 8), (_u8(pks, 96 * n) if n else np.zeros(1, np.uint8)), _u8(sig, 192)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g1pubs_verify_aggregate_with_domain(_p8(buf), _p8(d), _p8(p), _p8(s), C.c_size_t(n), C.byref(ok)), "verify_aggregate_with_domain")
+    return bool(ok.value)
+
+
+def _verify_aggregate_common(fn, pkb, sgb, msg, pks, sig, n):
+    m = _u8(bytes(msg) or b"\0")
+    p = _u8(pks, pkb * n) if n else np.zeros(1, np.uint8)
+    s = _u8(sig, sgb)
+    ok = C.c_int(0)
+    _check(fn(_p8(m), C.c_size_t(len(msg)), _p8(p), _p8(s), C.c_size_t(n), C.byref(ok)), "verify_aggregate_common")
+    return bool(ok.value)
+
+
+def g2pubs_verify_aggregate_common(msg, pks, sig, n):
+    return _verify_aggregate_common(_lib().blsmi_g2pubs_verify_aggregate_common, 192, 96, msg, pks, sig, n)
+
+
+def g1pubs_verify_aggregate_common(msg, pks, sig, n):
+    return _verify_aggregate_common(_lib().blsmi_g1pubs_verify_aggregate_common, 96, 192, msg, pks, sig, n)
+
+
+def g1pubs_verify_aggregate_common_with_domain(msg32, domain8, pks, sig, n):
+    m, d = _u8(msg32, 32), _u8(domain8, 8)
+    p = _u8(pks, 96 * n) if n else np.zeros(1, np.uint8)
+    s = _u8(sig, 192)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g1pubs_verify_aggregate_common_with_domain(_p8(m), _p8(d), _p8(p), _p8(s), C.c_size_t(n), C.byref(ok)), "verify_aggregate_common_with_domain")
+    return bool(ok.value)
+
+
+# ---- wire format -----------------------------------------------------------------------------------
+def _decompress(fn, ib, ob, data, n, check):
+    a = _u8(data, ib * n)
+    out = np.zeros((n, ob), dtype=np.uint8)
+    inf = np.zeros(n, dtype=np.uint8)
+    err = np.zeros(n, dtype=np.uint8)
+    _check(fn(_p8(a), C.c_int(int(check)), _p8(out.reshape(-1)), _p8(inf), _p8(err), C.c_size_t(n)), "decompress")
+    return out, inf.astype(bool), err
+
+
+def g1_decompress_batch(data, n, check_subgroup=True):
+    return _decompress(_lib().blsmi_g1_decompress_batch, 48, 96, data, n, check_subgroup)
+
+
+def g2_decompress_batch(data, n, check_subgroup=True):
+    return _decompress(_lib().blsmi_g2_decompress_batch, 96, 192, data, n, check_subgroup)
+
+
+def _compress(fn, ib, ob, pts, n, in_inf):
+    a = _u8(pts, ib * n)
+    f = _u8(in_inf, n) if in_inf is not None else None
+    out = np.zeros((n, ob), dtype=np.uint8)
+    _check(fn(_p8(a), _p8(f), _p8(out.reshape(-1)), C.c_size_t(n)), "compress")
+    return out
+
+
+def g1_compress_batch(pts, n, in_inf=None):
+    return _compress(_lib().blsmi_g1_compress_batch, 96, 48, pts, n, in_inf)
+
+
+def g2_compress_batch(pts, n, in_inf=None):
+    return _compress(_lib().blsmi_g2_compress_batch, 192, 96, pts, n, in_inf)
+
+
+# ---- unit-level device ops (parity tests) -------------------------------------------------------------
+OPS = dict(FQ_MUL=1, FQ_SQR=2, FQ_ADD=3, FQ_SUB=4, FQ_NEG=5, FQ_INV=6, FQ_SQRT=7,
+           FQ2_MUL=16, FQ2_SQR=17, FQ2_INV=18, FQ2_MUL_NR=19, FQ2_SQRT=20,
+           FQ6_MUL=32, FQ6_SQR=33, FQ6_INV=34, FQ6_FROB1=35,
+           FQ12_MUL=48, FQ12_SQR=49, FQ12_INV=50, FQ12_FROB1=51, FQ12_FROB2=52, FQ12_FROB3=53, FQ12_CYCLO_SQR=54,
+           G1_DOUBLE=64, G1_ADD=65, G2_DOUBLE=66, G2_ADD=67)
+
+
+def debug_op(name, a, b=None):
+    op = OPS[name]
+    width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 else (3 if op in (64, 65) else 6)
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 6 * width)
+    n = a.shape[0]
+    out = np.zeros_like(a)
+    flag = np.zeros(n, dtype=np.uint8)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 6 * width)
+        assert b.shape == a.shape
+        bp = b.ctypes.data_as(_u64p)
+    _check(_lib().blsmi_debug_op(op, a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
+    return out, flag.astype(bool)

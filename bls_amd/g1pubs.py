@@ -1,0 +1,145 @@
+"""Host-side mirror of the reference package g1pubs (g1pubs/bls.go): PublicKey in G1, Signature in
+G2, messages hashed to G2.  Same names, argument meaning and results as the Go API; every group,
+pairing and hash operation runs in the HIP kernels of libblsmi.so (no CPU fallback).
+
+    Verify(m, pub, sig)                         g1pubs/bls.go:165-168
+    sig.VerifyAggregate(pubKeys, msgs)          g1pubs/bls.go:252-282
+    sig.VerifyAggregateCommon(pubKeys, msg)     g1pubs/bls.go:287-290
+    AggregateSignatures / AggregatePublicKeys   g1pubs/bls.go:177-204
+    DeserializeSignature / DeserializePublicKey g1pubs/bls.go:33-40, 89-96
+plus VerifyBatch, the batch form the one-tuple-per-call Go API lacks.
+"""
+from . import engine
+from ._groups import DeserializeError, Point, point_sum  # noqa: F401
+
+SIG_GROUP, PK_GROUP = 2, 1
+
+
+class Signature:
+    def __init__(self, point):
+        self.s = point
+
+    def Serialize(self):                      # g1pubs/bls.go:18-20
+        return self.s.serialize()
+
+    def Copy(self):
+        return Signature(Point(self.s.raw, SIG_GROUP))
+
+    def Aggregate(self, other):               # g1pubs/bls.go:174-177
+        self.s = point_sum([self.s, other.s], SIG_GROUP)
+
+    def VerifyAggregate(self, pubKeys, msgs):
+        if len(pubKeys) != len(msgs):          # g1pubs/bls.go:241-243
+            return False
+        if self.s.infinity or any(p.p.infinity for p in pubKeys):
+            return False                       # the reference panics in MillerLoop on infinity; defined as false here
+        return engine.g1pubs_verify_aggregate(msgs, b"".join(p.p.raw for p in pubKeys), self.s.raw)
+
+    def VerifyAggregateCommon(self, pubKeys, msg):
+        return Verify(msg, AggregatePublicKeys(pubKeys), self)
+
+
+class PublicKey:
+    def __init__(self, point):
+        self.p = point
+
+    def Serialize(self):                      # g1pubs/bls.go:67-69
+        return self.p.serialize()
+
+    def Copy(self):
+        return PublicKey(Point(self.p.raw, PK_GROUP))
+
+    def Equals(self, other):
+        return self.p == other.p
+
+    def Aggregate(self, other):               # g1pubs/bls.go:189-192
+        self.p = point_sum([self.p, other.p], PK_GROUP)
+
+
+def NewSignatureFromG2(raw192):
+    return Signature(Point(raw192, SIG_GROUP))
+
+
+def NewPublicKeyFromG1(raw96):
+    return PublicKey(Point(raw96, PK_GROUP))
+
+
+def DeserializeSignature(b96):
+    return Signature(Point.deserialize(b96, SIG_GROUP))
+
+
+def DeserializePublicKey(b48):
+    return PublicKey(Point.deserialize(b48, PK_GROUP))
+
+
+def NewAggregateSignature():
+    return Signature(Point(None, SIG_GROUP))
+
+
+def NewAggregatePubkey():
+    return PublicKey(Point(None, PK_GROUP))
+
+
+def AggregateSignatures(sigs):
+    return Signature(point_sum([s.s for s in sigs], SIG_GROUP))
+
+
+def AggregatePublicKeys(pubs):
+    return PublicKey(point_sum([p.p for p in pubs], PK_GROUP))
+
+
+def VerifyBatch(msgs, pubs, sigs):
+    """[Verify(msgs[i], pubs[i], sigs[i]) for i] in one launch sequence."""
+    n = len(msgs)
+    if not (len(pubs) == len(sigs) == n):
+        raise ValueError("length mismatch")
+    if n == 0:
+        return []
+    flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
+    ok, _ = engine.g1pubs_verify_batch(msgs, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
+    return [bool(x) for x in ok]
+
+
+def Verify(m, pub, sig):
+    return VerifyBatch([m], [pub], [sig])[0]
+
+
+def SignBatch(msgs, secret_scalars):
+    """sigma_i = sk_i * HashG2(m_i) (Sign, g1pubs/bls.go:132-135); scalars are 32-byte big-endian."""
+    n = len(msgs)
+    h = engine.hash_g2_batch(msgs)
+    out, inf = engine.g2_mul_batch(h.reshape(-1), b"".join(secret_scalars), n)
+    return [Signature(Point(None if inf[i] else out[i].tobytes(), SIG_GROUP)) for i in range(n)]
+
+
+# ---- the *WithDomain family (g1pubs/bls.go:138-141, 171-174, 294-311) ---------------------------------
+def VerifyWithDomainBatch(msgs32, pubs, sigs, domain8):
+    n = len(msgs32)
+    if n == 0:
+        return []
+    flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
+    ok = engine.g1pubs_verify_with_domain_batch(msgs32, domain8, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
+    return [bool(x) for x in ok]
+
+
+def VerifyWithDomain(m32, pub, sig, domain8):
+    return VerifyWithDomainBatch([m32], [pub], [sig], domain8)[0]
+
+
+def VerifyAggregateCommonWithDomain(sig, pubKeys, msg32, domain8):
+    return VerifyWithDomain(msg32, AggregatePublicKeys(pubKeys), sig, domain8)
+
+
+def VerifyAggregateWithDomain(sig, pubKeys, msgs32, domain8):
+    if len(pubKeys) != len(msgs32):
+        return False
+    if sig.s.infinity or any(p.p.infinity for p in pubKeys):
+        return False
+    return engine.g1pubs_verify_aggregate_with_domain(msgs32, domain8, b"".join(p.p.raw for p in pubKeys), sig.s.raw)
+
+
+def SignWithDomainBatch(msgs32, secret_scalars, domain8):
+    n = len(msgs32)
+    h = engine.hash_g2_with_domain_batch(msgs32, domain8)
+    out, inf = engine.g2_mul_batch(h.reshape(-1), b"".join(secret_scalars), n)
+    return [Signature(Point(None if inf[i] else out[i].tobytes(), SIG_GROUP)) for i in range(n)]

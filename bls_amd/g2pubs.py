@@ -1,0 +1,112 @@
+"""Host-side mirror of the reference package g2pubs (g2pubs/bls.go): PublicKey in G2, Signature in
+G1, messages hashed to G1.  Same names, argument meaning and results as the Go API; every group,
+pairing and hash operation runs in the HIP kernels of libblsmi.so (no CPU fallback).
+
+    Verify(m, pub, sig)                         g2pubs/bls.go:159-162
+    sig.VerifyAggregate(pubKeys, msgs)          g2pubs/bls.go:240-270
+    sig.VerifyAggregateCommon(pubKeys, msg)     g2pubs/bls.go:275-278
+    AggregateSignatures / AggregatePublicKeys   g2pubs/bls.go:165-192
+    DeserializeSignature / DeserializePublicKey g2pubs/bls.go:33-40, 89-96
+plus VerifyBatch, the batch form the one-tuple-per-call Go API lacks.
+"""
+from . import engine
+from ._groups import DeserializeError, Point, point_sum  # noqa: F401
+
+SIG_GROUP, PK_GROUP = 1, 2
+
+
+class Signature:
+    def __init__(self, point):
+        self.s = point
+
+    def Serialize(self):                      # g2pubs/bls.go:18-20
+        return self.s.serialize()
+
+    def Copy(self):
+        return Signature(Point(self.s.raw, SIG_GROUP))
+
+    def Aggregate(self, other):               # g2pubs/bls.go:174-177
+        self.s = point_sum([self.s, other.s], SIG_GROUP)
+
+    def VerifyAggregate(self, pubKeys, msgs):
+        if len(pubKeys) != len(msgs):          # g2pubs/bls.go:241-243
+            return False
+        if self.s.infinity or any(p.p.infinity for p in pubKeys):
+            return False                       # the reference panics in MillerLoop on infinity; defined as false here
+        return engine.g2pubs_verify_aggregate(msgs, b"".join(p.p.raw for p in pubKeys), self.s.raw)
+
+    def VerifyAggregateCommon(self, pubKeys, msg):
+        return Verify(msg, AggregatePublicKeys(pubKeys), self)
+
+
+class PublicKey:
+    def __init__(self, point):
+        self.p = point
+
+    def Serialize(self):                      # g2pubs/bls.go:67-69
+        return self.p.serialize()
+
+    def Copy(self):
+        return PublicKey(Point(self.p.raw, PK_GROUP))
+
+    def Equals(self, other):
+        return self.p == other.p
+
+    def Aggregate(self, other):               # g2pubs/bls.go:189-192
+        self.p = point_sum([self.p, other.p], PK_GROUP)
+
+
+def NewSignatureFromG1(raw96):
+    return Signature(Point(raw96, SIG_GROUP))
+
+
+def NewPublicKeyFromG2(raw192):
+    return PublicKey(Point(raw192, PK_GROUP))
+
+
+def DeserializeSignature(b48):
+    return Signature(Point.deserialize(b48, SIG_GROUP))
+
+
+def DeserializePublicKey(b96):
+    return PublicKey(Point.deserialize(b96, PK_GROUP))
+
+
+def NewAggregateSignature():
+    return Signature(Point(None, SIG_GROUP))
+
+
+def NewAggregatePubkey():
+    return PublicKey(Point(None, PK_GROUP))
+
+
+def AggregateSignatures(sigs):
+    return Signature(point_sum([s.s for s in sigs], SIG_GROUP))
+
+
+def AggregatePublicKeys(pubs):
+    return PublicKey(point_sum([p.p for p in pubs], PK_GROUP))
+
+
+def VerifyBatch(msgs, pubs, sigs):
+    """[Verify(msgs[i], pubs[i], sigs[i]) for i] in one launch sequence."""
+    n = len(msgs)
+    if not (len(pubs) == len(sigs) == n):
+        raise ValueError("length mismatch")
+    if n == 0:
+        return []
+    flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
+    ok, _ = engine.g2pubs_verify_batch(msgs, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
+    return [bool(x) for x in ok]
+
+
+def Verify(m, pub, sig):
+    return VerifyBatch([m], [pub], [sig])[0]
+
+
+def SignBatch(msgs, secret_scalars):
+    """sigma_i = sk_i * HashG1(m_i) (Sign, g2pubs/bls.go:132-135); scalars are 32-byte big-endian."""
+    n = len(msgs)
+    h = engine.hash_g1_batch(msgs)
+    out, inf = engine.g1_mul_batch(h.reshape(-1), b"".join(secret_scalars), n)
+    return [Signature(Point(None if inf[i] else out[i].tobytes(), SIG_GROUP)) for i in range(n)]

@@ -1,0 +1,171 @@
+"""-m gpu: unit-level parity of the HIP field / tower / curve code against the CPU oracle, bit-exact
+on the reference's in-memory representation (6 x u64 Montgomery limbs, R = 2^384), through the C ABI."""
+import numpy as np
+import pytest
+
+from gpu_common import P, RC, mont, pack, rand_fq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bls_amd import engine
+    engine.init(0)
+    return engine
+
+
+def edge_values():
+    q = P.Q
+    return [0, 1, 2, q - 1, q - 2, (q - 1) // 2, (q + 1) // 2, (1 << 380) - 1, 1 << 380, 3, q - 3]
+
+
+def test_fq_ops(eng):
+    xs = P.XORShift(101)
+    n = 200
+    A = edge_values() + rand_fq(xs, n - 11)
+    B = list(reversed(edge_values())) + rand_fq(xs, n - 11)
+    a, b = pack(A), pack(B)
+    for name, fn in [("FQ_MUL", RC.fq_mul), ("FQ_ADD", RC.fq_add), ("FQ_SUB", RC.fq_sub)]:
+        out, _ = eng.debug_op(name, a, b)
+        exp = np.stack([fn(a[6 * i:6 * i + 6], b[6 * i:6 * i + 6]) for i in range(n)])
+        assert np.array_equal(out, exp), name
+    for name, fn in [("FQ_SQR", RC.fq_sqr), ("FQ_NEG", RC.fq_neg)]:
+        out, _ = eng.debug_op(name, a)
+        exp = np.stack([fn(a[6 * i:6 * i + 6]) for i in range(n)])
+        assert np.array_equal(out, exp), name
+    out, ok = eng.debug_op("FQ_INV", a)
+    for i in range(n):
+        r, e = RC.fq_inverse(a[6 * i:6 * i + 6])
+        assert bool(ok[i]) == bool(r)
+        if r:
+            assert np.array_equal(out[i], e)
+    sq = pack([x * x % P.Q for x in A[:40]] + A[40:80])
+    out, ok = eng.debug_op("FQ_SQRT", sq)
+    for i in range(80):
+        r, e = RC.fq_sqrt(sq[6 * i:6 * i + 6])
+        assert bool(ok[i]) == bool(r), i
+        if r:
+            assert np.array_equal(out[i], e)
+
+
+def test_fq_carry_stress(eng):
+    # limbs of all-ones / alternating patterns exercise every column of the product and the lazy bounds
+    vals = [(1 << k) - 1 for k in range(1, 381, 7)] + [P.Q - ((1 << k) - 1) for k in range(1, 380, 11)]
+    a = pack(vals)
+    b = pack(list(reversed(vals)))
+    n = len(vals)
+    out, _ = eng.debug_op("FQ_MUL", a, b)
+    exp = np.stack([RC.fq_mul(a[6 * i:6 * i + 6], b[6 * i:6 * i + 6]) for i in range(n)])
+    assert np.array_equal(out, exp)
+
+
+def test_fq2_ops(eng):
+    xs = P.XORShift(102)
+    n = 70
+    A = [rand_fq(xs, 2) for _ in range(n)]; B = [rand_fq(xs, 2) for _ in range(n)]
+    A[0] = [0, 0]; A[1] = [1, 0]; A[2] = [0, 1]; A[3] = [P.Q - 1, P.Q - 1]
+    a = np.stack([pack(x) for x in A]); b = np.stack([pack(x) for x in B])
+    out, _ = eng.debug_op("FQ2_MUL", a, b)
+    assert np.array_equal(out, np.stack([RC.fq2_mul(a[i], b[i]) for i in range(n)]))
+    out, _ = eng.debug_op("FQ2_SQR", a)
+    assert np.array_equal(out, np.stack([RC.fq2_sqr(a[i]) for i in range(n)]))
+    out, _ = eng.debug_op("FQ2_MUL_NR", a)
+    assert np.array_equal(out, np.stack([RC.fq2_mul_nr(a[i]) for i in range(n)]))
+    out, ok = eng.debug_op("FQ2_INV", a)
+    for i in range(n):
+        r, e = RC.fq2_inverse(a[i])
+        assert bool(ok[i]) == bool(r)
+        if r:
+            assert np.array_equal(out[i], e)
+    sq = np.stack([RC.fq2_sqr(a[i]) for i in range(n // 2)] + [a[i] for i in range(n // 2, n)])
+    out, ok = eng.debug_op("FQ2_SQRT", sq)
+    for i in range(n):
+        r, e = RC.fq2_sqrt(sq[i])
+        assert bool(ok[i]) == bool(r), i
+        if r:
+            assert np.array_equal(out[i], e), i
+
+
+def test_fq6_fq12_ops(eng):
+    xs = P.XORShift(103)
+    n = 66
+    a6 = np.stack([pack(rand_fq(xs, 6)) for _ in range(n)]); b6 = np.stack([pack(rand_fq(xs, 6)) for _ in range(n)])
+    out, _ = eng.debug_op("FQ6_MUL", a6, b6)
+    assert np.array_equal(out, np.stack([RC.fq6_mul(a6[i], b6[i]) for i in range(n)]))
+    out, _ = eng.debug_op("FQ6_SQR", a6)
+    assert np.array_equal(out, np.stack([RC.fq6_sqr(a6[i]) for i in range(n)]))
+    out, _ = eng.debug_op("FQ6_INV", a6)
+    assert np.array_equal(out, np.stack([RC.fq6_inverse(a6[i])[1] for i in range(n)]))
+    out, _ = eng.debug_op("FQ6_FROB1", a6)
+    assert np.array_equal(out, np.stack([RC.fq6_frobenius(a6[i], 1) for i in range(n)]))
+    a12 = np.stack([pack(rand_fq(xs, 12)) for _ in range(n)]); b12 = np.stack([pack(rand_fq(xs, 12)) for _ in range(n)])
+    out, _ = eng.debug_op("FQ12_MUL", a12, b12)
+    assert np.array_equal(out, np.stack([RC.fq12_mul(a12[i], b12[i]) for i in range(n)]))
+    out, _ = eng.debug_op("FQ12_SQR", a12)
+    assert np.array_equal(out, np.stack([RC.fq12_sqr(a12[i]) for i in range(n)]))
+    out, _ = eng.debug_op("FQ12_INV", a12)
+    assert np.array_equal(out, np.stack([RC.fq12_inverse(a12[i])[1] for i in range(n)]))
+    for k, name in [(1, "FQ12_FROB1"), (2, "FQ12_FROB2"), (3, "FQ12_FROB3")]:
+        out, _ = eng.debug_op(name, a12)
+        assert np.array_equal(out, np.stack([RC.fq12_frobenius(a12[i], k) for i in range(n)]))
+    # cyclotomic squaring == squaring on the cyclotomic subgroup (elements after the easy part)
+    cyc = []
+    for i in range(16):
+        f = a12[i]
+        inv = RC.fq12_inverse(f)[1]
+        conj = f.copy()
+        for j in range(36, 72, 6):
+            conj[j:j + 6] = RC.fq_neg(f[j:j + 6])
+        r = RC.fq12_mul(conj, inv)
+        r = RC.fq12_mul(RC.fq12_frobenius(r, 2), r)
+        cyc.append(r)
+    cyc = np.stack(cyc)
+    out, _ = eng.debug_op("FQ12_CYCLO_SQR", cyc)
+    assert np.array_equal(out, np.stack([RC.fq12_sqr(c) for c in cyc]))
+
+
+def _jac(aff_bytes, z, group):
+    """affine bytes + a scaling z -> Jacobian (x z^2, y z^3, z) Montgomery limbs"""
+    if group == 1:
+        x, y = int.from_bytes(aff_bytes[:48], "big"), int.from_bytes(aff_bytes[48:], "big")
+        return pack([x * z * z % P.Q, y * z * z * z % P.Q, z])
+    x = (int.from_bytes(aff_bytes[:48], "big"), int.from_bytes(aff_bytes[48:96], "big"))
+    y = (int.from_bytes(aff_bytes[96:144], "big"), int.from_bytes(aff_bytes[144:], "big"))
+    zz = (z, 0)
+    z2 = P.fq2_sqr(zz)
+    xx = P.fq2_mul(x, z2); yy = P.fq2_mul(y, P.fq2_mul(z2, zz))
+    return pack([xx[0], xx[1], yy[0], yy[1], z, 0])
+
+
+def test_curve_ops(eng):
+    from gpu_common import rand_g1, rand_g2
+    xs = P.XORShift(104)
+    for group, rnd, dbl, add, to_aff, w in [(1, rand_g1, "G1_DOUBLE", "G1_ADD", RC.g1_jac_to_affine_bytes, 18), (2, rand_g2, "G2_DOUBLE", "G2_ADD", RC.g2_jac_to_affine_bytes, 36)]:
+        pts = [rnd(xs) for _ in range(12)]
+        A, B = [], []
+        for i in range(12):
+            A.append(_jac(pts[i], P.rand_int(xs, P.Q - 1) + 1, group))
+            B.append(_jac(pts[(i + 1) % 12], P.rand_int(xs, P.Q - 1) + 1, group))
+        # special cases of g1.go:400-482: same point (different z), opposite points, infinity on either side
+        A.append(_jac(pts[0], 5, group)); B.append(_jac(pts[0], 7, group))
+        neg = bytearray(pts[1])
+        if group == 1:
+            neg[48:] = ((P.Q - int.from_bytes(pts[1][48:], "big")) % P.Q).to_bytes(48, "big")
+        else:
+            for o in (96, 144):
+                neg[o:o + 48] = ((P.Q - int.from_bytes(pts[1][o:o + 48], "big")) % P.Q).to_bytes(48, "big")
+        A.append(_jac(pts[1], 3, group)); B.append(_jac(bytes(neg), 11, group))
+        zero = np.zeros(w, np.uint64); zero[w // 3:2 * w // 3][:6] = mont(1)
+        A.append(zero); B.append(_jac(pts[2], 9, group))
+        A.append(_jac(pts[3], 2, group)); B.append(zero)
+        A.append(zero); B.append(zero)
+        a, b = np.stack(A), np.stack(B)
+        fn_d = RC.g1_double if group == 1 else RC.g2_double
+        fn_a = RC.g1_add if group == 1 else RC.g2_add
+        out, _ = eng.debug_op(dbl, a)
+        for i in range(len(A)):
+            assert to_aff(out[i]) == to_aff(fn_d(a[i])), (group, "dbl", i)
+        out, _ = eng.debug_op(add, a, b)
+        for i in range(len(A)):
+            assert to_aff(out[i]) == to_aff(fn_a(a[i], b[i])), (group, "add", i)

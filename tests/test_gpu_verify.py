@@ -1,0 +1,255 @@
+"""-m gpu: the verify surface (BASELINE configs 1, 4, 5 at test sizes) through the host mirror of the
+reference API (bls_amd.g2pubs / bls_amd.g1pubs), against the CPU oracle: hash-to-curve outputs byte for
+byte, Verify verdict tables with corrupted tuples, VerifyAggregate / Common, duplicate rejection,
+infinity handling, compressed wire format."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from gpu_common import P, RC, rand_g1, rand_g2, sk_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bls_amd import engine
+    engine.init(0)
+    return engine
+
+
+MSGS = [b"", b"a", b"the message to be signed", b"Hello world! 16 characters 0", bytes(range(55)), bytes(range(56)), bytes(range(64)), bytes(200), b"x" * 1000]
+
+
+def test_hash_g1_kat_and_parity(eng, kats):
+    out = eng.hash_g1_batch(MSGS)
+    for i, m in enumerate(MSGS):
+        assert out[i].tobytes() == RC.hash_g1(m), i
+    k = kats["hash_g1"]
+    assert out[2].tobytes() == int(k["x"], 16).to_bytes(48, "big") + int(k["y"], 16).to_bytes(48, "big")
+    many = [b"Hello world! 16 characters %d" % i for i in range(70)]
+    out = eng.hash_g1_batch(many)
+    assert all(out[i].tobytes() == RC.hash_g1(m) for i, m in enumerate(many))
+
+
+def test_hash_g2_kat_and_parity(eng, kats):
+    out = eng.hash_g2_batch(MSGS)
+    for i, m in enumerate(MSGS):
+        assert out[i].tobytes() == RC.hash_g2(m), i
+    k = kats["hash_g2"]
+    exp = b"".join(int(k[f], 16).to_bytes(48, "big") for f in ("x_c0", "x_c1", "y_c0", "y_c1"))
+    assert out[2].tobytes() == exp
+
+
+def test_hash_g2_with_domain_kat_and_parity(eng, kats):
+    msgs = [bytes(32)] + [hashlib.sha256(bytes([i])).digest() for i in range(5)]
+    dom = bytes(8)
+    out = eng.hash_g2_with_domain_batch(msgs, dom)
+    for i, m in enumerate(msgs):
+        assert out[i].tobytes() == RC.hash_g2_with_domain(m, dom), i
+    assert RC.g2_compress(out[0].tobytes()).hex() == kats["hash_g2_with_domain"]["compressed_hex"]
+    dom2 = bytes([1, 2, 3, 4, 5, 6, 7, 8])
+    out = eng.hash_g2_with_domain_batch(msgs[:2], dom2)
+    assert out[1].tobytes() == RC.hash_g2_with_domain(msgs[1], dom2)
+
+
+def _tuples(group, n, seed):
+    """config 1 / 5 construction: seeded keys, messages 'Hello world! 16 characters %d', every 4th tuple
+    corrupted in rotation (wrong message / wrong key / negated signature)."""
+    xs = P.XORShift(seed)
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    msgs, pks, sigs, expect = [], [], [], []
+    for i in range(n):
+        sk = sk_bytes(xs)
+        m = b"Hello world! 16 characters %d" % i
+        pk, sig = o.priv_to_pub(sk), o.sign(m, sk)
+        good = True
+        if i % 4 == 3:
+            good = False
+            kind = (i // 4) % 3
+            if kind == 0:
+                m = m + b"!"
+            elif kind == 1:
+                pk = o.priv_to_pub(sk_bytes(xs))
+            else:
+                sb = bytearray(sig)
+                if group == "g2pubs":
+                    sb[48:] = ((P.Q - int.from_bytes(sig[48:], "big")) % P.Q).to_bytes(48, "big")
+                else:
+                    for off in (96, 144):
+                        sb[off:off + 48] = ((P.Q - int.from_bytes(sig[off:off + 48], "big")) % P.Q).to_bytes(48, "big")
+                sig = bytes(sb)
+        msgs.append(m); pks.append(pk); sigs.append(sig); expect.append(good)
+    return msgs, pks, sigs, expect
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_verify_batch_verdict_table(eng, group):
+    import bls_amd.g1pubs as g1p
+    import bls_amd.g2pubs as g2p
+    n = 70
+    msgs, pks, sigs, expect = _tuples(group, n, 1 if group == "g2pubs" else 5)
+    mod = g2p if group == "g2pubs" else g1p
+    mk_pk = mod.NewPublicKeyFromG2 if group == "g2pubs" else mod.NewPublicKeyFromG1
+    mk_sig = mod.NewSignatureFromG1 if group == "g2pubs" else mod.NewSignatureFromG2
+    got = mod.VerifyBatch(msgs, [mk_pk(p) for p in pks], [mk_sig(s) for s in sigs])
+    assert got == expect
+    # oracle agrees tuple by tuple (sampled: the oracle takes ~10 ms per verify)
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    for i in range(0, n, 5):
+        assert o.verify(msgs[i], pks[i], sigs[i]) == expect[i]
+    # single-call form and bitmap packing
+    assert mod.Verify(msgs[0], mk_pk(pks[0]), mk_sig(sigs[0])) is True
+    assert mod.Verify(msgs[3], mk_pk(pks[3]), mk_sig(sigs[3])) is False
+    fn = eng.g2pubs_verify_batch if group == "g2pubs" else eng.g1pubs_verify_batch
+    ok, bitmap = fn(msgs, b"".join(pks), b"".join(sigs))
+    assert list(ok) == expect
+    assert [bool(bitmap[i >> 3] >> (i & 7) & 1) for i in range(n)] == expect
+    # a tuple flagged as containing the point at infinity is rejected (the reference panics there)
+    flags = [0] * n; flags[0] = 1; flags[1] = 2
+    ok, _ = fn(msgs, b"".join(pks), b"".join(sigs), flags)
+    assert not ok[0] and not ok[1] and list(ok[2:]) == expect[2:]
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_verify_aggregate(eng, group):
+    import bls_amd.g1pubs as g1p
+    import bls_amd.g2pubs as g2p
+    mod = g2p if group == "g2pubs" else g1p
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    mk_pk = mod.NewPublicKeyFromG2 if group == "g2pubs" else mod.NewPublicKeyFromG1
+    mk_sig = mod.NewSignatureFromG1 if group == "g2pubs" else mod.NewSignatureFromG2
+    xs = P.XORShift(4)
+    n = 9
+    sks = [sk_bytes(xs) for _ in range(n)]
+    msgs = [b">16 character identical message %d" % i for i in range(n)]
+    pks = [o.priv_to_pub(sk) for sk in sks]
+    sigs = [o.sign(m, sk) for m, sk in zip(msgs, sks)]
+    agg = mod.AggregateSignatures([mk_sig(s) for s in sigs])
+    ref_agg = (RC.g1_sum if group == "g2pubs" else RC.g2_sum)(b"".join(sigs), n)
+    assert agg.s.raw == ref_agg
+    pubs = [mk_pk(p) for p in pks]
+    assert agg.VerifyAggregate(pubs, msgs) is True
+    assert o.verify_aggregate(ref_agg, pks, msgs) is True
+    assert agg.VerifyAggregate(pubs[:-1], msgs) is False                                   # length mismatch
+    assert agg.VerifyAggregate(pubs, msgs[:1] + msgs[:1] + msgs[2:]) is False               # duplicate message
+    assert agg.VerifyAggregate(pubs, [msgs[1], msgs[0]] + msgs[2:]) is False                # permuted messages
+    assert agg.VerifyAggregate(pubs, [b""] + msgs[1:]) is False                             # empty message (nil compare upstream)
+    bad = mod.AggregateSignatures([mk_sig(s) for s in sigs[:-1]])
+    assert bad.VerifyAggregate(pubs, msgs) is False
+    # n = 1 and n = 2 (odd/even tree shapes)
+    for k in (1, 2, 3):
+        a = mod.AggregateSignatures([mk_sig(s) for s in sigs[:k]])
+        assert a.VerifyAggregate(pubs[:k], msgs[:k]) is True
+    # common message (AggregatePublicKeys + Verify), with a missing signature (g2pubs/bls_test.go:47-90)
+    msg = b">16 character identical message"
+    csigs = [o.sign(msg, sk) for sk in sks]
+    cagg = mod.AggregateSignatures([mk_sig(s) for s in csigs])
+    assert cagg.VerifyAggregateCommon(pubs, msg) is True
+    assert o.verify_aggregate_common(cagg.s.raw, pks, msg) is True
+    miss = mod.AggregateSignatures([mk_sig(s) for s in csigs[1:]])
+    assert miss.VerifyAggregateCommon(pubs, msg) is False
+    apk = mod.AggregatePublicKeys(pubs)
+    assert apk.p.raw == (RC.g2_sum if group == "g2pubs" else RC.g1_sum)(b"".join(pks), n)
+
+
+def test_g1pubs_with_domain(eng):
+    import bls_amd.g1pubs as g1p
+    xs = P.XORShift(6)
+    dom = bytes([1, 0, 0, 0, 0, 0, 0, 0])
+    n = 5
+    sks = [sk_bytes(xs) for _ in range(n)]
+    msgs = [hashlib.sha256(bytes([i])).digest() for i in range(n)]
+    pks = [RC.g1pubs.priv_to_pub(sk) for sk in sks]
+    sigs = [RC.g1pubs.sign_with_domain(m, sk, dom) for m, sk in zip(msgs, sks)]
+    pubs = [g1p.NewPublicKeyFromG1(p) for p in pks]; ss = [g1p.NewSignatureFromG2(s) for s in sigs]
+    assert g1p.VerifyWithDomainBatch(msgs, pubs, ss, dom) == [True] * n
+    assert g1p.VerifyWithDomainBatch(msgs, pubs, ss, bytes(8)) == [False] * n
+    assert g1p.VerifyWithDomain(msgs[0], pubs[1], ss[0], dom) is False
+    agg = g1p.AggregateSignatures(ss)
+    assert g1p.VerifyAggregateWithDomain(agg, pubs, msgs, dom) is True
+    assert RC.g1pubs.verify_aggregate_with_domain(agg.s.raw, pks, msgs, dom) is True
+    assert g1p.VerifyAggregateWithDomain(agg, pubs, list(reversed(msgs)), dom) is False
+    # no duplicate-message check in the WithDomain form (g1pubs/bls.go:300-311)
+    dsigs = [RC.g1pubs.sign_with_domain(msgs[0], sk, dom) for sk in sks[:2]]
+    dagg = g1p.AggregateSignatures([g1p.NewSignatureFromG2(s) for s in dsigs])
+    assert g1p.VerifyAggregateWithDomain(dagg, pubs[:2], [msgs[0], msgs[0]], dom) is True
+    assert g1p.VerifyAggregateCommonWithDomain(dagg, pubs[:2], msgs[0], dom) is True
+    # device-side signing equals the oracle's
+    mine = g1p.SignWithDomainBatch(msgs[:2], sks[:2], dom)
+    assert [s.s.raw for s in mine] == sigs[:2]
+
+
+def test_sign_on_device_matches_oracle(eng):
+    import bls_amd.g1pubs as g1p
+    import bls_amd.g2pubs as g2p
+    xs = P.XORShift(1)
+    sks = [sk_bytes(xs) for _ in range(3)]
+    msgs = [b"Hello world! 16 characters %d" % i for i in range(3)]
+    assert [s.s.raw for s in g2p.SignBatch(msgs, sks)] == [RC.g2pubs.sign(m, sk) for m, sk in zip(msgs, sks)]
+    assert [s.s.raw for s in g1p.SignBatch(msgs, sks)] == [RC.g1pubs.sign(m, sk) for m, sk in zip(msgs, sks)]
+
+
+def test_scalar_mul_and_sums(eng):
+    xs = P.XORShift(3)
+    n = 67
+    pts1 = [rand_g1(xs) for _ in range(n)]; pts2 = [rand_g2(xs) for _ in range(n)]
+    ks = [sk_bytes(xs) for _ in range(n)]
+    ks[0] = bytes(32); ks[1] = (1).to_bytes(32, "big"); ks[2] = P.R_ORDER.to_bytes(32, "big"); ks[3] = (P.R_ORDER - 1).to_bytes(32, "big"); ks[4] = (2).to_bytes(32, "big")
+    out, inf = eng.g1_mul_batch(b"".join(pts1), b"".join(ks), n)
+    for i in range(n):
+        e = RC.g1_mul(pts1[i], ks[i])
+        assert (e is None) == bool(inf[i]) and (e is None or out[i].tobytes() == e), i
+    out, inf = eng.g2_mul_batch(b"".join(pts2), b"".join(ks), n)
+    for i in range(n):
+        e = RC.g2_mul(pts2[i], ks[i])
+        assert (e is None) == bool(inf[i]) and (e is None or out[i].tobytes() == e), i
+    for m in (1, 2, 3, 64, 65, 67):
+        assert eng.g1_sum(b"".join(pts1[:m]), m) == RC.g1_sum(b"".join(pts1[:m]), m)
+        assert eng.g2_sum(b"".join(pts2[:m]), m) == RC.g2_sum(b"".join(pts2[:m]), m)
+    # P + (-P) = infinity; infinity flags skip points; duplicates double
+    neg = bytearray(pts1[0]); neg[48:] = ((P.Q - int.from_bytes(pts1[0][48:], "big")) % P.Q).to_bytes(48, "big")
+    assert eng.g1_sum(pts1[0] + bytes(neg), 2) is None
+    assert eng.g1_sum(pts1[0] + pts1[0], 2) == RC.g1_sum(pts1[0] + pts1[0], 2)
+    assert eng.g1_sum(pts1[0] + pts1[1] + pts1[2], 3, [0, 1, 0]) == RC.g1_sum(pts1[0] + pts1[2], 2)
+    assert eng.g2_sum(b"", 0) is None
+
+
+def test_wire_format(eng, kats):
+    xs = P.XORShift(9)
+    n = 10
+    p1 = [rand_g1(xs) for _ in range(n)]; p2 = [rand_g2(xs) for _ in range(n)]
+    c1 = eng.g1_compress_batch(b"".join(p1), n); c2 = eng.g2_compress_batch(b"".join(p2), n)
+    assert [c.tobytes() for c in c1] == [RC.g1_compress(p) for p in p1]
+    assert [c.tobytes() for c in c2] == [RC.g2_compress(p) for p in p2]
+    out, inf, err = eng.g1_decompress_batch(c1.reshape(-1), n)
+    assert not err.any() and not inf.any() and [o.tobytes() for o in out] == p1
+    out, inf, err = eng.g2_decompress_batch(c2.reshape(-1), n)
+    assert not err.any() and not inf.any() and [o.tobytes() for o in out] == p2
+    # error table: the reference's rejected encodings (g2pubs/bls_test.go:336-347, g1pubs/bls_test.go:422-433) + crafted
+    bad2 = bytes.fromhex(kats["invalid_pubkey_g2pubs_hex"]); bad1 = bytes.fromhex(kats["invalid_pubkey_g1pubs_hex"])
+    inf1 = RC.g1_compress(None); junk = bytearray(inf1); junk[7] = 1
+    cases1 = [bad1, bytes(48), inf1, bytes(junk), c1[0].tobytes()]
+    out, inf, err = eng.g1_decompress_batch(b"".join(cases1), len(cases1))
+    exp = [RC.g1_decompress(c) for c in cases1]
+    assert [int(e) for e in err] == [e for e, _ in exp]
+    assert bool(inf[2]) and err[2] == 0
+    out2, inf2, err2 = eng.g2_decompress_batch(bad2 + RC.g2_compress(None), 2)
+    assert int(err2[0]) == RC.g2_decompress(bad2)[0] != 0 and bool(inf2[1]) and err2[1] == 0
+    # a curve point outside the prime-order subgroup is rejected only when the check is on
+    x = 0
+    while True:
+        pt = P.g1_from_x(x, False)
+        if pt is not None and not P.g1_in_subgroup(pt):
+            break
+        x += 1
+    comp = P.g1_compress(pt)
+    _, _, e_on = eng.g1_decompress_batch(comp, 1, True)
+    _, _, e_off = eng.g1_decompress_batch(comp, 1, False)
+    assert int(e_on[0]) == 4 and int(e_off[0]) == 0
+    from bls_amd import g2pubs
+    with pytest.raises(g2pubs.DeserializeError):
+        g2pubs.DeserializePublicKey(bad2)
+    pk = g2pubs.DeserializePublicKey(c2[0].tobytes())
+    assert pk.p.raw == p2[0] and pk.Serialize() == c2[0].tobytes()
