@@ -338,6 +338,24 @@ int ensure_init(int device) {
 }
 inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
 
+// Grow-only scratch for the Miller-loop -> final-exponentiation hand-off (avoids a hipMalloc/hipFree
+// pair, and the implicit device synchronisation of hipFree, on every call).
+struct Workspace {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+} g_ws;
+// optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline object
+bool g_profile = false;
+hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
+float g_last_ms[2] = {0.f, 0.f};
+
 // RAII device buffer
 struct DBuf {
     void* p = nullptr;
@@ -360,6 +378,7 @@ BLSMI_API void blsmi_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_ready) return;
     (void)hipStreamSynchronize(g_stream);
+    if (g_ws.p) { (void)hipFree(g_ws.p); g_ws.p = nullptr; g_ws.cap = 0; }
     (void)hipStreamDestroy(g_stream);
     g_stream = nullptr;
     g_ready = false;
@@ -369,12 +388,31 @@ BLSMI_API const char* blsmi_version(void) { return g_version; }
 // ---- pairing ------------------------------------------------------------------------------------
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;
-    DBuf f;
-    HIPCHK(f.alloc(sizeof(i32) * 12 * NL * n));
-    hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f.as<i32>(), n);
-    hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, f.as<i32>(), (u64*)d_out, n, mode);
+    HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
+    i32* f = reinterpret_cast<i32*>(g_ws.p);
+    if (g_profile) HIPCHK(hipEventRecord(g_ev[0], s));
+    hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+    if (g_profile) HIPCHK(hipEventRecord(g_ev[1], s));
+    hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
+    if (g_profile) HIPCHK(hipEventRecord(g_ev[2], s));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));      // the scratch buffer dies with this scope
+    HIPCHK(hipStreamSynchronize(s));      // blocking entry point: results are ready on return
+    if (g_profile) {
+        HIPCHK(hipEventElapsedTime(&g_last_ms[0], g_ev[0], g_ev[1]));
+        HIPCHK(hipEventElapsedTime(&g_last_ms[1], g_ev[1], g_ev[2]));
+    }
+    return BLSMI_OK;
+}
+// Enable/disable per-kernel HIP-event timing of blsmi_pairing_batch[_dev]; read back with blsmi_last_kernel_ms.
+BLSMI_API int blsmi_set_profiling(int on) {
+    LOCK_AND_INIT();
+    if (on && !g_ev[0]) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&g_ev[i]));
+    g_profile = on != 0;
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_last_kernel_ms(float* miller_ms, float* final_exp_ms) {
+    if (!miller_ms || !final_exp_ms) return BLSMI_E_ARG;
+    *miller_ms = g_last_ms[0]; *final_exp_ms = g_last_ms[1];
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_pairing_batch_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, void* stream) {

@@ -8,8 +8,8 @@
  * Conventions
  *   - Host entry points (no suffix) take HOST pointers, are blocking and re-entrant; the library
  *     owns device memory and streams.  `_dev` entry points take DEVICE pointers (inputs already
- *     resident in HBM) plus a hipStream_t passed as void*, enqueue on that stream and return
- *     without synchronising.
+ *     resident in HBM) plus a hipStream_t passed as void* (NULL = the library's stream); the work is
+ *     enqueued on that stream and the call returns after synchronising it (results are ready).
  *   - Field elements on the wire are 48-byte big-endian normal form, exactly
  *     G1Affine.SerializeBytes / G2Affine.SerializeBytes of the reference
  *     (g1.go:157-167: x||y, 96 B; g2.go:172-186: x.c0||x.c1||y.c0||y.c1, 192 B).
@@ -49,6 +49,10 @@ const char *blsmi_version(void);
 int blsmi_pairing_batch(const uint8_t *g1_aff /* n*96 */, const uint8_t *g2_aff /* n*192 */,
                         uint64_t *out_fq12 /* n*72 */, size_t n);
 int blsmi_pairing_batch_dev(const void *d_g1_aff, const void *d_g2_aff, void *d_out_fq12, size_t n, void *stream);
+/* Per-kernel HIP-event timing of the last blsmi_pairing_batch[_dev] call (used by bench.py for the
+ * roofline object): Miller-loop kernel and final-exponentiation kernel durations in milliseconds. */
+int blsmi_set_profiling(int on);
+int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
 /* Miller loop only (pairing.go:16-75 with one pair per tuple), same output format */
 int blsmi_miller_loop_batch(const uint8_t *g1_aff, const uint8_t *g2_aff, uint64_t *out_fq12, size_t n);
 /* Final exponentiation only (pairing.go:79-129) on n Fq12 values in the output format */
