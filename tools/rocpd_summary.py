@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd (.db) outputs into text: per-kernel dispatch statistics
+(--kernel-trace --stats) and per-kernel PMC counter averages (--pmc ...).
+usage: rocpd_summary.py out.txt db1 [db2 ...]"""
+import sqlite3, sys, collections
+
+def kernels(db):
+    q = """select s.kernel_name, count(*), avg(d.end - d.start), min(d.end - d.start), max(d.end - d.start), sum(d.end - d.start),
+                  max(s.arch_vgpr_count), max(s.accum_vgpr_count), max(s.sgpr_count), max(d.private_segment_size), max(d.grid_size_x), max(d.workgroup_size_x)
+           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name order by 6 desc"""
+    return list(db.execute(q))
+
+def pmcs(db):
+    q = """select s.kernel_name, p.name, count(*), avg(e.value), sum(e.value)
+           from rocpd_pmc_event e join rocpd_info_pmc p on e.pmc_id = p.id
+           join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+           group by s.kernel_name, p.name order by 1, 2"""
+    return list(db.execute(q))
+
+out = open(sys.argv[1], "w")
+for path in sys.argv[2:]:
+    db = sqlite3.connect(path)
+    out.write("== %s\n" % path)
+    ks = kernels(db)
+    tot = sum(k[5] for k in ks) or 1
+    out.write("%-52s %6s %12s %12s %12s %7s %5s %5s %5s %8s %8s\n" % ("kernel", "calls", "avg_ns", "min_ns", "max_ns", "pct", "vgpr", "agpr", "sgpr", "scratchB", "grid"))
+    for k in ks:
+        if k[5] / tot < 0.002: continue
+        out.write("%-52s %6d %12.0f %12d %12d %6.2f%% %5d %5d %5d %8d %8d\n" % (k[0][:52], k[1], k[2], k[3], k[4], 100.0 * k[5] / tot, k[6], k[7], k[8], k[9], k[10]))
+    pm = pmcs(db)
+    if pm:
+        out.write("-- PMC (per-dispatch average, summed over instances/XCDs as stored)\n")
+        agg = collections.OrderedDict()
+        for kn, pn, c, av, sm in pm:
+            agg.setdefault(kn, []).append((pn, c, av, sm))
+        for kn, rows in agg.items():
+            n_disp = max(1, [k[1] for k in ks if k[0] == kn][0] if [k for k in ks if k[0] == kn] else 1)
+            out.write("%s (dispatches=%d)\n" % (kn[:70], n_disp))
+            for pn, c, av, sm in rows:
+                out.write("    %-28s samples=%-6d sum/dispatch=%.6g\n" % (pn, c, sm / n_disp))
+    out.write("\n")
+out.close()
+print(open(sys.argv[1]).read())
