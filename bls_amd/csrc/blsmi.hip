@@ -16,7 +16,10 @@
 using namespace blsmi;
 
 #define WG 64
-#define KERNEL __global__ void __launch_bounds__(WG, 1)
+#ifndef BLSMI_WAVES_PER_SIMD
+#define BLSMI_WAVES_PER_SIMD 1
+#endif
+#define KERNEL __global__ void __launch_bounds__(WG, BLSMI_WAVES_PER_SIMD)
 
 // ------------------------------------------------------------------------------------------------
 // device-side I/O helpers

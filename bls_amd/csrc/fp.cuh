@@ -45,7 +45,7 @@ struct Fp {
     static constexpr int L = L_, V = V_;
     i32 v[NL];
 };
-using FpS = Fp<1, 128>;                // storage type: (near-)normalised limbs, |value| <= 128 q
+using FpS = Fp<1, 256>;                // storage type: (near-)normalised limbs, |value| <= 256 q
 using FpC = Fp<1, 1>;                  // canonical: limbs in [0,2^27), value in [0,q)
 
 }  // namespace blsmi
@@ -325,7 +325,7 @@ __device__ __noinline__ vlimbs fp_pow_core(vlimbs a, const u32* ebits, int nbits
 }
 template <int L, int V>
 BLSMI_DEV FpS fp_pow_const(const Fp<L, V>& a, const u32* ebits, int nbits) {
-    const FpS base = fp_store(a);                          // L = 1, |value| <= 128 q: products stay valid
+    const FpS base = fp_store(a);                          // L = 1, |value| <= 256 q: products stay valid
     vlimbs x;
 #pragma unroll
     for (int i = 0; i < NL; i++) x[i] = base.v[i];

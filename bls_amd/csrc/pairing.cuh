@@ -33,49 +33,49 @@ BLSMI_DEV void fp12_conj_inplace(Fp12S& a) { a.c1 = fp6_store(fp6_neg(a.c1)); }
 
 // g2.go:655-708
 BLSMI_NOINLINE void doubling_step(G2Proj& r, Fp2S& o0, Fp2S& o1, Fp2S& o2) {
-    const Fp2S tmp0 = fp2_store(fp2_sqr(r.x));
-    const Fp2S tmp1 = fp2_store(fp2_sqr(r.y));
-    const Fp2S tmp2 = fp2_store(fp2_sqr(tmp1));
-    const Fp2S tmp3 = fp2_store(fp2_dbl(fp2_sub(fp2_sub(fp2_sqr(fp2_add(tmp1, r.x)), tmp0), tmp2)));
-    const Fp2S tmp4 = fp2_store(fp2_muls<3>(tmp0));
-    const Fp2S tmp6 = fp2_store(fp2_add(r.x, tmp4));
-    const Fp2S tmp5 = fp2_store(fp2_sqr(tmp4));
-    const Fp2S zsq = fp2_store(fp2_sqr(r.z));
-    const Fp2S nx = fp2_store(fp2_sub(fp2_sub(tmp5, tmp3), tmp3));
-    const Fp2S nz = fp2_store(fp2_sub(fp2_sub(fp2_sqr(fp2_add(r.z, r.y)), tmp1), zsq));
-    const Fp2S ny = fp2_store(fp2_sub(fp2_mul(fp2_sub(tmp3, nx), tmp4), fp2_muls<8>(tmp2)));
+    const auto tmp0 = fp2_norm(fp2_sqr(r.x));
+    const auto tmp1 = fp2_norm(fp2_sqr(r.y));
+    const auto tmp2 = fp2_norm(fp2_sqr(tmp1));
+    const auto tmp3 = fp2_norm(fp2_dbl(fp2_sub(fp2_sub(fp2_sqr(fp2_add(tmp1, r.x)), tmp0), tmp2)));
+    const auto tmp4 = fp2_norm(fp2_muls<3>(tmp0));
+    const auto tmp6 = fp2_norm(fp2_add(r.x, tmp4));
+    const auto tmp5 = fp2_norm(fp2_sqr(tmp4));
+    const auto zsq = fp2_norm(fp2_sqr(r.z));
+    const auto nx = fp2_norm(fp2_sub(fp2_sub(tmp5, tmp3), tmp3));
+    const auto nz = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(r.z, r.y)), tmp1), zsq));
+    const auto ny = fp2_norm(fp2_sub(fp2_mul(fp2_sub(tmp3, nx), tmp4), fp2_muls<8>(tmp2)));
     o1 = fp2_store(fp2_neg(fp2_dbl(fp2_mul(tmp4, zsq))));
     o2 = fp2_store(fp2_sub(fp2_sub(fp2_sub(fp2_sqr(tmp6), tmp0), tmp5), fp2_muls<4>(tmp1)));
     o0 = fp2_store(fp2_dbl(fp2_mul(nz, zsq)));
-    r.x = nx; r.y = ny; r.z = nz;
+    r.x = fp2_store(nx); r.y = fp2_store(ny); r.z = fp2_store(nz);
 }
 // g2.go:710-772
 BLSMI_NOINLINE void addition_step(G2Proj& r, const Fp2S& qx, const Fp2S& qy, Fp2S& o0, Fp2S& o1, Fp2S& o2) {
-    const Fp2S zsq = fp2_store(fp2_sqr(r.z));
-    const Fp2S ysq = fp2_store(fp2_sqr(qy));
-    const Fp2S t0 = fp2_store(fp2_mul(zsq, qx));
-    const Fp2S t1 = fp2_store(fp2_mul(fp2_sub(fp2_sub(fp2_sqr(fp2_add(qy, r.z)), ysq), zsq), zsq));
-    const Fp2S t2 = fp2_store(fp2_sub(t0, r.x));
-    const Fp2S t3 = fp2_store(fp2_sqr(t2));
-    const Fp2S t4 = fp2_store(fp2_muls<4>(t3));
-    const Fp2S t5 = fp2_store(fp2_mul(t4, t2));
-    const Fp2S t6 = fp2_store(fp2_sub(fp2_sub(t1, r.y), r.y));
-    const Fp2S t9 = fp2_store(fp2_mul(t6, qx));
-    const Fp2S t7 = fp2_store(fp2_mul(t4, r.x));
-    const Fp2S nx = fp2_store(fp2_sub(fp2_sub(fp2_sub(fp2_sqr(t6), t5), t7), t7));
-    const Fp2S nz = fp2_store(fp2_sub(fp2_sub(fp2_sqr(fp2_add(r.z, t2)), zsq), t3));
-    const Fp2S t8 = fp2_store(fp2_mul(fp2_sub(t7, nx), t6));
-    const Fp2S ny = fp2_store(fp2_sub(t8, fp2_dbl(fp2_mul(r.y, t5))));
-    const Fp2S t10 = fp2_store(fp2_sub(fp2_sub(fp2_sqr(fp2_add(qy, nz)), ysq), fp2_sqr(nz)));
+    const auto zsq = fp2_norm(fp2_sqr(r.z));
+    const auto ysq = fp2_norm(fp2_sqr(qy));
+    const auto t0 = fp2_norm(fp2_mul(zsq, qx));
+    const auto t1 = fp2_norm(fp2_mul(fp2_sub(fp2_sub(fp2_sqr(fp2_add(qy, r.z)), ysq), zsq), zsq));
+    const auto t2 = fp2_norm(fp2_sub(t0, r.x));
+    const auto t3 = fp2_norm(fp2_sqr(t2));
+    const auto t4 = fp2_norm(fp2_muls<4>(t3));
+    const auto t5 = fp2_norm(fp2_mul(t4, t2));
+    const auto t6 = fp2_norm(fp2_sub(fp2_sub(t1, r.y), r.y));
+    const auto t9 = fp2_norm(fp2_mul(t6, qx));
+    const auto t7 = fp2_norm(fp2_mul(t4, r.x));
+    const auto nx = fp2_norm(fp2_sub(fp2_sub(fp2_sub(fp2_sqr(t6), t5), t7), t7));
+    const auto nz = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(r.z, t2)), zsq), t3));
+    const auto t8 = fp2_norm(fp2_mul(fp2_sub(t7, nx), t6));
+    const auto ny = fp2_norm(fp2_sub(t8, fp2_dbl(fp2_mul(r.y, t5))));
+    const auto t10 = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(qy, nz)), ysq), fp2_sqr(nz)));
     o2 = fp2_store(fp2_sub(fp2_dbl(t9), t10));
     o0 = fp2_store(fp2_dbl(nz));
     o1 = fp2_store(fp2_dbl(fp2_neg(t6)));
-    r.x = nx; r.y = ny; r.z = nz;
+    r.x = fp2_store(nx); r.y = fp2_store(ny); r.z = fp2_store(nz);
 }
 // pairing.go:28-39: f *= line evaluated at P (sparse 014 multiplication)
 BLSMI_NOINLINE void ell(Fp12S& f, const Fp2S& o0, const Fp2S& o1, const Fp2S& o2, const FpS& px, const FpS& py) {
-    const Fp2S c0 = fp2_store(fp2_mul_fp(o0, py));
-    const Fp2S c1 = fp2_store(fp2_mul_fp(o1, px));
+    const auto c0 = fp2_mul_fp(o0, py);
+    const auto c1 = fp2_mul_fp(o1, px);
     f = fp12_store(fp12_mul_by_014(f, o2, c1, c0));
 }
 

@@ -138,6 +138,7 @@ BLSMI_DEV Fp2S fp2_sqrt(const Fp2<L, V>& a_in, bool& ok) {
 template <int La, int Va, int Lb, int Vb> BLSMI_DEV auto fp6_add(const Fp6<La, Va>& a, const Fp6<Lb, Vb>& b) { return make_fp6(fp2_add(a.c0, b.c0), fp2_add(a.c1, b.c1), fp2_add(a.c2, b.c2)); }
 template <int La, int Va, int Lb, int Vb> BLSMI_DEV auto fp6_sub(const Fp6<La, Va>& a, const Fp6<Lb, Vb>& b) { return make_fp6(fp2_sub(a.c0, b.c0), fp2_sub(a.c1, b.c1), fp2_sub(a.c2, b.c2)); }
 template <int L, int V> BLSMI_DEV auto fp6_neg(const Fp6<L, V>& a) { return make_fp6(fp2_neg(a.c0), fp2_neg(a.c1), fp2_neg(a.c2)); }
+template <int L, int V> BLSMI_DEV auto fp6_norm(const Fp6<L, V>& a) { return make_fp6(fp2_norm(a.c0), fp2_norm(a.c1), fp2_norm(a.c2)); }
 template <int L, int V> BLSMI_DEV Fp6S fp6_store(const Fp6<L, V>& a) { Fp6S r; r.c0 = fp2_store(a.c0); r.c1 = fp2_store(a.c1); r.c2 = fp2_store(a.c2); return r; }
 BLSMI_DEV Fp6S fp6_zero() { Fp6S r; r.c0 = fp2_zero(); r.c1 = fp2_zero(); r.c2 = fp2_zero(); return r; }
 BLSMI_DEV Fp6S fp6_one() { Fp6S r; r.c0 = fp2_one(); r.c1 = fp2_zero(); r.c2 = fp2_zero(); return r; }
@@ -210,23 +211,23 @@ template <int L, int V> BLSMI_DEV auto fp12_conj(const Fp12<L, V>& a) { return m
 // fq12.go:198-213
 template <int La, int Va, int Lb, int Vb>
 BLSMI_DEV auto fp12_mul(const Fp12<La, Va>& a, const Fp12<Lb, Vb>& b) {
-    const Fp6S aa = fp6_store(fp6_mul(a.c0, b.c0));
-    const Fp6S bb = fp6_store(fp6_mul(a.c1, b.c1));
+    const auto aa = fp6_norm(fp6_mul(a.c0, b.c0));       // tight bounds (normalised limbs, value bound kept)
+    const auto bb = fp6_norm(fp6_mul(a.c1, b.c1));
     const auto t = fp6_mul(fp6_add(a.c1, a.c0), fp6_add(b.c0, b.c1));
     return make_fp12(fp6_add(fp6_mul_nr(bb), aa), fp6_sub(fp6_sub(t, aa), bb));
 }
 // fq12.go:180-195
 template <int L, int V>
 BLSMI_DEV auto fp12_sqr(const Fp12<L, V>& a) {
-    const Fp6S ab = fp6_store(fp6_mul(a.c0, a.c1));
+    const auto ab = fp6_norm(fp6_mul(a.c0, a.c1));
     const auto t = fp6_mul(fp6_add(fp6_mul_nr(a.c1), a.c0), fp6_add(a.c0, a.c1));
     return make_fp12(fp6_sub(fp6_sub(t, ab), fp6_mul_nr(ab)), fp6_add(ab, ab));
 }
 // fq12.go:32-47
 template <int L, int V, int L0, int V0, int L1, int V1, int L4, int V4>
 BLSMI_DEV auto fp12_mul_by_014(const Fp12<L, V>& a, const Fp2<L0, V0>& c0, const Fp2<L1, V1>& c1, const Fp2<L4, V4>& c4) {
-    const Fp6S aa = fp6_store(fp6_mul_by_01(a.c0, c0, c1));
-    const Fp6S bb = fp6_store(fp6_mul_by_1(a.c1, c4));
+    const auto aa = fp6_norm(fp6_mul_by_01(a.c0, c0, c1));
+    const auto bb = fp6_norm(fp6_mul_by_1(a.c1, c4));
     const auto t = fp6_mul_by_01(fp6_add(a.c1, a.c0), c0, fp2_add(c1, c4));
     return make_fp12(fp6_add(fp6_mul_nr(bb), aa), fp6_sub(fp6_sub(t, aa), bb));
 }
@@ -247,27 +248,30 @@ BLSMI_DEV auto fp12_frob(const Fp12<L, V>& a) {
 // Granger-Scott squaring for elements of the cyclotomic subgroup (after the easy part of the final
 // exponentiation).  The reference has no such routine -- FQ12.Exp (fq12.go:108-120) squares with a
 // full multiplication -- but on the subgroup the value is the same: x^2.
+template <class A, class B> struct Pair { A first; B second; };
 template <int La, int Va, int Lb, int Vb>
-BLSMI_DEV void fp4_sqr(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b, Fp2S& c0, Fp2S& c1) {
-    const Fp2S t0 = fp2_store(fp2_sqr(a));
-    const Fp2S t1 = fp2_store(fp2_sqr(b));
-    c0 = fp2_store(fp2_add(fp2_mul_nr(t1), t0));
-    c1 = fp2_store(fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1));
+BLSMI_DEV auto fp4_sqr(const Fp2<La, Va>& a, const Fp2<Lb, Vb>& b) {
+    const auto t0 = fp2_norm(fp2_sqr(a));
+    const auto t1 = fp2_norm(fp2_sqr(b));
+    const auto c0 = fp2_norm(fp2_add(fp2_mul_nr(t1), t0));
+    const auto c1 = fp2_norm(fp2_sub(fp2_sub(fp2_sqr(fp2_add(a, b)), t0), t1));
+    return Pair<decltype(c0), decltype(c1)>{c0, c1};
 }
+// outputs are 3t -+ 2z with z an input: the representation doubles per squaring, so each output is
+// value-reduced (fp_store) -- the only place in the pairing where a reduction is inherent.
 BLSMI_DEV Fp12S fp12_cyclotomic_sqr(const Fp12S& f) {
-    Fp2S t0, t1, t2, t3;
     const Fp2S z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
     Fp12S r;
-    fp4_sqr(z0, z1, t0, t1);
-    r.c0.c0 = fp2_store(fp2_add(fp2_dbl(fp2_sub(t0, z0)), t0));
-    r.c1.c1 = fp2_store(fp2_add(fp2_dbl(fp2_add(t1, z1)), t1));
-    fp4_sqr(z2, z3, t0, t1);
-    fp4_sqr(z4, z5, t2, t3);
-    r.c0.c1 = fp2_store(fp2_add(fp2_dbl(fp2_sub(t0, z4)), t0));
-    r.c1.c2 = fp2_store(fp2_add(fp2_dbl(fp2_add(t1, z5)), t1));
-    const auto t3n = fp2_mul_nr(t3);
+    const auto a = fp4_sqr(z0, z1);
+    r.c0.c0 = fp2_store(fp2_add(fp2_dbl(fp2_sub(a.first, z0)), a.first));
+    r.c1.c1 = fp2_store(fp2_add(fp2_dbl(fp2_add(a.second, z1)), a.second));
+    const auto b = fp4_sqr(z2, z3);
+    const auto c = fp4_sqr(z4, z5);
+    r.c0.c1 = fp2_store(fp2_add(fp2_dbl(fp2_sub(b.first, z4)), b.first));
+    r.c1.c2 = fp2_store(fp2_add(fp2_dbl(fp2_add(b.second, z5)), b.second));
+    const auto t3n = fp2_norm(fp2_mul_nr(c.second));
     r.c1.c0 = fp2_store(fp2_add(fp2_dbl(fp2_add(t3n, z2)), t3n));
-    r.c0.c2 = fp2_store(fp2_add(fp2_dbl(fp2_sub(t2, z3)), t2));
+    r.c0.c2 = fp2_store(fp2_add(fp2_dbl(fp2_sub(c.first, z3)), c.first));
     return r;
 }
 template <int La, int Va, int Lb, int Vb>
