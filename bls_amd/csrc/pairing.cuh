@@ -106,8 +106,8 @@ BLSMI_DEV void miller_loop(Fp12S& f, const G1Aff (&p)[NP], const G2Aff (&q)[NP])
 BLSMI_NOINLINE void exp_by_x(Fp12S& out, const Fp12S& f, u64 e) {
     Fp12S res = f;
     for (int i = 62 - __builtin_clzll(e); i >= 0; i--) {
-        nf_fp12_cyc_sqr(res, res);
-        if ((e >> i) & 1) nf_fp12_mul(res, res, f);
+        res = fp12_cyclotomic_sqr(res);                                 // inlined: the accumulator stays in registers
+        if ((e >> i) & 1) { Fp12S t = res; nf_fp12_mul(t, t, f); res = t; }   // rare (<= 6 set bits): spill only here
     }
     fp12_conj_inplace(res);
     out = res;
