@@ -1,0 +1,133 @@
+"""-m gpu: BASELINE.json configs at FULL size, checked through size-independent properties (the oracle
+needs ~3 ms per pairing, so bit-for-bit comparison is done on seeded samples and the rest through
+identities that hold only if every element is right).
+
+config 3: 2^20-point G1 and G2 scalar multiplication + grand sum
+config 4: 2^20-signature g2pubs VerifyAggregate with distinct messages (single GPU here; the 8-way shard
+          is the same call per rank + the Fq12 partial-product gather)
+config 5: 262 144 g1pubs tuples with a corruption schedule
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from gpu_common import P, RC
+
+pytestmark = pytest.mark.gpu
+R = P.R_ORDER
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bls_amd import engine
+    engine.init(0)
+    return engine
+
+
+def scalars(n, seed):
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    raw[:, 0] &= 0x3f                       # < 2^254 < r
+    return raw
+
+
+def to_int_sum(raw):
+    """sum of big-endian 256-bit scalars mod r, vectorised over 32-bit words"""
+    w = raw.reshape(raw.shape[0], 8, 4).astype(np.uint64)
+    words = (w[:, :, 0] << 24) | (w[:, :, 1] << 16) | (w[:, :, 2] << 8) | w[:, :, 3]
+    tot = 0
+    for j in range(8):
+        tot = (tot << 32) + int(words[:, j].sum())
+    return tot % R
+
+
+def test_config3_msm_1m_points(eng):
+    n = 1 << 20
+    k = scalars(n, 3)
+    for gen, mul, summ, ref_mul, pb in [(RC.g1_generator(), eng.g1_mul_batch, eng.g1_sum, RC.g1_mul, 96), (RC.g2_generator(), eng.g2_mul_batch, eng.g2_sum, RC.g2_mul, 192)]:
+        # base points: 4096 distinct multiples of the generator, tiled; scalars all distinct
+        base = 4096
+        bk = scalars(base, 33)
+        bpts, _ = mul(gen * base, bk.reshape(-1), base)
+        pts = np.tile(bpts, (n // base, 1))
+        out, inf = mul(pts.reshape(-1), k.reshape(-1), n)
+        assert not inf.any()
+        # (1) seeded sample bit-for-bit against the oracle
+        for i in [0, 1, 4095, 4096, 500000, n - 1]:
+            assert out[i].tobytes() == ref_mul(pts[i].tobytes(), k[i].tobytes()), i
+        # (2) grand sum identity: sum_i k_i * (b_{i mod base} G) = (sum_i k_i b_{i mod base}) G  -- wrong in any element => wrong sum
+        total = summ(out.reshape(-1), n)
+        bints = [int.from_bytes(bk[j].tobytes(), "big") for j in range(base)]
+        acc = 0
+        kk = k.reshape(n // base, base, 32)
+        for j in range(base):
+            acc = (acc + bints[j] * to_int_sum(kk[:, j, :])) % R
+        assert total == ref_mul(gen, acc.to_bytes(32, "big"))
+
+
+def _distinct_msgs(n):
+    idx = np.arange(n, dtype=np.uint64)
+    return [hashlib.sha256(int(i).to_bytes(8, "little")).digest() for i in idx]
+
+
+def test_config4_verify_aggregate_1m(eng):
+    import bls_amd.g2pubs as g2p
+    n = 1 << 20
+    msgs = _distinct_msgs(n)
+    # 1024 distinct signers, each signing 1024 distinct messages; sigma = sum_i sk_{i mod 1024} H(m_i)
+    nk = 1024
+    sk = scalars(nk, 4)
+    pks, _ = eng.g2_mul_batch(RC.g2_generator() * nk, sk.reshape(-1), nk)
+    for j in (0, nk - 1):
+        assert pks[j].tobytes() == RC.g2pubs.priv_to_pub(sk[j].tobytes())
+    h = eng.hash_g1_batch(msgs)
+    for i in (0, 77777, n - 1):
+        assert h[i].tobytes() == RC.hash_g1(msgs[i])
+    sks = np.tile(sk, (n // nk, 1))
+    sig_pts, inf = eng.g1_mul_batch(h.reshape(-1), sks.reshape(-1), n)
+    assert not inf.any()
+    agg = eng.g1_sum(sig_pts.reshape(-1), n)
+    all_pks = np.tile(pks, (n // nk, 1))
+    assert eng.g2pubs_verify_aggregate(msgs, all_pks.reshape(-1), agg) is True
+    # one corrupted public key (swap two signers) must flip the verdict
+    bad = all_pks.copy(); bad[12345] = all_pks[12346]
+    assert eng.g2pubs_verify_aggregate(msgs, bad.reshape(-1), agg) is False
+    # a duplicated message is rejected on the host before any device work (g2pubs/bls.go:245-261)
+    dup = list(msgs); dup[999] = dup[5]
+    assert eng.g2pubs_verify_aggregate(dup, all_pks.reshape(-1), agg) is False
+
+
+def test_config5_g1pubs_256k(eng):
+    n = 262144
+    nk = 256
+    sk = scalars(nk, 5)
+    pks, _ = eng.g1_mul_batch(RC.g1_generator() * nk, sk.reshape(-1), nk)
+    msgs = [b"Hello world! 16 characters %d" % i for i in range(n)]
+    h = eng.hash_g2_batch(msgs)
+    assert h[n - 1].tobytes() == RC.hash_g2(msgs[n - 1])
+    sks = np.tile(sk, (n // nk, 1))
+    sigs, inf = eng.g2_mul_batch(h.reshape(-1), sks.reshape(-1), n)
+    assert not inf.any()
+    assert sigs[4242].tobytes() == RC.g1pubs.sign(msgs[4242], sks[4242].tobytes())
+    all_pks = np.tile(pks, (n // nk, 1))
+    # corruption schedule: every 16th tuple broken in rotation (wrong message / wrong key / negated signature)
+    expect = np.ones(n, dtype=bool)
+    msgs2 = list(msgs); pk2 = all_pks.copy(); sg2 = sigs.copy()
+    q = P.Q
+    for i in range(15, n, 16):
+        expect[i] = False
+        kind = (i // 16) % 3
+        if kind == 0:
+            msgs2[i] = msgs[i] + b"!"
+        elif kind == 1:
+            pk2[i] = all_pks[(i + 1) % n]
+        else:
+            for off in (96, 144):
+                v = int.from_bytes(sg2[i, off:off + 48].tobytes(), "big")
+                sg2[i, off:off + 48] = np.frombuffer(((q - v) % q).to_bytes(48, "big"), dtype=np.uint8)
+    ok, bitmap = eng.g1pubs_verify_batch(msgs2, pk2.reshape(-1), sg2.reshape(-1))
+    assert np.array_equal(ok, expect)
+    assert np.array_equal(np.unpackbits(bitmap, bitorder="little")[:n].astype(bool), expect)
+    for i in (15, 31, 47, 100):
+        assert RC.g1pubs.verify(msgs2[i], pk2[i].tobytes(), sg2[i].tobytes()) == bool(expect[i])
