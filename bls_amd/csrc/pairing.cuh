@@ -79,6 +79,14 @@ BLSMI_NOINLINE void ell(Fp12S& f, const Fp2S& o0, const Fp2S& o1, const Fp2S& o2
     f = fp12_store(fp12_mul_by_014(f, o2, c1, c0));
 }
 
+// f = (f * line(P))^2 in one call: the 180-word accumulator crosses the call boundary once per iteration
+BLSMI_NOINLINE void ell_sqr(Fp12S& f, const Fp2S& o0, const Fp2S& o1, const Fp2S& o2, const FpS& px, const FpS& py) {
+    const auto c0 = fp2_mul_fp(o0, py);
+    const auto c1 = fp2_mul_fp(o1, px);
+    const Fp12S g = fp12_store(fp12_mul_by_014(f, o2, c1, c0));
+    f = fp12_store(fp12_sqr(g));
+}
+
 // pairing.go:16-75 for NP pairs sharing the squarings; bits of |x|>>1 below its leading one.
 template <int NP>
 BLSMI_DEV void miller_loop(Fp12S& f, const G1Aff (&p)[NP], const G2Aff (&q)[NP]) {
@@ -89,13 +97,21 @@ BLSMI_DEV void miller_loop(Fp12S& f, const G1Aff (&p)[NP], const G2Aff (&q)[NP])
     const u64 xr = BLSMI_X_ABS >> 1;
     Fp2S o0, o1, o2;
     for (int i = 61; i >= 0; i--) {
+        const bool add = (xr >> i) & 1;
 #pragma unroll
-        for (int k = 0; k < NP; k++) { doubling_step(r[k], o0, o1, o2); ell(f, o0, o1, o2, p[k].x, p[k].y); }
-        if ((xr >> i) & 1) {
-#pragma unroll
-            for (int k = 0; k < NP; k++) { addition_step(r[k], q[k].x, q[k].y, o0, o1, o2); ell(f, o0, o1, o2, p[k].x, p[k].y); }
+        for (int k = 0; k < NP; k++) {
+            doubling_step(r[k], o0, o1, o2);
+            if (!add && k == NP - 1) ell_sqr(f, o0, o1, o2, p[k].x, p[k].y);       // common case: multiply by the last line and square
+            else ell(f, o0, o1, o2, p[k].x, p[k].y);
         }
-        nf_fp12_sqr(f, f);
+        if (add) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                addition_step(r[k], q[k].x, q[k].y, o0, o1, o2);
+                if (k == NP - 1) ell_sqr(f, o0, o1, o2, p[k].x, p[k].y);
+                else ell(f, o0, o1, o2, p[k].x, p[k].y);
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < NP; k++) { doubling_step(r[k], o0, o1, o2); ell(f, o0, o1, o2, p[k].x, p[k].y); }
