@@ -78,6 +78,36 @@ BLSMI_DEV void store_m384(u64* p, const Fp<L, V>& x) {
 #pragma unroll
     for (int j = 0; j < 12; j++) w32[j] = w[j];
 }
+// ---- tuple I/O staged through LDS --------------------------------------------------------------------
+// The host-facing records are array-of-structures (96 / 192 / 576 bytes per tuple).  A wave moves its
+// 64 records between HBM and LDS with lane-contiguous dword accesses (256 B per wave instruction,
+// fully coalesced) and each lane then works on its own record inside LDS.  Records are padded by one
+// word in LDS so that the per-lane stride is odd (no bank conflicts on the per-lane side).
+template <int WORDS>
+BLSMI_DEV void tile_load(u32* lds, const u8* gbase, size_t first, size_t n) {
+    const u32* g = reinterpret_cast<const u32*>(gbase) + first * WORDS;
+    const size_t valid = (n - first < (size_t)WG ? n - first : (size_t)WG) * WORDS;
+    for (int idx = threadIdx.x; idx < WG * WORDS; idx += WG)
+        if ((size_t)idx < valid) lds[(idx / WORDS) * (WORDS + 1) + (idx % WORDS)] = g[idx];
+    __syncthreads();
+}
+template <int WORDS>
+BLSMI_DEV void tile_store(const u32* lds, u8* gbase, size_t first, size_t n) {
+    __syncthreads();
+    u32* g = reinterpret_cast<u32*>(gbase) + first * WORDS;
+    const size_t valid = (n - first < (size_t)WG ? n - first : (size_t)WG) * WORDS;
+    for (int idx = threadIdx.x; idx < WG * WORDS; idx += WG)
+        if ((size_t)idx < valid) g[idx] = lds[(idx / WORDS) * (WORDS + 1) + (idx % WORDS)];
+}
+BLSMI_DEV FpS lds_be48(const u32* rec) {                                  // 12 big-endian words of this lane's record
+    u32 w[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) w[j] = __builtin_bswap32(rec[11 - j]);
+    return fp_from_words(w);
+}
+BLSMI_DEV G1Aff lds_g1(const u32* rec) { G1Aff a; a.x = lds_be48(rec); a.y = lds_be48(rec + 12); a.inf = 0; return a; }
+BLSMI_DEV G2Aff lds_g2(const u32* rec) { G2Aff a; a.x.c0 = lds_be48(rec); a.x.c1 = lds_be48(rec + 12); a.y.c0 = lds_be48(rec + 24); a.y.c1 = lds_be48(rec + 36); a.inf = 0; return a; }
+
 BLSMI_DEV G1Aff load_g1(const u8* p) { G1Aff a; a.x = load_be48(p); a.y = load_be48(p + 48); a.inf = 0; return a; }
 BLSMI_DEV G2Aff load_g2(const u8* p) {
     G2Aff a; a.x.c0 = load_be48(p); a.x.c1 = load_be48(p + 48); a.y.c0 = load_be48(p + 96); a.y.c1 = load_be48(p + 144); a.inf = 0; return a;
@@ -96,25 +126,36 @@ BLSMI_DEV void store_g2(u8* p, const G2Aff& a) {
 // ------------------------------------------------------------------------------------------------
 // Miller loop for one pair per tuple; f goes to the internal SoA buffer (or nowhere else).
 KERNEL k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    const size_t tt = t < n ? t : n - 1;                                // tail lanes redo the last tuple
+    __shared__ u32 lds[WG * 49];
+    const size_t first = (size_t)blockIdx.x * WG;
+    const size_t t = first + threadIdx.x;
+    const int rec = (t < n) ? (int)threadIdx.x : (int)(n - 1 - first);   // tail lanes redo the last tuple
     G1Aff p[1]; G2Aff q[1];
-    p[0] = load_g1(g1 + 96 * tt);
-    q[0] = load_g2(g2 + 192 * tt);
+    tile_load<24>(lds, g1, first, n);
+    p[0] = lds_g1(lds + rec * 25);
+    __syncthreads();
+    tile_load<48>(lds, g2, first, n);
+    q[0] = lds_g2(lds + rec * 49);
     Fp12S f;
     miller_loop<1>(f, p, q);
     if (t < n) soa_store12(fbuf, n, t, f);
 }
 // mode 0: out = FE(f) as Montgomery-384 limbs; mode 1: out = f itself (no final exponentiation)
 KERNEL k_final_exp(const i32* fbuf, u64* out, size_t n, int mode) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    __shared__ u32 lds[WG * 145];
+    const size_t first = (size_t)blockIdx.x * WG;
+    const size_t t = first + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
     Fp12S f = soa_load12(fbuf, n, tt);
     if (mode == 0) final_exponentiation(f);
-    if (t < n) {
-        const FpS* c = reinterpret_cast<const FpS*>(&f);
-        for (int e = 0; e < 12; e++) store_m384(out + 72 * t + 6 * e, c[e]);
+    const FpS* c = reinterpret_cast<const FpS*>(&f);
+    for (int e = 0; e < 12; e++) {                                       // this lane's 576-byte record, into LDS
+        u32 w[12];
+        fp_to_mont384_words(c[e], w);
+#pragma unroll
+        for (int j = 0; j < 12; j++) lds[threadIdx.x * 145 + 12 * e + j] = w[j];
     }
+    tile_store<144>(lds, reinterpret_cast<u8*>(out), first, n);         // coalesced write-out
 }
 KERNEL k_fq12_from_m384(const u64* in, i32* fbuf, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;

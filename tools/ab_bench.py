@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = r'''
 import ctypes as C, sys, time, numpy as np, torch
 lib = C.CDLL(sys.argv[1]); lib.blsmi_init(0)
-n = 65536
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 sys.path.insert(0, %r)
 import bench
 from bls_amd import engine, _native
@@ -23,5 +23,7 @@ for i in range(6):
     x, y = C.c_float(0), C.c_float(0); lib.blsmi_last_kernel_ms(C.byref(x), C.byref(y))
 print("%%s rc=%%d best %%.3f ms/step (miller %%.3f, fexp %%.3f) -> %%.0f pairings/s checksum %%d" %% (sys.argv[1], rc, min(ts[1:]) * 1e3, x.value, y.value, n / min(ts[1:]), int(o[::997].sum().item()) & 0xffffffff))
 ''' % ROOT
-for so in sys.argv[1:]:
-    subprocess.run([sys.executable, "-c", code, os.path.abspath(so)], check=False)
+sizes = [a for a in sys.argv[1:] if a.isdigit()] or ["65536"]
+for so in [a for a in sys.argv[1:] if not a.isdigit()]:
+    for n in sizes:
+        subprocess.run([sys.executable, "-c", code, os.path.abspath(so), n], check=False)
