@@ -49,3 +49,69 @@ def torch_all_reduce(device=None):
 
 def unpack_bitmap(bitmap, n):
     return np.unpackbits(np.asarray(bitmap, dtype=np.uint8), bitorder="little")[:n].astype(bool)
+
+
+def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all_gather_bytes, engine=None):
+    """One n-way VerifyAggregate (g2pubs/bls.go:240-270) whose (message, public key) pairs are block-sharded
+    over `world` ranks.  Per rank: duplicate screening on SHA-256 digests of its messages, the shard's
+    Miller-loop product on its GPU; then TWO small all-gathers -- 32-byte message digests (global duplicate
+    rejection) and the 576-byte Fq12 partials -- after which every rank multiplies the partials, runs the
+    signature-side Miller loop and one final exponentiation, and compares.  Returns the same boolean on
+    every rank.  `all_gather_bytes(b: bytes) -> list[bytes]` is the collective (RCCL via torch.distributed
+    in production, gloo in the CPU test); `engine` defaults to bls_amd.engine."""
+    import hashlib
+    if engine is None:
+        from . import engine as _e
+        engine = _e
+    digests = b"".join(hashlib.sha256(bytes(m)).digest() for m in shard_msgs)
+    empties = any(len(m) == 0 for m in shard_msgs)
+    gathered = all_gather_bytes(digests + (b"\x01" if empties else b"\x00"))
+    alld = []
+    any_empty = False
+    for g in gathered:
+        any_empty |= g[-1:] == b"\x01"
+        alld.extend(g[i:i + 32] for i in range(0, len(g) - 1, 32))
+    if any_empty or len(set(alld)) != len(alld):              # duplicate (or empty) message: reject, like the reference
+        return False
+    part = engine.aggregate_partial(group, shard_msgs, shard_pks)
+    parts = all_gather_bytes(part.tobytes())
+    rhs = engine.fq12_product(np.frombuffer(b"".join(parts), dtype=np.uint64))
+    if group == "g2pubs":
+        lhs = engine.miller_loop_batch(sig, engine_generator(engine, 2), 1)[0]
+    else:
+        lhs = engine.miller_loop_batch(engine_generator(engine, 1), sig, 1)[0]
+    fe = engine.final_exponentiation_batch(np.stack([lhs, rhs]))
+    return bool(np.array_equal(fe[0], fe[1]))
+
+
+_G1_GEN = bytes.fromhex("17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+                        "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")
+_G2_GEN = bytes.fromhex("024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"
+                        "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+                        "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801"
+                        "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be")
+
+
+def engine_generator(engine, group):
+    """G1 / G2 generators in the affine wire format (g1.go:25-26, g2.go:26-29)."""
+    return _G1_GEN if group == 1 else _G2_GEN
+
+
+def torch_all_gather_bytes(device=None):
+    """all-gather of variable-length byte strings over torch.distributed (lengths first, then padded payloads)."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(b):
+        world = dist.get_world_size()
+        ln = torch.tensor([len(b)], dtype=torch.int64, device=device)
+        lens = [torch.zeros_like(ln) for _ in range(world)]
+        dist.all_gather(lens, ln)
+        mx = int(max(int(x.item()) for x in lens))
+        buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+        if len(b):
+            buf[:len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(buf.device)
+        outs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        return [bytes(o.cpu().numpy()[:int(l.item())]) for o, l in zip(outs, lens)]
+    return fn

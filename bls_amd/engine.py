@@ -228,6 +228,25 @@ def g1pubs_verify_aggregate_common_with_domain(msg32, domain8, pks, sig, n):
     return bool(ok.value)
 
 
+def aggregate_partial(group, msgs, pks):
+    """Shard-level half of VerifyAggregate: prod_i MillerLoop(H(m_i), pk_i) as (72,) uint64 (wire format)."""
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    pkb = 192 if group == "g2pubs" else 96
+    p = _u8(pks, pkb * n) if n else np.zeros(1, np.uint8)
+    out = np.zeros(72, dtype=np.uint64)
+    fn = _lib().blsmi_g2pubs_aggregate_partial if group == "g2pubs" else _lib().blsmi_g1pubs_aggregate_partial
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), _p8(p), C.c_size_t(n), out.ctypes.data_as(_u64p)), "aggregate_partial")
+    return out
+
+
+def fq12_product(vals):
+    x = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1, 72)
+    out = np.zeros(72, dtype=np.uint64)
+    _check(_lib().blsmi_fq12_product(x.ctypes.data_as(_u64p), C.c_size_t(x.shape[0]), out.ctypes.data_as(_u64p)), "fq12_product")
+    return out
+
+
 # ---- wire format -----------------------------------------------------------------------------------
 def _decompress(fn, ib, ob, data, n, check):
     a = _u8(data, ib * n)

@@ -98,6 +98,13 @@ int blsmi_g1pubs_verify_with_domain_batch(const uint8_t *msgs32, const uint8_t d
 int blsmi_g1pubs_verify_aggregate_with_domain(const uint8_t *msgs32, const uint8_t domain[8], const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
 int blsmi_g1pubs_verify_aggregate_common_with_domain(const uint8_t msg32[32], const uint8_t domain[8], const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
 
+/* Multi-GPU VerifyAggregate: each rank computes the product of its shard's Miller loops
+ * prod_i ML(H(m_i), pk_i) (no final exponentiation) as one Fq12 in the wire format; the ranks all-gather
+ * the 576-byte partials, multiply them (blsmi_fq12_product) and finish with one final exponentiation. */
+int blsmi_g2pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */);
+int blsmi_g1pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */);
+int blsmi_fq12_product(const uint64_t *in_fq12 /* n*72 */, size_t n, uint64_t *out_fq12 /* 72 */);
+
 /* device-pointer forms of the verify batches (inputs resident in HBM; ok is n bytes on the device) */
 int blsmi_g2pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
 int blsmi_g1pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);

@@ -66,3 +66,84 @@ def test_sharded_bitmap_allreduce_gloo_world2(n):
     assert res[0] == res[1]                                   # every rank holds the full bitmap
     got = bdist.unpack_bitmap(np.frombuffer(res[0], dtype=np.uint8), n)
     assert list(got) == expect
+
+
+class _OracleEngine:
+    """bls_amd.engine stand-in backed by the CPU oracle (CPU test of the collective logic only)."""
+    from oracle import refcpu as _RC
+
+    @staticmethod
+    def aggregate_partial(group, msgs, pks):
+        from oracle import refcpu as RC
+        n = len(msgs)
+        if n == 0:
+            one = np.zeros(72, dtype=np.uint64); one[:6] = RC.fq_from_repr([1, 0, 0, 0, 0, 0]); return one
+        pk = b"".join(pks) if isinstance(pks, list) else bytes(pks)
+        pb = 192 if group == "g2pubs" else 96
+        acc = None
+        for i, m in enumerate(msgs):
+            if group == "g2pubs":
+                f = RC.miller_loop(RC.hash_g1(m), pk[pb * i:pb * i + pb], 1)
+            else:
+                f = RC.miller_loop(pk[pb * i:pb * i + pb], RC.hash_g2(m), 1)
+            acc = f if acc is None else RC.fq12_mul(acc, f)
+        return acc
+
+    @staticmethod
+    def fq12_product(vals):
+        from oracle import refcpu as RC
+        v = np.asarray(vals, dtype=np.uint64).reshape(-1, 72)
+        acc = v[0]
+        for x in v[1:]:
+            acc = RC.fq12_mul(acc, x)
+        return acc
+
+    @staticmethod
+    def miller_loop_batch(g1, g2, n):
+        from oracle import refcpu as RC
+        return np.stack([RC.miller_loop(g1, g2, 1)])
+
+    @staticmethod
+    def final_exponentiation_batch(v):
+        from oracle import refcpu as RC
+        return np.stack([RC.final_exponentiation(x)[1] for x in v])
+
+
+def _agg_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import pyref as P
+        from oracle import refcpu as RC
+        xs = P.XORShift(4)
+        n = 5
+        sks = [P.rand_fr(xs).to_bytes(32, "big") for _ in range(n)]
+        msgs = [b">16 character identical message %d" % i for i in range(n)]
+        pks = [RC.g2pubs.priv_to_pub(sk) for sk in sks]
+        agg = RC.g1_sum(b"".join(RC.g2pubs.sign(m, sk) for m, sk in zip(msgs, sks)), n)
+        lo, hi = bdist.shard_bounds(n, rank, world)
+        gather = bdist.torch_all_gather_bytes()
+        ok = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(pks[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
+        dup = list(msgs); dup[n - 1] = dup[0]                 # duplicate across the two shards
+        ok_dup = bdist.sharded_verify_aggregate("g2pubs", dup[lo:hi], b"".join(pks[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
+        swapped = [pks[1], pks[0]] + pks[2:]
+        ok_bad = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(swapped[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
+        q.put((rank, ok, ok_dup, ok_bad, RC.g2pubs.verify_aggregate(agg, pks, msgs)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_verify_aggregate_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ok_dup, ok_bad, ref in res:
+        assert ok is True and ref is True and ok_dup is False and ok_bad is False

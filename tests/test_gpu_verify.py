@@ -253,3 +253,48 @@ def test_wire_format(eng, kats):
         g2pubs.DeserializePublicKey(bad2)
     pk = g2pubs.DeserializePublicKey(c2[0].tobytes())
     assert pk.p.raw == p2[0] and pk.Serialize() == c2[0].tobytes()
+
+
+def test_sharded_verify_aggregate_single_process(eng):
+    """The multi-GPU VerifyAggregate protocol (bls_amd/dist.py) with both shards evaluated on this GPU: the
+    all-gathers are simulated by computing every rank's contribution first."""
+    from bls_amd import dist as bdist
+    xs = P.XORShift(4)
+    n = 11
+    sks = [sk_bytes(xs) for _ in range(n)]
+    msgs = [b">16 character identical message %d" % i for i in range(n)]
+    for group, o, sumf in [("g2pubs", RC.g2pubs, RC.g1_sum), ("g1pubs", RC.g1pubs, RC.g2_sum)]:
+        pks = [o.priv_to_pub(sk) for sk in sks]
+        agg = sumf(b"".join(o.sign(m, sk) for m, sk in zip(msgs, sks)), n)
+        for world in (2, 3):
+            def run(pk_list):
+                logs = {}
+
+                def gather_factory(rank):
+                    calls = {"i": 0}
+
+                    def gather(b):
+                        i = calls["i"]; calls["i"] += 1
+                        logs.setdefault(i, {})[rank] = b
+                        return None
+                    return gather
+                # pass 1: record each rank's contributions; pass 2: replay with full gathers
+                contrib = []
+                import hashlib
+                for r in range(world):
+                    lo, hi = bdist.shard_bounds(n, r, world)
+                    dig = b"".join(hashlib.sha256(m).digest() for m in msgs[lo:hi]) + b"\x00"
+                    part = eng.aggregate_partial(group, msgs[lo:hi], b"".join(pk_list[lo:hi])).tobytes()
+                    contrib.append((dig, part))
+                outs = []
+                for r in range(world):
+                    lo, hi = bdist.shard_bounds(n, r, world)
+                    seq = iter([[c[0] for c in contrib], [c[1] for c in contrib]])
+                    outs.append(bdist.sharded_verify_aggregate(group, msgs[lo:hi], b"".join(pk_list[lo:hi]), agg, r, world, lambda b: next(seq)))
+                assert len(set(outs)) == 1
+                return outs[0]
+            assert run(pks) is True
+            assert run([pks[1], pks[0]] + pks[2:]) is False
+    # partial product of an empty shard is 1, and fq12_product agrees with the oracle
+    one = eng.aggregate_partial("g2pubs", [], b"")
+    assert np.array_equal(eng.fq12_product(np.stack([one, one])), one)
