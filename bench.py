@@ -31,8 +31,10 @@ sys.path.insert(0, ROOT)
 PAIRINGS_PER_GPU = 65536
 BYTES_PER_PAIRING = 864            # 96 B G1 + 192 B G2 in, 576 B Fq12 out
 HBM_PEAK_GBS = 8000.0              # MI355X spec (MI355X_MICROARCH.md)
-# measured integer-VALU ceiling: 67.8e9 15x27-limb Montgomery multiplications/s = the fp_mul_core body
-# (225+225 v_mad_i64_i32 + 120 others) at 4 waves/SIMD on all 256 CUs (profiles/r01_ubench2_fmul.log scaled to 15 limbs)
+# measured integer-VALU ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip,
+# profiles/r01_ubench2_fmul_15x27.log): 61.2e9 mul/s at 4 waves/SIMD, 45.6e9 at the 1 wave/SIMD the pairing kernels run at
+VALU_PEAK_GMULS = 61.2
+VALU_PEAK_1WAVE_GMULS = 45.6
 FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k)
 
 
@@ -61,6 +63,54 @@ def synth_inputs(engine, n, seed):
     g1 = np.tile(g1b, (reps, 1))[:n]
     g2 = np.concatenate([np.roll(g2b, -r, axis=0) for r in range(reps)])[:n]
     return np.ascontiguousarray(g1), np.ascontiguousarray(g2)
+
+
+def verify_extra(engine, dev, n=65536):
+    """Outside the timed region: throughput of the full Verify path (hash-to-curve + 2-pair Miller loop + final
+    exponentiation + compare) on n device-resident tuples, both packages.  1 Verify = 2 Miller-loop pairs + 1 final exp + 1 hash."""
+    import hashlib
+    import torch
+    out = {}
+    nk = 256
+    sk = b"".join(hashlib.sha256(b"bench-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
+    msgs = [b"Hello world! 16 characters %d" % i for i in range(n)]
+    buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(m) for m in msgs])
+    g1gen, g2gen = _gens()
+    for group in ("g2pubs", "g1pubs"):
+        if group == "g2pubs":
+            pks, _ = engine.g2_mul_batch(g2gen * nk, sk, nk)
+            h = engine.hash_g1_batch(msgs)
+            sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
+        else:
+            pks, _ = engine.g1_mul_batch(g1gen * nk, sk, nk)
+            h = engine.hash_g2_batch(msgs)
+            sigs, _ = engine.g2_mul_batch(h.reshape(-1), sk * (n // nk), n)
+        allpk = np.tile(pks, (n // nk, 1))
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (buf.copy(), off.view(np.int64), allpk, sigs)]
+        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        assert bool(d_ok.all().item()), "synthetic tuples must all verify"
+        out[group + "_verifies_per_s"] = round(n / best, 1)
+    out["tuples"] = n
+    out["note"] = "all tuples valid; inputs resident in HBM; includes hash-to-curve on the GPU"
+    return out
+
+
+def _gens():
+    g1gen = bytes.fromhex(
+        "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+        "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")
+    g2gen = bytes.fromhex(
+        "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"
+        "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+        "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801"
+        "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be")
+    return g1gen, g2gen
 
 
 def cpu_baseline(g1, g2, budget_s=12.0):
@@ -94,6 +144,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairings", type=int, default=PAIRINGS_PER_GPU, help="pairings per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify-extra", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -168,11 +219,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
                          "kernel_ms": {"k_miller1": round(ml, 3), "k_final_exp": round(fe, 3)},
                          "note": "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"},
-            "valu": {"bound": "int32 VALU (v_mad_i64_i32)", "achieved_fq_mul_per_s": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
-                     "peak_fq_mul_per_s": 57.9, "unit": "G Fq-mul/s", "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / 57.9, 4),
-                     "note": "peak = measured fp_mul_core issue ceiling per GPU (profiles/r01_ubench2_fmul.log, 67.8 G/s for 14 limbs x 480/562 instr)"},
+            "valu": {"bound": "int32 VALU (v_mad_i64_i32)", "achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
+                     "peak": VALU_PEAK_GMULS, "unit": "G Fq-mul/s", "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_GMULS, 4),
+                     "frac_of_1wave_per_simd_peak": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_1WAVE_GMULS, 4),
+                     "note": "peak = measured issue ceiling of the 15x27 Montgomery multiply core per GPU (profiles/r01_ubench2_fmul_15x27.log); "
+                             "achieved = pairings/s x 14.6k Fq multiplications per pairing (SURVEY 8d)"},
             "checksum": checksum,
         }
+        if world == 1 and not args.no_verify_extra:
+            line["verify"] = verify_extra(engine, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g1, g2)
         print(json.dumps(line), flush=True)

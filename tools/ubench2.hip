@@ -54,9 +54,10 @@ template<int MODE> __global__ void __launch_bounds__(256) k_alu(u32* out, int it
 }
 
 // 14 x 28-bit signed limbs, Montgomery R = 2^392, product-scanning (FIPS), no carries between lanes/words.
-#define NL 14
-#define MASK28 0x0fffffff
-__constant__ i32 QL[NL] = {0xfffaaab,0xfeffffb,0x3ffffb9,0xfeb153f,0x6241eab,0xf6b0f,0xbf6730d,0x4f38512,0x764774b,0x434bacd,0xb1ba7b6,0x7fe69a4,0x111ea39,0x1a0};
+#define NL 15
+#define MASK28 0x07ffffff
+#define LBITS 27
+__constant__ i32 QL[NL] = {0x7ffaaab,0x7fdffff,0x7fffdcf,0x7d62a7f,0x241eabf,0x7b0f624,0x349a83d,0x4afd9cc,0x4e9c4e1,0x35d91dd,0x5a10d2e,0x4d258dd,0x65cbfe6,0x47a8e5f,0x6a04};
 struct F { i32 v[NL]; };
 __device__ __forceinline__ F fmul(const F& a, const F& b, i32 qinv) {
   i32 m[NL]; F r; i64 acc=0;
@@ -68,7 +69,7 @@ __device__ __forceinline__ F fmul(const F& a, const F& b, i32 qinv) {
     for (int i=0;i<k;i++) acc += (i64)m[i]*QL[k-i];
     m[k] = ((i32)acc*qinv) & MASK28;
     acc += (i64)m[k]*QL[0];
-    acc >>= 28;
+    acc >>= LBITS;
   }
   #pragma unroll
   for (int k=NL;k<2*NL-1;k++) {
@@ -77,7 +78,7 @@ __device__ __forceinline__ F fmul(const F& a, const F& b, i32 qinv) {
     #pragma unroll
     for (int i=k-NL+1;i<NL;i++) acc += (i64)m[i]*QL[k-i];
     r.v[k-NL] = (i32)acc & MASK28;
-    acc >>= 28;
+    acc >>= LBITS;
   }
   r.v[NL-1]=(i32)acc;
   return r;
@@ -125,7 +126,7 @@ int main() {
                        if(wps==4) hipLaunchKernelGGL(k_fmul<4>,dim3(blocks),dim3(256),0,0,(i32*)out,iters,(i32)0xfffcfffd); };
     float ms=timeit(launch);
     double muls=(double)blocks*256*iters;
-    printf("FMUL14x28 waves/SIMD=%d  %8.3f ms  %.1f Gmul/s  %.0f cyc/mul/wave-slot (@2.4GHz, per SIMD: %.0f)\n", wps, ms, muls/ms/1e6, ms*1e6*2.4/iters, ms*1e6*2.4/iters/wps);
+    printf("FMUL15x27 waves/SIMD=%d  %8.3f ms  %.1f Gmul/s  %.0f cyc/mul/wave-slot (@2.4GHz, per SIMD: %.0f)\n", wps, ms, muls/ms/1e6, ms*1e6*2.4/iters, ms*1e6*2.4/iters/wps);
   }
   return 0;
 }
