@@ -35,6 +35,11 @@ HBM_PEAK_GBS = 8000.0              # MI355X spec (MI355X_MICROARCH.md)
 # profiles/r01_ubench2_fmul_15x27.log): 61.2e9 mul/s at 4 waves/SIMD, 45.6e9 at the 1 wave/SIMD the pairing kernels run at
 VALU_PEAK_GMULS = 61.2
 VALU_PEAK_1WAVE_GMULS = 45.6
+# HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+# (r01_rocprof_pairing_summary_final.txt: k_final_exp, 65 536 tuples per launch, FETCH_SIZE 4.088e6 KB +
+# WRITE_SIZE 6.649e6 KB, separate --pmc passes; FETCH_SIZE may under-count narrow reads on gfx950 -- guide, HBM
+# section).  It is per-lane scratch (Fq12 temporaries of the out-of-line tower functions), not tuple I/O.
+MEASURED_TRAFFIC_BYTES = {"k_final_exp": (4.08818e6 + 6.64894e6) * 1024, "k_miller1": (4.34452e6 + 8.77347e6) * 1024}
 FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k)
 
 
@@ -216,7 +221,10 @@ def main():
             "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exp) per GPU per step, inputs resident in HBM, "
                                    "output bit-exact Fq12 (tests/test_gpu_pairing.py)" % n, "pairings_per_gpu": n, "parallelism": "shard%d" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 8),
+                         "traffic": (MEASURED_TRAFFIC_BYTES[dom] * n / 65536.0) if dom in MEASURED_TRAFFIC_BYTES else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_rocprof_pairing_summary_final.txt)",
+                         "algorithmic_bytes_per_launch": BYTES_PER_PAIRING * n,
                          "kernel_ms": {"k_miller1": round(ml, 3), "k_final_exp": round(fe, 3)},
                          "note": "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"},
             "valu": {"bound": "int32 VALU (v_mad_i64_i32)", "achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
