@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
-_SOURCES = ["blsmi.hip", "fp.cuh", "tower_fwd.cuh", "tower.cuh", "curve.cuh", "pairing.cuh", "hash.cuh", "consts.cuh",
+_SOURCES = ["blsmi.hip", "fp.cuh", "tower_fwd.cuh", "tower.cuh", "fp2_single.inc", "fp2_pair.inc", "tower_body.inc", "pairing_body.inc", "pair_kernels.inc", "curve.cuh", "pairing.cuh", "hash.cuh", "consts.cuh",
             "verify_kernels.inc", "verify_host.inc"]
 
 

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 
 using namespace blsmi;
 
@@ -360,12 +362,14 @@ KERNEL k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp
 KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
 
 #include "verify_kernels.inc"
+#include "pair_kernels.inc"
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
 std::mutex g_mu;
+bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
 int g_device = 0;
 hipStream_t g_stream = nullptr;
@@ -384,6 +388,8 @@ int ensure_init(int device) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     snprintf(g_version, sizeof g_version, "blsmi 0.1 %s CUs=%d", prop.gcnArchName, prop.multiProcessorCount);
     g_device = device;
+    const char* lay = getenv("BLSMI_LAYOUT");
+    g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
     g_ready = true;
     return BLSMI_OK;
 }
@@ -442,9 +448,12 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
     if (g_profile) HIPCHK(hipEventRecord(g_ev[0], s));
-    hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+    const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
+    if (g_pair_layout) hipLaunchKernelGGL(k_miller1_pair, dim3(pblocks), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+    else hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
     if (g_profile) HIPCHK(hipEventRecord(g_ev[1], s));
-    hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
+    if (g_pair_layout) hipLaunchKernelGGL(k_final_exp_pair, dim3(pblocks), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
+    else hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
     if (g_profile) HIPCHK(hipEventRecord(g_ev[2], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));      // blocking entry point: results are ready on return

@@ -140,7 +140,7 @@ template <int L, int V> BLSMI_DEV auto fp_dbl(const Fp<L, V>& a) { return fp_mul
 // the instruction cache while tower code shrinks to call sequences.
 typedef i32 vlimbs __attribute__((ext_vector_type(15)));
 
-__device__ __noinline__ vlimbs fp_mul_core(vlimbs a, vlimbs b) {
+BLSMI_DEV vlimbs fp_mul_body(vlimbs a, vlimbs b) {
     i32 m[NL];
     vlimbs r;
     i64 acc = 0;
@@ -166,6 +166,7 @@ __device__ __noinline__ vlimbs fp_mul_core(vlimbs a, vlimbs b) {
     r[NL - 1] = (i32)acc;
     return r;
 }
+__device__ __noinline__ vlimbs fp_mul_core(vlimbs a, vlimbs b) { return fp_mul_body(a, b); }
 // Squaring (fq.go:151-198): off-diagonal products once, against the doubled operand.
 __device__ __noinline__ vlimbs fp_sqr_core(vlimbs a) {
     i32 m[NL], a2[NL];
@@ -315,7 +316,7 @@ BLSMI_DEV FpS fp_one() { return C_ONE; }
 
 // ---- exponentiation by a fixed public exponent (fq.go:96-113), bits MSB-first from constant memory.
 // The loop is rolled: two call sites, uniform control flow (the exponent is the same for all lanes).
-__device__ __noinline__ vlimbs fp_pow_core(vlimbs a, const u32* ebits, int nbits) {
+BLSMI_DEV vlimbs fp_pow_core(vlimbs a, const u32* ebits, int nbits) {
     vlimbs res = a;                                        // top bit is always 1
     for (int i = nbits - 2; i >= 0; i--) {
         res = fp_sqr_core(res);
