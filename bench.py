@@ -36,10 +36,11 @@ HBM_PEAK_GBS = 8000.0              # MI355X spec (MI355X_MICROARCH.md)
 VALU_PEAK_GMULS = 61.2
 VALU_PEAK_1WAVE_GMULS = 45.6
 # HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-# (r01_rocprof_pairing_summary_final.txt: k_final_exp, 65 536 tuples per launch, FETCH_SIZE 4.088e6 KB +
-# WRITE_SIZE 6.649e6 KB, separate --pmc passes; FETCH_SIZE may under-count narrow reads on gfx950 -- guide, HBM
-# section).  It is per-lane scratch (Fq12 temporaries of the out-of-line tower functions), not tuple I/O.
-MEASURED_TRAFFIC_BYTES = {"k_final_exp": (4.08818e6 + 6.64894e6) * 1024, "k_miller1": (4.34452e6 + 8.77347e6) * 1024}
+# (r01_rocprof_pairing_summary_final.txt: k_final_exp_pair, 65 536 tuples per launch, FETCH_SIZE 5.855e6 KB +
+# WRITE_SIZE 1.060e7 KB, separate --pmc passes; FETCH_SIZE may under-count narrow reads on gfx950 -- guide, HBM
+# section).  It is per-lane scratch (Fq12 temporaries / spills of the out-of-line tower functions), not tuple I/O.
+MEASURED_TRAFFIC_BYTES = {"k_final_exp_pair": (5.85503e6 + 1.06026e7) * 1024, "k_miller1_pair": (5.196e6 + 1.02919e7) * 1024,
+                          "k_final_exp": (4.08818e6 + 6.64894e6) * 1024, "k_miller1": (4.34452e6 + 8.77347e6) * 1024}
 FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k)
 
 
@@ -209,23 +210,25 @@ def main():
     checksum = int(d_out[::997].sum().item()) & 0xffffffff
     if rank == 0:
         ml = float(np.mean([k[0] for k in kms])); fe = float(np.mean([k[1] for k in kms]))
-        dom, dom_ms = ("k_final_exp", fe) if fe >= ml else ("k_miller1", ml)
+        suffix = "" if os.environ.get("BLSMI_LAYOUT") == "single" else "_pair"
+        dom, dom_ms = ("k_final_exp" + suffix, fe) if fe >= ml else ("k_miller1" + suffix, ml)
         achieved = BYTES_PER_PAIRING * n / (dom_ms * 1e-3) / 1e9
         value = world * n * args.steps / dt
         per_gpu = value / world
         line = {
             "metric": "BLS12-381 pairings/sec (batch verify)", "value": round(value, 1), "unit": "pairings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32x15 (27-bit limbs, int64 accumulate)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (15 x 27-bit limbs, int64 accumulate)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exp) per GPU per step, inputs resident in HBM, "
-                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py)" % n, "pairings_per_gpu": n, "parallelism": "shard%d" % world},
+                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py)" % n, "pairings_per_gpu": n, "parallelism": "shard%d" % world,
+                       "layout": "one tuple per lane" if suffix == "" else "lane pair per tuple (one Fq2 coefficient per lane), 2 waves/SIMD"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8),
                          "traffic": (MEASURED_TRAFFIC_BYTES[dom] * n / 65536.0) if dom in MEASURED_TRAFFIC_BYTES else None,
                          "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_rocprof_pairing_summary_final.txt)",
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIRING * n,
-                         "kernel_ms": {"k_miller1": round(ml, 3), "k_final_exp": round(fe, 3)},
+                         "kernel_ms": {"k_miller1" + suffix: round(ml, 3), "k_final_exp" + suffix: round(fe, 3)},
                          "note": "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"},
             "valu": {"bound": "int32 VALU (v_mad_i64_i32)", "achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
                      "peak": VALU_PEAK_GMULS, "unit": "G Fq-mul/s", "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_GMULS, 4),
