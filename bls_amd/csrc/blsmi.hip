@@ -8,6 +8,7 @@
 #include "pairing.cuh"
 #include "hash.cuh"
 #include <mutex>
+#include <condition_variable>
 #include <vector>
 #include <algorithm>
 #include <cstring>
@@ -282,10 +283,10 @@ BLSMI_DEV void store_aff(u8* p, const G2Aff& a) { store_g2(p, a); }
 // 252 doublings + 63 + 14 additions, uniform control flow for all 64 lanes.  Same group element, so the
 // affine output is identical to the reference's.
 template <class F, int PB>
-__device__ void mul_batch_body(const u8* pts, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+__device__ void mul_batch_body(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
-    const Aff<F> p = load_aff<F>(pts + (size_t)PB * tt);
+    const Aff<F> p = load_aff<F>(pts + pt_stride * tt);                  // stride 0: one common base point (PrivToPub)
     const u32* s32 = reinterpret_cast<const u32*>(scalars + 32 * tt);
     Jac<F> tab[16];
     tab[0] = jac_zero<F>();
@@ -302,8 +303,8 @@ __device__ void mul_batch_body(const u8* pts, const u8* scalars, u8* out, u8* ou
     const Aff<F> a = jac_to_affine(res);
     if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
 }
-KERNEL k_g1_mul(const u8* pts, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, scalars, out, out_inf, n); }
-KERNEL k_g2_mul(const u8* pts, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, scalars, out, out_inf, n); }
+KERNEL k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
+KERNEL k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
 
 // Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
 template <class F> struct jac_words { static constexpr int value = sizeof(F) / sizeof(FpS) * 3; };
@@ -368,35 +369,20 @@ KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
+// Host state. Every entry point leases one call context (a non-blocking stream, a grow-only scratch buffer and
+// timing events) from a small pool, so calls from several OS threads (cgo pins one per goroutine call) run
+// concurrently on separate HIP streams; temporaries come from the device's stream-ordered memory pool, whose
+// release threshold is raised so freed blocks are reused by later calls instead of returning to the driver.
 std::mutex g_mu;
+std::condition_variable g_cv;
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
 int g_device = 0;
-hipStream_t g_stream = nullptr;
 char g_version[160] = "blsmi 0.1 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
-int ensure_init(int device) {
-    if (g_ready) return BLSMI_OK;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
-    if (device < 0 || device >= count) return BLSMI_E_ARG;
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    snprintf(g_version, sizeof g_version, "blsmi 0.1 %s CUs=%d", prop.gcnArchName, prop.multiProcessorCount);
-    g_device = device;
-    const char* lay = getenv("BLSMI_LAYOUT");
-    g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
-    g_ready = true;
-    return BLSMI_OK;
-}
-inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
-
-// Grow-only scratch for the Miller-loop -> final-exponentiation hand-off (avoids a hipMalloc/hipFree
-// pair, and the implicit device synchronisation of hipFree, on every call).
+// Grow-only scratch for the Miller-loop -> final-exponentiation hand-off of one call context.
 struct Workspace {
     void* p = nullptr; size_t cap = 0;
     hipError_t reserve(size_t bytes) {
@@ -407,22 +393,99 @@ struct Workspace {
         if (e == hipSuccess) cap = bytes;
         return e;
     }
-} g_ws;
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct Ctx {
+    hipStream_t stream = nullptr;
+    Workspace ws;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool busy = false;
+};
+constexpr int MAX_CTX = 16;
+Ctx g_ctx[MAX_CTX];
+int g_nctx = 4;                         // BLSMI_STREAMS
+thread_local Ctx* tl_ctx = nullptr;
+#define g_stream (tl_ctx->stream)
+#define g_ws (tl_ctx->ws)
+// G1/G2 generators in wire form, written once at init (read-only afterwards)
+struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; } g_gens;
 // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline object
 bool g_profile = false;
-hipEvent_t g_ev[3] = {nullptr, nullptr, nullptr};
 float g_last_ms[2] = {0.f, 0.f};
 
-// RAII device buffer
+int ensure_init(int device) {           // caller holds g_mu
+    if (g_ready) return BLSMI_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
+    if (device < 0 || device >= count) return BLSMI_E_ARG;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(g_version, sizeof g_version, "blsmi 0.1 %s CUs=%d", prop.gcnArchName, prop.multiProcessorCount);
+    g_device = device;
+    const char* lay = getenv("BLSMI_LAYOUT");
+    g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
+    const char* ns = getenv("BLSMI_STREAMS");
+    if (ns) { int v = atoi(ns); g_nctx = v < 1 ? 1 : (v > MAX_CTX ? MAX_CTX : v); }
+    hipMemPool_t pool;
+    HIPCHK(hipDeviceGetDefaultMemPool(&pool, device));
+    uint64_t keep = UINT64_MAX;
+    HIPCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    if (!g_gens.g1) {
+        HIPCHK(hipMalloc((void**)&g_gens.g1, 96)); HIPCHK(hipMalloc((void**)&g_gens.g2, 192));
+        hipLaunchKernelGGL(k_write_generators, dim3(1), dim3(WG), 0, nullptr, g_gens.g1, g_gens.g2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipDeviceSynchronize());
+    }
+    g_ready = true;
+    return BLSMI_OK;
+}
+inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
+
+// Lease of one call context for the duration of an entry point.
+struct CtxLease {
+    int rc = BLSMI_OK;
+    CtxLease() {
+        std::unique_lock<std::mutex> lk(g_mu);
+        rc = ensure_init(g_device);
+        if (rc) return;
+        if (hipSetDevice(g_device) != hipSuccess) { rc = BLSMI_E_HIP; return; }     // the current device is per-thread state
+        Ctx* c = nullptr;
+        for (;;) {
+            for (int i = 0; i < g_nctx && !c; i++) if (!g_ctx[i].busy) c = &g_ctx[i];
+            if (c) break;
+            g_cv.wait(lk);
+        }
+        if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = BLSMI_E_HIP; return; }
+        c->busy = true;
+        tl_ctx = c;
+    }
+    ~CtxLease() {
+        if (!tl_ctx) return;
+        { std::lock_guard<std::mutex> lk(g_mu); tl_ctx->busy = false; }
+        tl_ctx = nullptr;
+        g_cv.notify_one();
+    }
+};
+
+// A caller-supplied stream (the *_dev entry points) stands in for the leased context's stream for one call.
+struct UseStream {
+    hipStream_t saved;
+    explicit UseStream(void* s) : saved(tl_ctx->stream) { if (s) tl_ctx->stream = (hipStream_t)s; }
+    ~UseStream() { tl_ctx->stream = saved; }
+};
+
+// RAII device temporary from the stream-ordered pool of the leased context's stream
 struct DBuf {
     void* p = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    ~DBuf() { if (p) (void)hipFree(p); }
+    hipStream_t s = nullptr;
+    hipError_t alloc(size_t bytes) { s = g_stream; return hipMallocAsync(&p, bytes ? bytes : 1, s); }
+    ~DBuf() { if (p) (void)hipFreeAsync(p, s); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 }  // namespace
 
-#define LOCK_AND_INIT() std::lock_guard<std::mutex> lk_(g_mu); { int rc_ = ensure_init(g_device); if (rc_) return rc_; }
+#define LOCK_AND_INIT() CtxLease lease_; if (lease_.rc) return lease_.rc;
 
 #define BLSMI_API extern "C" __attribute__((visibility("default")))
 
@@ -432,12 +495,26 @@ BLSMI_API int blsmi_init(int device) {
     return ensure_init(device);
 }
 BLSMI_API void blsmi_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     if (!g_ready) return;
-    (void)hipStreamSynchronize(g_stream);
-    if (g_ws.p) { (void)hipFree(g_ws.p); g_ws.p = nullptr; g_ws.cap = 0; }
-    (void)hipStreamDestroy(g_stream);
-    g_stream = nullptr;
+    for (;;) {                          // wait for calls in flight
+        bool busy = false;
+        for (int i = 0; i < MAX_CTX; i++) busy |= g_ctx[i].busy;
+        if (!busy) break;
+        g_cv.wait(lk);
+    }
+    (void)hipSetDevice(g_device);
+    for (int i = 0; i < MAX_CTX; i++) {
+        Ctx& c = g_ctx[i];
+        if (!c.stream) continue;
+        (void)hipStreamSynchronize(c.stream);
+        c.ws.release();
+        for (auto& e : c.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        (void)hipStreamDestroy(c.stream);
+        c.stream = nullptr;
+    }
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, g_device) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     g_ready = false;
 }
 BLSMI_API const char* blsmi_version(void) { return g_version; }
@@ -447,26 +524,27 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     if (n == 0) return BLSMI_OK;
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
-    if (g_profile) HIPCHK(hipEventRecord(g_ev[0], s));
+    const bool prof = g_profile;
+    if (prof && !tl_ctx->ev[0]) for (auto& e : tl_ctx->ev) HIPCHK(hipEventCreate(&e));
+    if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[0], s));
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
     if (g_pair_layout) hipLaunchKernelGGL(k_miller1_pair, dim3(pblocks), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
     else hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
-    if (g_profile) HIPCHK(hipEventRecord(g_ev[1], s));
+    if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[1], s));
     if (g_pair_layout) hipLaunchKernelGGL(k_final_exp_pair, dim3(pblocks), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
     else hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
-    if (g_profile) HIPCHK(hipEventRecord(g_ev[2], s));
+    if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[2], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));      // blocking entry point: results are ready on return
-    if (g_profile) {
-        HIPCHK(hipEventElapsedTime(&g_last_ms[0], g_ev[0], g_ev[1]));
-        HIPCHK(hipEventElapsedTime(&g_last_ms[1], g_ev[1], g_ev[2]));
+    if (prof) {
+        HIPCHK(hipEventElapsedTime(&g_last_ms[0], tl_ctx->ev[0], tl_ctx->ev[1]));
+        HIPCHK(hipEventElapsedTime(&g_last_ms[1], tl_ctx->ev[1], tl_ctx->ev[2]));
     }
     return BLSMI_OK;
 }
 // Enable/disable per-kernel HIP-event timing of blsmi_pairing_batch[_dev]; read back with blsmi_last_kernel_ms.
 BLSMI_API int blsmi_set_profiling(int on) {
     LOCK_AND_INIT();
-    if (on && !g_ev[0]) for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&g_ev[i]));
     g_profile = on != 0;
     return BLSMI_OK;
 }
@@ -478,7 +556,8 @@ BLSMI_API int blsmi_last_kernel_ms(float* miller_ms, float* final_exp_ms) {
 BLSMI_API int blsmi_pairing_batch_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, void* stream) {
     if (n && (!d_g1 || !d_g2 || !d_out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
-    return pairing_dev(d_g1, d_g2, d_out, n, stream ? (hipStream_t)stream : g_stream, 0);
+    UseStream us(stream);
+    return pairing_dev(d_g1, d_g2, d_out, n, g_stream, 0);
 }
 static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n, int mode) {
     if (n && (!g1 || !g2 || !out)) return BLSMI_E_ARG;
@@ -537,24 +616,27 @@ BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint6
 }
 
 // ---- scalar multiplication / sums ----------------------------------------------------------------
+// pts == nullptr: every scalar multiplies the group generator (PrivToPub, g2pubs/bls.go:138-140, g1pubs/bls.go:144-146)
 template <int PB, class K>
-static int mul_batch(K kernel, const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
-    if (n && (!pts || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
+static int mul_batch(K kernel, const uint8_t* pts, const u8* d_gen, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
+    if (n && ((!pts && !d_gen) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
     if (n == 0) return BLSMI_OK;
     DBuf dp, ds, dout, dinf;
-    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
-    HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
+    if (pts) { HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream)); }
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
+    hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)PB * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipMemcpyAsync(out_inf, dinf.p, n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
     return BLSMI_OK;
 }
-BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, pts, scalars, out, out_inf, n); }
-BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, pts, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<96>(k_g1_mul, pts, nullptr, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<192>(k_g2_mul, pts, nullptr, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g1_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, nullptr, g_gens.g1, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g2_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, g_gens.g2, scalars, out, out_inf, n); }
 
 // tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
 template <int PB, int W, class K0, class K1, class K2>
@@ -596,6 +678,30 @@ static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* 
 }
 BLSMI_API int blsmi_g1_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[96], int* out_inf) { return sum_host<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, in_inf, n, out, out_inf); }
 BLSMI_API int blsmi_g2_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[192], int* out_inf) { return sum_host<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, in_inf, n, out, out_inf); }
+
+// multi-scalar multiplication sum_i k_i * P_i: the windowed multiples stay on the device and feed the tree sum
+template <int PB, int W, class KM, class K0, class K1, class K2>
+static int msm_host(KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int* out_inf) {
+    if (!out || !out_inf || (n && (!pts || !scalars))) return BLSMI_E_ARG;
+    if (n == 0) { memset(out, 0, PB); *out_inf = 1; return BLSMI_OK; }
+    LOCK_AND_INIT();
+    DBuf dp, ds, dm, dinf, dout, dflag;
+    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dm.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
+    HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
+    HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
+    hipLaunchKernelGGL(kmul, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), (size_t)PB, ds.as<u8>(), dm.as<u8>(), dinf.as<u8>(), n);
+    int rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    if (rc) return rc;
+    i32 flag = 0;
+    HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *out_inf = flag;
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_g1_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[96], int* out_inf) { return msm_host<96, 3>(k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, scalars, n, out, out_inf); }
+BLSMI_API int blsmi_g2_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[192], int* out_inf) { return msm_host<192, 6>(k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, scalars, n, out, out_inf); }
 
 #include "verify_host.inc"
 

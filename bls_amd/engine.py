@@ -103,6 +103,42 @@ def g2_mul_batch(pts, scalars, n):
     return _mul(_lib().blsmi_g2_mul_batch, 192, pts, scalars, n)
 
 
+def _mul_gen(fn, pb, scalars, n):
+    s = _u8(scalars, 32 * n)
+    out = np.zeros(pb * n, dtype=np.uint8)
+    inf = np.zeros(n, dtype=np.uint8)
+    _check(fn(_p8(s), _p8(out), _p8(inf), C.c_size_t(n)), "mul_generator_batch")
+    return out.reshape(n, pb), inf.astype(bool)
+
+
+def g1_mul_generator_batch(scalars, n):
+    """k_i * G1 generator (PrivToPub of g1pubs)."""
+    return _mul_gen(_lib().blsmi_g1_mul_generator_batch, 96, scalars, n)
+
+
+def g2_mul_generator_batch(scalars, n):
+    """k_i * G2 generator (PrivToPub of g2pubs)."""
+    return _mul_gen(_lib().blsmi_g2_mul_generator_batch, 192, scalars, n)
+
+
+def _msm(fn, pb, pts, scalars, n):
+    p = _u8(pts, pb * n) if n else np.zeros(1, np.uint8)
+    s = _u8(scalars, 32 * n) if n else np.zeros(1, np.uint8)
+    out = np.zeros(pb, dtype=np.uint8)
+    oinf = C.c_int(0)
+    _check(fn(_p8(p), _p8(s), C.c_size_t(n), _p8(out), C.byref(oinf)), "msm")
+    return None if oinf.value else out.tobytes()
+
+
+def g1_msm(pts, scalars, n):
+    """sum_i k_i * P_i -> 96 affine bytes, or None for the point at infinity."""
+    return _msm(_lib().blsmi_g1_msm, 96, pts, scalars, n)
+
+
+def g2_msm(pts, scalars, n):
+    return _msm(_lib().blsmi_g2_msm, 192, pts, scalars, n)
+
+
 def _sum(fn, pb, pts, n, in_inf):
     p = _u8(pts, pb * n) if n else np.zeros(1, np.uint8)
     f = _u8(in_inf, n) if in_inf is not None else None

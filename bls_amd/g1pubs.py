@@ -104,6 +104,13 @@ def Verify(m, pub, sig):
     return VerifyBatch([m], [pub], [sig])[0]
 
 
+def PrivToPubBatch(secret_scalars):
+    """pk_i = sk_i * generator (PrivToPub, g1pubs/bls.go:144-146); scalars are 32-byte big-endian."""
+    n = len(secret_scalars)
+    out, inf = engine.g1_mul_generator_batch(b"".join(secret_scalars), n)
+    return [PublicKey(Point(None if inf[i] else out[i].tobytes(), PK_GROUP)) for i in range(n)]
+
+
 def SignBatch(msgs, secret_scalars):
     """sigma_i = sk_i * HashG2(m_i) (Sign, g1pubs/bls.go:132-135); scalars are 32-byte big-endian."""
     n = len(msgs)

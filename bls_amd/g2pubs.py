@@ -104,6 +104,13 @@ def Verify(m, pub, sig):
     return VerifyBatch([m], [pub], [sig])[0]
 
 
+def PrivToPubBatch(secret_scalars):
+    """pk_i = sk_i * generator (PrivToPub, g2pubs/bls.go:138-140); scalars are 32-byte big-endian."""
+    n = len(secret_scalars)
+    out, inf = engine.g2_mul_generator_batch(b"".join(secret_scalars), n)
+    return [PublicKey(Point(None if inf[i] else out[i].tobytes(), PK_GROUP)) for i in range(n)]
+
+
 def SignBatch(msgs, secret_scalars):
     """sigma_i = sk_i * HashG1(m_i) (Sign, g2pubs/bls.go:132-135); scalars are 32-byte big-endian."""
     n = len(msgs)

@@ -64,10 +64,17 @@ int blsmi_final_exponentiation_batch(const uint64_t *in_fq12, uint64_t *out_fq12
  * (its 96/192 bytes are then zero).  in_inf may be NULL (all finite). */
 int blsmi_g1_mul_batch(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
 int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
+/* k_i * generator (PrivToPub g2pubs/bls.go:138-140 uses G2, g1pubs/bls.go:144-146 uses G1) */
+int blsmi_g1_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
+int blsmi_g2_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
 /* sum of n points (tree reduction on the device; equals the reference's sequential Jacobian sum
  * after ToAffine).  *out_inf = 1 for the point at infinity. */
 int blsmi_g1_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t out[96], int *out_inf);
 int blsmi_g2_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t out[192], int *out_inf);
+/* multi-scalar multiplication sum_i k_i * P_i (BASELINE config 3: fixed-window multiples + tree sum, one
+ * device pass; equals summing the reference's MulFR results with AddAssign, compared after ToAffine) */
+int blsmi_g1_msm(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[96], int *out_inf);
+int blsmi_g2_msm(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[192], int *out_inf);
 
 /* ---- hash to curve (HashG1 hash.go:326-331, HashG2 hash.go:405-411, HashG2WithDomain
  * g2.go:1041-1085) -- messages are concatenated in `msgs`, message i = msgs[off[i] .. off[i+1]) -- */

@@ -216,6 +216,71 @@ def test_scalar_mul_and_sums(eng):
     assert eng.g2_sum(b"", 0) is None
 
 
+def test_priv_to_pub_and_msm(eng):
+    import bls_amd.g1pubs as g1p
+    import bls_amd.g2pubs as g2p
+    xs = P.XORShift(12)
+    n = 66
+    sks = [sk_bytes(xs) for _ in range(n)]
+    sks[0] = bytes(32); sks[1] = (1).to_bytes(32, "big")
+    pk2 = g2p.PrivToPubBatch(sks); pk1 = g1p.PrivToPubBatch(sks)
+    assert pk2[0].p.infinity and pk1[0].p.infinity
+    for i in range(1, n):
+        assert pk2[i].p.raw == RC.g2pubs.priv_to_pub(sks[i]), i
+        assert pk1[i].p.raw == RC.g1pubs.priv_to_pub(sks[i]), i
+    # multi-scalar multiplication = sum of the per-point multiples (config 3)
+    pts1 = [pk1[i].p.raw for i in range(1, n)]; pts2 = [pk2[i].p.raw for i in range(1, n)]
+    ks = [sk_bytes(xs) for _ in range(n - 1)]
+    ks[3] = bytes(32)
+    for m in (1, 2, 5, n - 1):
+        e1 = [RC.g1_mul(p, k) for p, k in zip(pts1[:m], ks[:m])]; e1 = [e for e in e1 if e is not None]
+        e2 = [RC.g2_mul(p, k) for p, k in zip(pts2[:m], ks[:m])]; e2 = [e for e in e2 if e is not None]
+        assert eng.g1_msm(b"".join(pts1[:m]), b"".join(ks[:m]), m) == RC.g1_sum(b"".join(e1), len(e1))
+        assert eng.g2_msm(b"".join(pts2[:m]), b"".join(ks[:m]), m) == RC.g2_sum(b"".join(e2), len(e2))
+    assert eng.g1_msm(b"", b"", 0) is None
+    assert eng.g1_msm(pts1[0], bytes(32), 1) is None
+
+
+def test_concurrent_callers(eng):
+    """The C ABI is callable from several OS threads at once (cgo pins one per call): each call leases its own
+    stream/scratch context.  ctypes drops the GIL for the duration of a call, so these really overlap."""
+    import threading
+    import bls_amd.g1pubs as g1p
+    import bls_amd.g2pubs as g2p
+    jobs = []
+    for group, seed in (("g2pubs", 21), ("g1pubs", 22), ("g2pubs", 23), ("g1pubs", 24)):
+        msgs, pks, sigs, expect = _tuples(group, 24, seed)
+        jobs.append((group, msgs, pks, sigs, expect))
+    xs = P.XORShift(25)
+    g1s = [rand_g1(xs) for _ in range(8)]; g2s = [rand_g2(xs) for _ in range(8)]
+    want_pair = eng.pairing_batch(b"".join(g1s), b"".join(g2s), 8).copy()
+    results = {}
+
+    def run(idx):
+        try:
+            if idx < len(jobs):
+                group, msgs, pks, sigs, expect = jobs[idx]
+                mod = g2p if group == "g2pubs" else g1p
+                mk_pk = mod.NewPublicKeyFromG2 if group == "g2pubs" else mod.NewPublicKeyFromG1
+                mk_sig = mod.NewSignatureFromG1 if group == "g2pubs" else mod.NewSignatureFromG2
+                for _ in range(3):
+                    got = mod.VerifyBatch(msgs, [mk_pk(p) for p in pks], [mk_sig(s) for s in sigs])
+                    assert got == expect
+            else:
+                for _ in range(6):
+                    assert (eng.pairing_batch(b"".join(g1s), b"".join(g2s), 8) == want_pair).all()
+            results[idx] = True
+        except Exception as e:  # noqa: BLE001
+            results[idx] = e
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs) + 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(results.get(i) is True for i in range(len(threads))), results
+
+
 def test_wire_format(eng, kats):
     xs = P.XORShift(9)
     n = 10
