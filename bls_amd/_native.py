@@ -47,6 +47,28 @@ class NativeError(RuntimeError):
     pass
 
 
+def _prefer_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (and HSA runtime) under
+    torch/lib; libblsmi.so names the same SONAME with /opt/rocm on its runpath.  Whichever copy is mapped first
+    serves both, and a process that maps /opt/rocm's first and imports torch afterwards ends up with torch unable
+    to see the GPU ("ProcessGroupNCCL ... no GPUs found").  When torch is installed, map its copy first -- without
+    importing torch -- so the load order of `bls_amd` and `torch` no longer matters.  Without torch (the Go/cgo
+    deployment) the runpath copy is used."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: fall back to the runpath copy
+        pass
+
+
 def load():
     """Return the ctypes handle of libblsmi.so; never falls back to anything else."""
     global _lib
@@ -55,6 +77,7 @@ def load():
     if not os.path.exists(SO_PATH):
         raise NativeError("bls_amd/libblsmi.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _prefer_torch_hip_runtime()
     _lib = C.CDLL(SO_PATH)
     _lib.blsmi_version.restype = C.c_char_p
     return _lib

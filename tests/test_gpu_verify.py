@@ -363,3 +363,33 @@ def test_sharded_verify_aggregate_single_process(eng):
     # partial product of an empty shard is 1, and fq12_product agrees with the oracle
     one = eng.aggregate_partial("g2pubs", [], b"")
     assert np.array_equal(eng.fq12_product(np.stack([one, one])), one)
+
+
+def test_rccl_collectives_world1(eng):
+    """The production collectives (torch.distributed backend "nccl" = RCCL, device tensors) on a one-rank group:
+    bitmap all-reduce of a sharded batch verify and the two all-gathers of a sharded VerifyAggregate."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from bls_amd import dist as bdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        msgs, pks, sigs, expect = _tuples("g2pubs", 19, 31)
+
+        def shard(lo, hi):
+            ok, _ = eng.g2pubs_verify_batch(msgs[lo:hi], b"".join(pks[lo:hi]), b"".join(sigs[lo:hi]))
+            return ok
+        bitmap = bdist.sharded_verify_bitmap(len(msgs), shard, 0, 1, bdist.torch_all_reduce(dev))
+        assert list(bdist.unpack_bitmap(bitmap, len(msgs))) == expect
+        xs = P.XORShift(32)
+        sks = [sk_bytes(xs) for _ in range(5)]
+        amsgs = [b"distinct message %d" % i for i in range(5)]
+        apks = [RC.g2pubs.priv_to_pub(sk) for sk in sks]
+        agg = RC.g1_sum(b"".join(RC.g2pubs.sign(m, sk) for m, sk in zip(amsgs, sks)), 5)
+        gather = bdist.torch_all_gather_bytes(dev)
+        assert bdist.sharded_verify_aggregate("g2pubs", amsgs, b"".join(apks), agg, 0, 1, gather) is True
+        assert bdist.sharded_verify_aggregate("g2pubs", amsgs, b"".join(apks[::-1]), agg, 0, 1, gather) is False
+    finally:
+        dist.destroy_process_group()
