@@ -208,6 +208,7 @@ KERNEL k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_
         case BLSMI_OP_FQ2_INV: r = fp2_store(fp2_inv(x)); ok = !fp2_is_zero(x); break;
         case BLSMI_OP_FQ2_MUL_NR: r = fp2_store(fp2_mul_nr(x)); break;
         case BLSMI_OP_FQ2_SQRT: r = fp2_sqrt(x, ok); break;
+        case BLSMI_OP_FQ2_SQRT_ANY: r = fp2_sqrt_any(x, ok); break;
     }
     as<Fp2S>(ro) = r;
     rec_store<2>(out, t, ro);

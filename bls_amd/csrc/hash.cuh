@@ -188,13 +188,13 @@ __device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
     const Fp2S x0 = fp2_store(fp2_mul(num, fp2_store(fp2_inv(den))));
     const Fp2S gx0 = fp2_store(fp2_add(fp2_add(fp2_mul(fp2_sqr(x0), x0), fp2_mul(C_ELL2PA, x0)), C_ELL2PB));
     bool ok0, ok1;
-    const Fp2S s0 = fp2_sqrt(gx0, ok0);
+    const Fp2S s0 = fp2_sqrt_any(gx0, ok0);                               // sign fixed below
     const bool good0 = ok0 & fp2_eq(fp2_sqr(s0), gx0);                     // g2.go:977-981
     const Fp2S x1 = fp2_store(fp2_mul(nqr_tsq, x0));
     const Fp2S t6 = fp2_store(fp2_sqr(fp2_mul(tsq, t)));
     Fp2S nqr3 = fp2_store(fp2_mul_nr(fp2_mul_nr(nqr)));                    // nqr^3
     const Fp2S gx1 = fp2_store(fp2_mul(fp2_mul(nqr3, t6), gx0));
-    const Fp2S s1 = fp2_sqrt(gx1, ok1);
+    const Fp2S s1 = fp2_sqrt_any(gx1, ok1);
     const i32 m0 = good0 ? -1 : 0;
     const Fp2S x = fp2_select(m0, x0, x1);
     Fp2S y = fp2_select(m0, s0, s1);
@@ -289,7 +289,7 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
     while (true) {
         const Fp2S gx = fp2_store(fp2_add(fp2_mul(fp2_sqr(x0), x0), C_B2));
         bool ok;
-        Fp2S y = fp2_sqrt(gx, ok);
+        Fp2S y = fp2_sqrt_any(gx, ok);                                     // sign fixed below
         const i32 take = (ok ? -1 : 0) & ~done;
         // favour y with Parity() == true (g2.go:1074-1077): parity(y) <=> y > -y (fq2.go:256-260)
         const i32 y_gt = fp2_sign_is_neg(y);                               // y > (q-1)/2 lexicographically (c1 first) <=> y > -y

@@ -127,7 +127,7 @@ int blsmi_g2_compress_batch(const uint8_t *pts, const uint8_t *in_inf, uint8_t *
  * arrays of n records of `width` Fq values, each Fq as 6 LE uint64 Montgomery(2^384) limbs. -------- */
 enum blsmi_debug_op {
     BLSMI_OP_FQ_MUL = 1, BLSMI_OP_FQ_SQR, BLSMI_OP_FQ_ADD, BLSMI_OP_FQ_SUB, BLSMI_OP_FQ_NEG, BLSMI_OP_FQ_INV, BLSMI_OP_FQ_SQRT,
-    BLSMI_OP_FQ2_MUL = 16, BLSMI_OP_FQ2_SQR, BLSMI_OP_FQ2_INV, BLSMI_OP_FQ2_MUL_NR, BLSMI_OP_FQ2_SQRT,
+    BLSMI_OP_FQ2_MUL = 16, BLSMI_OP_FQ2_SQR, BLSMI_OP_FQ2_INV, BLSMI_OP_FQ2_MUL_NR, BLSMI_OP_FQ2_SQRT, BLSMI_OP_FQ2_SQRT_ANY /* either root */,
     BLSMI_OP_FQ6_MUL = 32, BLSMI_OP_FQ6_SQR, BLSMI_OP_FQ6_INV, BLSMI_OP_FQ6_FROB1,
     BLSMI_OP_FQ12_MUL = 48, BLSMI_OP_FQ12_SQR, BLSMI_OP_FQ12_INV, BLSMI_OP_FQ12_FROB1, BLSMI_OP_FQ12_FROB2, BLSMI_OP_FQ12_FROB3, BLSMI_OP_FQ12_CYCLO_SQR,
     BLSMI_OP_G1_DOUBLE = 64, BLSMI_OP_G1_ADD, BLSMI_OP_G2_DOUBLE, BLSMI_OP_G2_ADD

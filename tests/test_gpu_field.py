@@ -85,6 +85,19 @@ def test_fq2_ops(eng):
         assert bool(ok[i]) == bool(r), i
         if r:
             assert np.array_equal(out[i], e), i
+    # the two-Fq-exponentiation root used on the hash / decompress paths: same squareness verdict, a root of the
+    # input (either sign), including the Fq-embedded cases a1 = 0 with a0 a residue / a non-residue, and u * Fq
+    extra = []
+    for v in (4, 9, 5, 7, P.Q - 4, P.Q - 5):
+        extra.append(pack([v, 0])); extra.append(pack([0, v]))
+    sq2 = np.concatenate([sq, np.stack(extra)])
+    out, ok = eng.debug_op("FQ2_SQRT_ANY", sq2)
+    for i in range(len(sq2)):
+        r, e = RC.fq2_sqrt(sq2[i])
+        assert bool(ok[i]) == bool(r), i
+        if r:
+            assert np.array_equal(RC.fq2_sqr(out[i]), sq2[i]), i
+            assert np.array_equal(out[i], e) or np.array_equal(out[i], RC.fq2_neg(e)), i
 
 
 def test_fq6_fq12_ops(eng):
