@@ -265,7 +265,17 @@ BLSMI_DEV void debug_curve(int dbl, const u64* a, const u64* b, u64* out, size_t
 KERNEL k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     if (t >= n) return;
-    if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
+    if (op == BLSMI_OP_SWU_G1) {                                         // optimizedSWUMapHelper (g1.go:628-714) on a caller-chosen t
+        Rec<3> r = rec_load<3>(a, t);
+        G1Aff p; swu_g1_helper(p, reinterpret_cast<FpS*>(&r)[0]);
+        reinterpret_cast<FpS*>(&r)[0] = p.x; reinterpret_cast<FpS*>(&r)[1] = p.y; reinterpret_cast<FpS*>(&r)[2] = fp_zero();
+        rec_store<3>(out, t, r);
+    } else if (op == BLSMI_OP_SWU_G2) {                                  // OptimizedSWU2MapHelper (g2.go:933-1031)
+        Rec<6> r = rec_load<6>(a, t);
+        G2Aff p; swu_g2_helper(p, reinterpret_cast<Fp2S*>(&r)[0]);
+        reinterpret_cast<Fp2S*>(&r)[0] = p.x; reinterpret_cast<Fp2S*>(&r)[1] = p.y; reinterpret_cast<Fp2S*>(&r)[2] = fp2_zero();
+        rec_store<6>(out, t, r);
+    } else if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
     else debug_curve<Fp2S, 6>(op == BLSMI_OP_G2_DOUBLE, a, b, out, t);
 }
 
@@ -593,7 +603,7 @@ BLSMI_API int blsmi_final_exponentiation_batch(const uint64_t* in, uint64_t* out
 
 // ---- unit-level ops -------------------------------------------------------------------------------
 BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flag, size_t n) {
-    int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) ? 3 : 6;
+    int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
     if (n && (!a || !out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
     if (n == 0) return BLSMI_OK;

@@ -137,7 +137,11 @@ __device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
     const FpS y0 = fp_sqrt(gx0, ok0);
     const FpS x1 = fp_store(fp_mul(fp_neg(tsq), x0));                      // (-1) t^2 x0
     const FpS gx1 = fp_store(fp_add(fp_add(fp_mul(fp_sqr(x1), x1), fp_mul(C_ELLPA, x1)), C_ELLPB));
-    const FpS y1 = fp_sqrt(gx1, ok1);
+    // When gx0 is a non-residue, y0 = gx0^((q+1)/4) squares to -gx0, and gx1 = (-1)^3 t^6 gx0 = (t^3 y0)^2: the second
+    // root costs three multiplications instead of an exponentiation.  (Either root serves: the sign is fixed below.)
+    // The identity needs the regular x0; the exceptional t (ndc == 0: t in {0, 1, -1}) takes the reference's route.
+    FpS y1 = fp_store(fp_mul(fp_mul(tsq, t), y0));
+    if (__any(ndc0 != 0)) y1 = fp_select(ndc0, fp_sqrt(gx1, ok1), y1);
     const i32 m0 = ok0 ? -1 : 0;
     const FpS x = fp_select(m0, x0, x1);
     const FpS y = fp_select(m0, y0, y1);
@@ -187,17 +191,23 @@ __device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
     const Fp2S den = fp2_select(ndc0, fp2_store(fp2_mul_nr(C_ELL2PA)), fp2_store(fp2_mul(C_ELL2PA, ndc)));
     const Fp2S x0 = fp2_store(fp2_mul(num, fp2_store(fp2_inv(den))));
     const Fp2S gx0 = fp2_store(fp2_add(fp2_add(fp2_mul(fp2_sqr(x0), x0), fp2_mul(C_ELL2PA, x0)), C_ELL2PB));
-    bool ok0, ok1;
-    const Fp2S s0 = fp2_sqrt_any(gx0, ok0);                               // sign fixed below
-    const bool good0 = ok0 & fp2_eq(fp2_sqr(s0), gx0);                     // g2.go:977-981
+    // The reference takes sqrt(gx0) and, when gx0 is not a square, sqrt(gx1) with gx1 = nqr^3 t^6 gx0 (g2.go:977-1019).
+    // Exactly one root is needed, so: one Fq exponentiation decides gx0 through its norm n0 (s0 = n0^((q+1)/4),
+    // s0^2 = +-n0); for a non-residue, N(gx1) = 8 N(t)^6 n0 = (sqrt(-8) N(t)^3 s0)^2 gives the norm root of gx1 for
+    // free; a second exponentiation then finishes the root of whichever was selected (fp2_sqrt_from_norm_root).
+    bool ok0;
+    FpS n0;
+    const FpS s0 = fp2_norm_root(gx0, n0, ok0);
     const Fp2S x1 = fp2_store(fp2_mul(nqr_tsq, x0));
     const Fp2S t6 = fp2_store(fp2_sqr(fp2_mul(tsq, t)));
     Fp2S nqr3 = fp2_store(fp2_mul_nr(fp2_mul_nr(nqr)));                    // nqr^3
     const Fp2S gx1 = fp2_store(fp2_mul(fp2_mul(nqr3, t6), gx0));
-    const Fp2S s1 = fp2_sqrt_any(gx1, ok1);
-    const i32 m0 = good0 ? -1 : 0;
+    const FpS nt = fp_store(fp_add(fp_sqr(t.c0), fp_sqr(t.c1)));
+    const FpS s1 = fp_store(fp_mul(fp_mul(fp_mul(fp_sqr(nt), nt), s0), C_SQRT_M8));
+    const i32 m0 = ok0 ? -1 : 0;
     const Fp2S x = fp2_select(m0, x0, x1);
-    Fp2S y = fp2_select(m0, s0, s1);
+    const Fp2S g = fp2_select(m0, gx0, gx1);
+    Fp2S y = fp2_sqrt_from_norm_root(g, fp_select(m0, s0, s1));
     const i32 flip = fp2_sign_is_neg(t) ^ fp2_sign_is_neg(y);             // signT != signY (g2.go:983-988, 1021-1026)
     y = fp2_select(flip, fp2_store(fp2_neg(y)), y);
     out.x = x; out.y = y; out.inf = 0;

@@ -3,7 +3,7 @@ on the reference's in-memory representation (6 x u64 Montgomery limbs, R = 2^384
 import numpy as np
 import pytest
 
-from gpu_common import P, RC, mont, pack, rand_fq
+from gpu_common import P, RC, mont, pack, rand_fq, unmont
 
 pytestmark = pytest.mark.gpu
 
@@ -182,3 +182,27 @@ def test_curve_ops(eng):
         out, _ = eng.debug_op(add, a, b)
         for i in range(len(A)):
             assert to_aff(out[i]) == to_aff(fn_a(a[i], b[i])), (group, "add", i)
+
+
+def test_swu_helpers_including_exceptional_t(eng):
+    """optimizedSWUMapHelper / OptimizedSWU2MapHelper (g1.go:628-714, g2.go:933-1031) on chosen t, against the Python
+    twin: the device derives the second square root from the first exponentiation, except for the exceptional
+    t (ndc == 0: 0, 1, -1 in G1; 0 and the roots of nqr*t^2 = -1 in G2), which no message hash reaches."""
+    xs = P.XORShift(104)
+    ts = [0, 1, P.Q - 1, 2, P.Q - 2] + rand_fq(xs, 40)
+    a = np.stack([np.concatenate([mont(t), mont(0), mont(0)]) for t in ts])
+    out, _ = eng.debug_op("SWU_G1", a)
+    for i, t in enumerate(ts):
+        x, y = P.swu_g1_helper(t)[:2]
+        assert unmont(out[i][:6]) == x and unmont(out[i][6:12]) == y, (i, t)
+    t2s = [(0, 0), (1, 0), (0, 1), (P.Q - 1, 0)] + [tuple(rand_fq(xs, 2)) for _ in range(40)]
+    # nqr * t^2 = -1  <=>  t^2 = -1/(1+u): an exceptional t of the G2 helper when that is a square
+    r = P.fq2_sqrt(P.fq2_neg(P.fq2_inv((1, 1))))
+    if r is not None:
+        t2s.append(tuple(r))
+    a = np.stack([np.concatenate([mont(t[0]), mont(t[1])] + [mont(0)] * 4) for t in t2s])
+    out, _ = eng.debug_op("SWU_G2", a)
+    for i, t in enumerate(t2s):
+        p = P.swu_g2_helper(t)
+        got = [unmont(out[i][6 * k:6 * k + 6]) for k in range(4)]
+        assert got == [p[0][0], p[0][1], p[1][0], p[1][1]], (i, t)
