@@ -233,11 +233,13 @@ BLSMI_DEV auto fp_sqr(const Fp<L, V>& a) {
 }
 
 // ---- value reduction: subtract round(value/q)*q with exact carries -> value in (-1.01q, 2.01q) ------
-// The quotient is estimated in fp32 from the two top limbs (value / 2^351).
+// The quotient is estimated in fp32 from the two top limbs (value / 2^351); un-normalised lower limbs
+// (|limb| <= 15 * 2^27) move the estimate by < 2^-25, and the exact carry pass below normalises anyway.
 template <int L, int V>
 BLSMI_DEV Fp<1, 3> fp_reduce(const Fp<L, V>& x) {
     static_assert(V <= VMAX, "value bound exceeded");
-    Fp<1, V> y = fp_norm(x);
+    static_assert(L <= LMAX, "limb bound exceeded before reduce");
+    const Fp<L, V>& y = x;
     const float top = (float)y.v[NL - 1] * 134217728.0f + (float)y.v[NL - 2];
     const i32 k = (i32)floorf(top * BLSMI_Q_TOP2_INV);
     Fp<1, 3> r;
