@@ -419,7 +419,8 @@ thread_local Ctx* tl_ctx = nullptr;
 #define g_stream (tl_ctx->stream)
 #define g_ws (tl_ctx->ws)
 // G1/G2 generators in wire form, written once at init (read-only afterwards)
-struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; } g_gens;
+struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; } g_gens;
+bool g_use_gen_lines = true;           // BLSMI_GEN_LINES=0 recomputes the generator's lines per tuple (A/B switch)
 // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline object
 bool g_profile = false;
 float g_last_ms[2] = {0.f, 0.f};
@@ -445,9 +446,13 @@ int ensure_init(int device) {           // caller holds g_mu
     if (!g_gens.g1) {
         HIPCHK(hipMalloc((void**)&g_gens.g1, 96)); HIPCHK(hipMalloc((void**)&g_gens.g2, 192));
         hipLaunchKernelGGL(k_write_generators, dim3(1), dim3(WG), 0, nullptr, g_gens.g1, g_gens.g2);
+        HIPCHK(hipMalloc((void**)&g_gens.lines, sizeof(i32) * 68 * 3 * 2 * NL));
+        hipLaunchKernelGGL(k_prepare_generator_lines, dim3(1), dim3(WG), 0, nullptr, (const u8*)g_gens.g2, g_gens.lines);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
     }
+    const char* gl = getenv("BLSMI_GEN_LINES");
+    g_use_gen_lines = !(gl && std::string(gl) == "0");
     g_ready = true;
     return BLSMI_OK;
 }
