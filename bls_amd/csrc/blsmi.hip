@@ -23,6 +23,8 @@ using namespace blsmi;
 #define BLSMI_WAVES_PER_SIMD 1
 #endif
 #define KERNEL __global__ void __launch_bounds__(WG, BLSMI_WAVES_PER_SIMD)
+// G1-side kernels keep far less live state (Fq, not Fq2/Fq12): 256 registers, two waves per SIMD
+#define KERNEL2 __global__ void __launch_bounds__(WG, 2)
 
 // ------------------------------------------------------------------------------------------------
 // device-side I/O helpers
@@ -265,18 +267,25 @@ BLSMI_DEV void debug_curve(int dbl, const u64* a, const u64* b, u64* out, size_t
 KERNEL k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     if (t >= n) return;
-    if (op == BLSMI_OP_SWU_G1) {                                         // optimizedSWUMapHelper (g1.go:628-714) on a caller-chosen t
-        Rec<3> r = rec_load<3>(a, t);
-        G1Aff p; swu_g1_helper(p, reinterpret_cast<FpS*>(&r)[0]);
-        reinterpret_cast<FpS*>(&r)[0] = p.x; reinterpret_cast<FpS*>(&r)[1] = p.y; reinterpret_cast<FpS*>(&r)[2] = fp_zero();
-        rec_store<3>(out, t, r);
-    } else if (op == BLSMI_OP_SWU_G2) {                                  // OptimizedSWU2MapHelper (g2.go:933-1031)
-        Rec<6> r = rec_load<6>(a, t);
-        G2Aff p; swu_g2_helper(p, reinterpret_cast<Fp2S*>(&r)[0]);
-        reinterpret_cast<Fp2S*>(&r)[0] = p.x; reinterpret_cast<Fp2S*>(&r)[1] = p.y; reinterpret_cast<Fp2S*>(&r)[2] = fp2_zero();
-        rec_store<6>(out, t, r);
-    } else if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
+    if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
     else debug_curve<Fp2S, 6>(op == BLSMI_OP_G2_DOUBLE, a, b, out, t);
+}
+// SWU helpers on a caller-chosen t (own kernels: the G1 helper keeps the two-waves-per-SIMD register budget of k_hash_g1)
+KERNEL2 k_debug_swu_g1(const u64* a, u64* out, size_t n) {               // optimizedSWUMapHelper (g1.go:628-714)
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<3> r = rec_load<3>(a, t);
+    G1Aff p; swu_g1_helper(p, reinterpret_cast<FpS*>(&r)[0]);
+    reinterpret_cast<FpS*>(&r)[0] = p.x; reinterpret_cast<FpS*>(&r)[1] = p.y; reinterpret_cast<FpS*>(&r)[2] = fp_zero();
+    rec_store<3>(out, t, r);
+}
+KERNEL k_debug_swu_g2(const u64* a, u64* out, size_t n) {                // OptimizedSWU2MapHelper (g2.go:933-1031)
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<6> r = rec_load<6>(a, t);
+    G2Aff p; swu_g2_helper(p, reinterpret_cast<Fp2S*>(&r)[0]);
+    reinterpret_cast<Fp2S*>(&r)[0] = p.x; reinterpret_cast<Fp2S*>(&r)[1] = p.y; reinterpret_cast<Fp2S*>(&r)[2] = fp2_zero();
+    rec_store<6>(out, t, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,7 +323,7 @@ __device__ void mul_batch_body(const u8* pts, size_t pt_stride, const u8* scalar
     const Aff<F> a = jac_to_affine(res);
     if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
 }
-KERNEL k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
+KERNEL2 k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
 KERNEL k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
 
 // Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
@@ -351,7 +360,7 @@ __device__ void sum_level0_body(const u8* pts, const u8* in_inf, i32* buf, size_
     }
     jac_soa_store(buf, half, t, r);
 }
-KERNEL k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<FpS, 96>(pts, in_inf, buf, n, half); }
+KERNEL2 k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<FpS, 96>(pts, in_inf, buf, n, half); }
 KERNEL k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<Fp2S, 192>(pts, in_inf, buf, n, half); }
 template <class F>
 __device__ void sum_level_body(const i32* src, i32* dst, size_t n, size_t half) {
@@ -361,7 +370,7 @@ __device__ void sum_level_body(const i32* src, i32* dst, size_t n, size_t half) 
     if (t + half < n) r = jac_add(r, jac_soa_load<F>(src, n, t + half));
     jac_soa_store(dst, half, t, r);
 }
-KERNEL k_g1_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<FpS>(src, dst, n, half); }
+KERNEL2 k_g1_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<FpS>(src, dst, n, half); }
 KERNEL k_g2_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<Fp2S>(src, dst, n, half); }
 template <class F, int PB>
 __device__ void sum_final_body(const i32* src, u8* out, i32* out_inf) {
@@ -370,7 +379,7 @@ __device__ void sum_final_body(const i32* src, u8* out, i32* out_inf) {
     store_aff(out, a);
     *out_inf = a.inf ? 1 : 0;
 }
-KERNEL k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<FpS, 96>(src, out, out_inf); }
+KERNEL2 k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<FpS, 96>(src, out, out_inf); }
 KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
 
 #include "verify_kernels.inc"
@@ -623,6 +632,8 @@ BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint6
     else if (op < 32) hipLaunchKernelGGL(k_debug_fq2, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
     else if (op < 48) hipLaunchKernelGGL(k_debug_fq6, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
     else if (op < 64) hipLaunchKernelGGL(k_debug_fq12, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
+    else if (op == BLSMI_OP_SWU_G1) hipLaunchKernelGGL(k_debug_swu_g1, g, w, 0, g_stream, da.as<u64>(), dout.as<u64>(), n);
+    else if (op == BLSMI_OP_SWU_G2) hipLaunchKernelGGL(k_debug_swu_g2, g, w, 0, g_stream, da.as<u64>(), dout.as<u64>(), n);
     else hipLaunchKernelGGL(k_debug_curve, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout.p, bytes, hipMemcpyDeviceToHost, g_stream));
