@@ -71,29 +71,35 @@ def synth_inputs(engine, n, seed):
     return np.ascontiguousarray(g1), np.ascontiguousarray(g2)
 
 
-def verify_extra(engine, dev, n=65536):
-    """Outside the timed region: throughput of the full Verify path (hash-to-curve + 2-pair Miller loop + final
-    exponentiation + compare) on n device-resident tuples, both packages.  1 Verify = 2 Miller-loop pairs + 1 final exp + 1 hash."""
+def _verify_inputs(engine, dev, group, n):
+    """n valid (message, public key, signature) tuples of one package, resident in HBM (signed on the device)."""
     import hashlib
     import torch
-    out = {}
     nk = 256
     sk = b"".join(hashlib.sha256(b"bench-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
     msgs = [b"Hello world! 16 characters %d" % i for i in range(n)]
     buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(m) for m in msgs])
     g1gen, g2gen = _gens()
+    if group == "g2pubs":
+        pks, _ = engine.g2_mul_batch(g2gen * nk, sk, nk)
+        h = engine.hash_g1_batch(msgs)
+        sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
+    else:
+        pks, _ = engine.g1_mul_batch(g1gen * nk, sk, nk)
+        h = engine.hash_g2_batch(msgs)
+        sigs, _ = engine.g2_mul_batch(h.reshape(-1), sk * (n // nk), n)
+    allpk = np.tile(pks, (n // nk, 1))
+    return [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (buf.copy(), off.view(np.int64), allpk, sigs)]
+
+
+def verify_extra(engine, dev, n=65536):
+    """Outside the timed region: throughput of the full Verify path (hash-to-curve + 2-pair Miller loop + final
+    exponentiation + compare) on n device-resident tuples, both packages.  1 Verify = 2 Miller-loop pairs + 1 final exp + 1 hash."""
+    import torch
+    out = {}
     for group in ("g2pubs", "g1pubs"):
-        if group == "g2pubs":
-            pks, _ = engine.g2_mul_batch(g2gen * nk, sk, nk)
-            h = engine.hash_g1_batch(msgs)
-            sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
-        else:
-            pks, _ = engine.g1_mul_batch(g1gen * nk, sk, nk)
-            h = engine.hash_g2_batch(msgs)
-            sigs, _ = engine.g2_mul_batch(h.reshape(-1), sk * (n // nk), n)
-        allpk = np.tile(pks, (n // nk, 1))
-        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (buf.copy(), off.view(np.int64), allpk, sigs)]
+        d = _verify_inputs(engine, dev, group, n)
         d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
         best = 1e9
         for _ in range(3):
@@ -105,6 +111,32 @@ def verify_extra(engine, dev, n=65536):
     out["tuples"] = n
     out["note"] = "all tuples valid; inputs resident in HBM; includes hash-to-curve on the GPU"
     return out
+
+
+def sharded_verify_extra(engine, dev, rank, world, dist, n=65536):
+    """Outside the timed region, every rank: the north-star's multi-GPU batch verify -- each rank verifies its own
+    block of n g2pubs tuples, packs the verdicts into its slice of the world*n-bit bitmap, and ONE RCCL all-reduce
+    (sum over disjoint bit ownership == OR) gives every rank the full bitmap.  Returns whole-job verifies/s (max time
+    over ranks) on rank 0."""
+    import torch
+    d = _verify_inputs(engine, dev, "g2pubs", n)
+    d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=dev)
+    full = torch.zeros(world * n // 8, dtype=torch.int32, device=dev)
+    best = 1e9
+    for _ in range(3):
+        full.zero_()
+        dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        engine.verify_batch_dev("g2pubs", d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+        full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        best = min(best, float(t.item()))
+    assert bool((full == 255).all().item()), "every rank's tuples must verify and land in the shared bitmap"
+    return {"g2pubs_verifies_per_s": round(world * n / best, 1), "tuples_per_gpu": n, "bitmap_bytes": world * n // 8,
+            "collective": "one all_reduce(SUM, int32 lanes, disjoint bit ownership) over RCCL per batch"}
 
 
 def _gens():
@@ -119,11 +151,29 @@ def _gens():
     return g1gen, g2gen
 
 
+def usable_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(g1, g2, budget_s=12.0):
-    """Time the oracle's Pairing() (C port of the reference algorithm) on all host cores over a bounded sample."""
+    """Time the oracle's Pairing() (C port of the reference algorithm) on the host cores this container may use,
+    one thread per core, over a bounded sample."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import refcpu as RC
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     t0 = time.time()
     RC.pairing_batch(g1[:4].tobytes(), g2[:4].tobytes(), 4)
     per = (time.time() - t0) / 4
@@ -138,8 +188,9 @@ def cpu_baseline(g1, g2, budget_s=12.0):
         list(ex.map(work, range(cores)))
     dt = time.time() - t0
     return {"value": round(cores * chunk / dt, 2), "unit": "pairings/s", "cores": cores, "kind": "port",
-            "sample": "%d reference-algorithm Pairing() calls of the same workload (%d per core x %d cores, %.1f s wall); "
-                      "oracle/refcpu.c = C restatement of the Go reference (no Go toolchain on this image)" % (cores * chunk, chunk, cores, dt),
+            "sample": "%d reference-algorithm Pairing() calls of the same workload (%d per thread x %d threads = usable cores: "
+                      "affinity mask capped by the cgroup CPU quota; host reports %d logical CPUs; %.1f s wall); "
+                      "oracle/refcpu.c = C restatement of the Go reference (no Go toolchain on this image)" % (cores * chunk, chunk, cores, os.cpu_count() or 0, dt),
             "single_core_pairings_per_s": round(1.0 / per, 2)}
 
 
@@ -209,6 +260,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    sharded = None
+    if use_dist and not args.no_verify_extra:                       # all ranks take part in the collective
+        try:
+            sharded = sharded_verify_extra(engine, dev, rank, world, dist)
+        except Exception as e:  # noqa: BLE001 -- an extra must never cost the headline line
+            sharded = {"error": repr(e)[:300]}
     # cross-rank sanity outside the timed region: every rank holds finite, distinct outputs; rank 0 checks a sample
     checksum = int(d_out[::997].sum().item()) & 0xffffffff
     if rank == 0:
@@ -240,6 +297,8 @@ def main():
                              "achieved = pairings/s x 14.6k Fq multiplications per pairing (SURVEY 8d)"},
             "checksum": checksum,
         }
+        if sharded is not None:
+            line["sharded_verify"] = sharded
         if world == 1 and not args.no_verify_extra:
             line["verify"] = verify_extra(engine, dev)
         if world == 1 and not args.no_cpu_baseline:
