@@ -124,7 +124,9 @@ BLSMI_DEV i32 fp2_sign_is_neg(const Fp2S& f) {                                  
 }
 
 // ---- G1: simplified SWU to the 11-isogenous curve (g1.go:628-714) ----------------------------------
-__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
+// The map as the reference writes it: an inversion for x0 and a square root (one exponentiation each).  Kept for the
+// rare lanes the fused version below cannot serve (exceptional t, g(x0) = 0).
+__device__ __noinline__ void swu_g1_helper_ref(G1Aff& out, const FpS& t) {
     const FpS tsq = fp_store(fp_sqr(t));
     const FpS ndc = fp_store(fp_sub(fp_sqr(tsq), tsq));                   // (-1)^2 t^4 + (-1) t^2
     const i32 ndc0 = fp_is_zero(ndc) ? -1 : 0;
@@ -148,6 +150,41 @@ __device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
     out.x = x;
     out.y = fp_store(fp_mul(y, fp_mul(fp_sign(y), fp_sign(t))));          // g1.go:706-711
     out.inf = 0;
+}
+// Same map with ONE exponentiation.  x0 = num/den and g(x0) = U/V with U = num^3 + A num den^2 + B den^3, V = den^3.
+// With w = U V^3 and e = w^((q-3)/4):  e^2 w = chi(w) = chi(U/V) = +-1, so
+//   y0 = U V e        has  y0^2 = chi * U/V   (the square root of g(x0), or of -g(x0) for a non-residue)
+//   1/V = chi U V^2 e^2,   x0 = num den^2 / V
+// and for a non-residue g(x0), g(x1) = -t^6 g(x0) = (t^3 y0)^2.  Outputs are the same field elements.
+__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
+    const FpS tsq = fp_store(fp_sqr(t));
+    const FpS ndc = fp_store(fp_sub(fp_sqr(tsq), tsq));                   // (-1)^2 t^4 + (-1) t^2
+    const i32 ndc0 = fp_is_zero(ndc) ? -1 : 0;
+    const FpS num = fp_select(ndc0, FpS(C_ELLPB), fp_store(fp_mul(fp_neg(C_ELLPB), fp_add(ndc, C_ONE))));   // g1.go:645-659
+    const FpS den = fp_select(ndc0, fp_store(fp_neg(C_ELLPA)), fp_store(fp_mul(C_ELLPA, ndc)));
+    const FpS den2 = fp_store(fp_sqr(den)), V = fp_store(fp_mul(den2, den));
+    const FpS nd2 = fp_store(fp_mul(num, den2));                           // num den^2
+    const FpS U = fp_store(fp_add(fp_add(fp_mul(fp_sqr(num), num), fp_mul(C_ELLPA, nd2)), fp_mul(C_ELLPB, V)));
+    const FpS V2 = fp_store(fp_sqr(V));
+    const FpS UV = fp_store(fp_mul(U, V));
+    const FpS e = fp_pow_const(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
+    const FpS y0 = fp_store(fp_mul(UV, e));
+    const i32 m0 = fp_eq(fp_mul(fp_sqr(y0), V), U) ? -1 : 0;              // g(x0) is a square
+    const FpS vinv = fp_store(fp_mul(fp_mul(UV, V), fp_sqr(e)));           // chi / V
+    const FpS x0p = fp_store(fp_mul(nd2, vinv));                           // chi * x0
+    const FpS x0 = fp_select(m0, x0p, fp_store(fp_neg(x0p)));
+    const FpS x1 = fp_store(fp_mul(fp_neg(tsq), x0));                      // (-1) t^2 x0
+    const FpS y1 = fp_store(fp_mul(fp_mul(tsq, t), y0));
+    const FpS x = fp_select(m0, x0, x1);
+    const FpS y = fp_select(m0, y0, y1);
+    out.x = x;
+    out.y = fp_store(fp_mul(y, fp_mul(fp_sign(y), fp_sign(t))));          // g1.go:706-711
+    out.inf = 0;
+    const i32 special = ndc0 | (fp_is_zero(U) ? -1 : 0);
+    if (__any(special != 0)) {
+        G1Aff r; swu_g1_helper_ref(r, t);
+        out.x = fp_select(special, r.x, out.x); out.y = fp_select(special, r.y, out.y);
+    }
 }
 template <int N>
 BLSMI_DEV FpS horner_fp(const FpS (&c)[N], const FpS& x) {
@@ -181,7 +218,8 @@ __device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len) {
 }
 
 // ---- G2 (g2.go:933-1031, hash.go:282-411) ---------------------------------------------------------------
-__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
+// Reference-shaped version (inversion + norm root + root: three exponentiations); serves g(x0) = 0.
+__device__ __noinline__ void swu_g2_helper_ref(G2Aff& out, const Fp2S& t) {
     Fp2S nqr; nqr.c0 = C_ONE; nqr.c1 = C_ONE;
     const Fp2S tsq = fp2_store(fp2_sqr(t));
     const Fp2S nqr_tsq = fp2_store(fp2_mul_nr(tsq));
@@ -211,6 +249,50 @@ __device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
     const i32 flip = fp2_sign_is_neg(t) ^ fp2_sign_is_neg(y);             // signT != signY (g2.go:983-988, 1021-1026)
     y = fp2_select(flip, fp2_store(fp2_neg(y)), y);
     out.x = x; out.y = y; out.inf = 0;
+}
+// Same map with TWO exponentiations: g(x0) = U/V as above (over Fq2); its norm is a/b with a = N(U), b = N(V).
+// With w = a b^3, e = w^((q-3)/4):  s0 = a b e has s0^2 = chi * a/b (the norm root fp2_sqrt_from_norm_root needs) and
+// 1/b = chi a b^2 e^2, which yields both x0 = num conj(den) N(den)^2 / b and g(x0) = U conj(V) / b without an inversion.
+__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
+    Fp2S nqr; nqr.c0 = C_ONE; nqr.c1 = C_ONE;
+    const Fp2S tsq = fp2_store(fp2_sqr(t));
+    const Fp2S nqr_tsq = fp2_store(fp2_mul_nr(tsq));
+    const Fp2S ndc = fp2_store(fp2_add(fp2_sqr(nqr_tsq), nqr_tsq));       // nqr^2 t^4 + nqr t^2
+    const i32 ndc0 = fp2_is_zero(ndc) ? -1 : 0;
+    const Fp2S num = fp2_select(ndc0, Fp2S(C_ELL2PB), fp2_store(fp2_mul(fp2_neg(C_ELL2PB), fp2_add(ndc, fp2_one()))));
+    const Fp2S den = fp2_select(ndc0, fp2_store(fp2_mul_nr(C_ELL2PA)), fp2_store(fp2_mul(C_ELL2PA, ndc)));
+    const Fp2S den2 = fp2_store(fp2_sqr(den)), V = fp2_store(fp2_mul(den2, den));
+    const Fp2S nd2 = fp2_store(fp2_mul(num, den2));
+    const Fp2S U = fp2_store(fp2_add(fp2_add(fp2_mul(fp2_sqr(num), num), fp2_mul(C_ELL2PA, nd2)), fp2_mul(C_ELL2PB, V)));
+    const FpS nden = fp_store(fp_add(fp_sqr(den.c0), fp_sqr(den.c1)));    // N(den)
+    const FpS nden2 = fp_store(fp_sqr(nden));
+    const FpS bb = fp_store(fp_mul(nden2, nden));                           // b = N(V) = N(den)^3
+    const FpS aa = fp_store(fp_add(fp_sqr(U.c0), fp_sqr(U.c1)));           // a = N(U)
+    const FpS ab = fp_store(fp_mul(aa, bb)), b2 = fp_store(fp_sqr(bb));
+    const FpS e = fp_pow_const(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
+    const FpS s0 = fp_store(fp_mul(ab, e));
+    const i32 m0 = fp_eq(fp_mul(fp_sqr(s0), bb), aa) ? -1 : 0;             // N(g(x0)) is a square <=> g(x0) is a square
+    const FpS binv_p = fp_store(fp_mul(fp_mul(ab, bb), fp_sqr(e)));        // chi / b
+    const FpS binv = fp_select(m0, binv_p, fp_store(fp_neg(binv_p)));
+    const Fp2S x0 = fp2_store(fp2_mul_fp(fp2_mul(num, fp2_conj(den)), fp_store(fp_mul(nden2, binv))));
+    const Fp2S gx0 = fp2_store(fp2_mul_fp(fp2_mul(U, fp2_conj(V)), binv));
+    const Fp2S x1 = fp2_store(fp2_mul(nqr_tsq, x0));
+    const Fp2S t6 = fp2_store(fp2_sqr(fp2_mul(tsq, t)));
+    Fp2S nqr3 = fp2_store(fp2_mul_nr(fp2_mul_nr(nqr)));                    // nqr^3
+    const Fp2S gx1 = fp2_store(fp2_mul(fp2_mul(nqr3, t6), gx0));          // g2.go:1005-1010
+    const FpS nt = fp_store(fp_add(fp_sqr(t.c0), fp_sqr(t.c1)));
+    const FpS s1 = fp_store(fp_mul(fp_mul(fp_mul(fp_sqr(nt), nt), s0), C_SQRT_M8));   // N(gx1) = 8 N(t)^6 N(gx0) = s1^2
+    const Fp2S x = fp2_select(m0, x0, x1);
+    const Fp2S g = fp2_select(m0, gx0, gx1);
+    Fp2S y = fp2_sqrt_from_norm_root(g, fp_select(m0, s0, s1));
+    const i32 flip = fp2_sign_is_neg(t) ^ fp2_sign_is_neg(y);             // signT != signY (g2.go:983-988, 1021-1026)
+    y = fp2_select(flip, fp2_store(fp2_neg(y)), y);
+    out.x = x; out.y = y; out.inf = 0;
+    const i32 special = fp_is_zero(aa) ? -1 : 0;
+    if (__any(special != 0)) {
+        G2Aff r; swu_g2_helper_ref(r, t);
+        out.x = fp2_select(special, r.x, out.x); out.y = fp2_select(special, r.y, out.y);
+    }
 }
 template <int N>
 BLSMI_DEV Fp2S horner_fp2(const Fp2S (&c)[N], const Fp2S& x) {

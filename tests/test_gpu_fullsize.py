@@ -45,7 +45,8 @@ def to_int_sum(raw):
 def test_config3_msm_1m_points(eng):
     n = 1 << 20
     k = scalars(n, 3)
-    for gen, mul, summ, ref_mul, pb in [(RC.g1_generator(), eng.g1_mul_batch, eng.g1_sum, RC.g1_mul, 96), (RC.g2_generator(), eng.g2_mul_batch, eng.g2_sum, RC.g2_mul, 192)]:
+    for gen, mul, summ, msm, ref_mul, pb in [(RC.g1_generator(), eng.g1_mul_batch, eng.g1_sum, eng.g1_msm, RC.g1_mul, 96),
+                                              (RC.g2_generator(), eng.g2_mul_batch, eng.g2_sum, eng.g2_msm, RC.g2_mul, 192)]:
         # base points: 4096 distinct multiples of the generator, tiled; scalars all distinct
         base = 4096
         bk = scalars(base, 33)
@@ -64,6 +65,8 @@ def test_config3_msm_1m_points(eng):
         for j in range(base):
             acc = (acc + bints[j] * to_int_sum(kk[:, j, :])) % R
         assert total == ref_mul(gen, acc.to_bytes(32, "big"))
+        # (3) the one-pass multi-scalar multiplication entry point (multiples never leave the device) gives the same point
+        assert msm(pts.reshape(-1), k.reshape(-1), n) == total
 
 
 def _distinct_msgs(n):
