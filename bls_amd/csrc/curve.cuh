@@ -110,6 +110,7 @@ template <class F> __device__ __noinline__ Aff<F> jac_to_affine(const Jac<F>& g)
     a.inf = g.inf;
     return a;
 }
+template <class F> BLSMI_DEV Jac<F> jac_neg(const Jac<F>& a) { Jac<F> r; r.x = a.x; r.y = f_store(f_neg(a.y)); r.z = a.z; r.inf = a.inf; return r; }
 template <class F> BLSMI_DEV Aff<F> aff_neg(const Aff<F>& a) { Aff<F> r; r.x = a.x; r.y = f_store(f_neg(a.y)); r.inf = a.inf; return r; }
 
 // MSB-first double-and-add over a 256-bit scalar held as 8 little-endian u32 words per lane
@@ -131,6 +132,15 @@ template <class F> BLSMI_DEV Jac<F> aff_mul_u64_public(const Aff<F>& p, u64 k) {
     for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
         res = jac_double(res);
         if ((k >> i) & 1) res = jac_add_affine(res, p);
+    }
+    return res;
+}
+// the same for a Jacobian base point (general additions; g2.go:609-619)
+template <class F> BLSMI_DEV Jac<F> jac_mul_u64_public(const Jac<F>& p, u64 k) {
+    Jac<F> res = p;
+    for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
+        res = jac_double(res);
+        if ((k >> i) & 1) res = jac_add(res, p);
     }
     return res;
 }

@@ -192,6 +192,30 @@ BLSMI_DEV FpS horner_fp(const FpS (&c)[N], const FpS& x) {
     for (int i = N - 2; i >= 0; i--) v = fp_store(fp_add(fp_mul(v, x), c[i]));
     return v;
 }
+// The isogeny evaluated on a Jacobian point without inversions.  With x = X/W, W = Z^2, every polynomial is
+// homogenised (P_h = sum c_i X^i W^(d-i) = p(x) W^d); deg xnum = deg xden + 1 and deg ynum = deg yden, so
+//   x' = XN / (W XD),  y' = Y YN / (Z^3 YD)   and   (X', Y', Z') = (XN XD YD^2,  Y YN XD^3 YD^2,  Z XD YD).
+// Same point as iso11/iso3 of the affine image (hash.go:185-206, 282-303), minus two inversions per hash.
+template <class F, int NXN, int NXD, int NYN, int NYD>
+__device__ __noinline__ void iso_jac(Jac<F>& out, const Jac<F>& p, const F (&xn)[NXN], const F (&xd)[NXD], const F (&yn)[NYN], const F (&yd)[NYD]) {
+    static_assert(NXD == NXN - 1 && NYD == NYN && NXN <= NYN, "degree pattern of the 11- and 3-isogeny maps");
+    constexpr int D = NYN - 1;
+    F wp[D + 1];
+    wp[1] = f_store(f_sqr(p.z));
+    for (int i = 2; i <= D; i++) wp[i] = f_store(f_mul(wp[i - 1], wp[1]));
+    auto hom = [&](const F* c, int d) {
+        F v = c[d];
+        for (int i = d - 1; i >= 0; i--) v = f_store(f_add(f_mul(v, p.x), f_mul(c[i], wp[d - i])));
+        return v;
+    };
+    const F XN = hom(xn, NXN - 1), XD = hom(xd, NXD - 1), YN = hom(yn, NYN - 1), YD = hom(yd, NYD - 1);
+    const F xdyd = f_store(f_mul(XD, YD));
+    const F yd2 = f_store(f_sqr(YD)), xd2 = f_store(f_sqr(XD));
+    out.z = f_store(f_mul(p.z, xdyd));
+    out.x = f_store(f_mul(f_mul(XN, XD), yd2));
+    out.y = f_store(f_mul(f_mul(f_mul(p.y, YN), f_mul(xd2, XD)), yd2));
+    out.inf = p.inf | (f_is_zero(out.z) ? -1 : 0);
+}
 // hash.go:185-206
 __device__ __noinline__ void iso11(G1Aff& out, const G1Aff& p) {
     const FpS xn = horner_fp(C_XNUM11, p.x), xd = horner_fp(C_XDEN11, p.x), yn = horner_fp(C_YNUM11, p.x), yd = horner_fp(C_YDEN11, p.x);
@@ -201,13 +225,21 @@ __device__ __noinline__ void iso11(G1Aff& out, const G1Aff& p) {
     out.inf = 0;
 }
 // hash.go:306-321: add the two mapped points, apply the isogeny, clear the cofactor by (|x| + 1)
+// The sum stays in Jacobian coordinates through the isogeny and the cofactor multiplication: one inversion (the final
+// ToAffine) instead of three.  A sum at infinity (p2 = -p1) follows the reference's affine steps literally.
 __device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2) {
-    G1Aff p1, p2, s;
+    G1Aff p1, p2;
     swu_g1_helper(p1, t1);
     swu_g1_helper(p2, t2);
-    s = jac_to_affine(jac_add_affine(to_jac(p1), p2));
-    iso11(p1, s);
-    out = jac_to_affine(jac_add_affine(aff_mul_u64_public(p1, BLSMI_X_ABS), p1));
+    const G1Jac sj = jac_add_affine(to_jac(p1), p2);
+    G1Jac ij; iso_jac(ij, sj, C_XNUM11, C_XDEN11, C_YNUM11, C_YDEN11);
+    out = jac_to_affine(jac_add(jac_mul_u64_public(ij, BLSMI_X_ABS), ij));
+    if (__any(sj.inf != 0)) {
+        G1Aff s = jac_to_affine(sj), q, r;
+        iso11(q, s);
+        r = jac_to_affine(jac_add_affine(aff_mul_u64_public(q, BLSMI_X_ABS), q));
+        out.x = fp_select(sj.inf, r.x, out.x); out.y = fp_select(sj.inf, r.y, out.y); out.inf = (sj.inf & r.inf) | (~sj.inf & out.inf);
+    }
 }
 // hash.go:326-331
 __device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len) {
@@ -321,15 +353,6 @@ __device__ __noinline__ void psi(G2Aff& out, const G2Aff& g) {
     out.y = fp2_store(fp2_mul_nr(q2));
     out.inf = g.inf;
 }
-// G2Projective.Mul by |x| (g2.go:609-619): double-and-add with the general addition
-BLSMI_DEV G2Jac jac_mul_u64_public(const G2Jac& p, u64 k) {
-    G2Jac res = p;
-    for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
-        res = jac_double(res);
-        if ((k >> i) & 1) res = jac_add(res, p);
-    }
-    return res;
-}
 // hash.go:368-389
 __device__ __noinline__ void clear_h2(G2Aff& out, const G2Aff& p) {
     G2Jac work = aff_mul_u64_public(p, BLSMI_X_ABS);
@@ -344,6 +367,28 @@ __device__ __noinline__ void clear_h2(G2Aff& out, const G2Aff& p) {
     work = jac_add_affine(work, p2);
     out = jac_to_affine(work);
 }
+// psi on Jacobian coordinates: (X, Y, Z) -> (Cx conj(X), Cy conj(Y), conj(Z)) with Cx = (1+u) kQiX conj(iwsc),
+// Cy = (1+u)^2 kQiY conj(iwsc) -- the affine psi above is (x, y) -> (Cx conj(x), Cy conj(y)).
+BLSMI_DEV G2Jac psi_jac(const G2Jac& g) {
+    G2Jac r;
+    r.x = fp2_store(fp2_mul(C_PSI_CX, fp2_conj(g.x)));
+    r.y = fp2_store(fp2_mul(C_PSI_CY, fp2_conj(g.y)));
+    r.z = fp2_store(fp2_conj(g.z));
+    r.inf = g.inf;
+    return r;
+}
+// clearH2 (hash.go:368-389) on a Jacobian input: the same chain with general additions, no intermediate ToAffine
+__device__ __noinline__ void clear_h2_jac(G2Aff& out, const G2Jac& p) {
+    G2Jac work = jac_mul_u64_public(p, BLSMI_X_ABS);
+    work = jac_add(work, p);
+    const G2Jac mpsi = jac_neg(psi_jac(p));
+    work = jac_add(work, mpsi);
+    work = jac_mul_u64_public(work, BLSMI_X_ABS);
+    work = jac_add(work, mpsi);
+    work = jac_add(work, jac_neg(p));
+    work = jac_add(work, psi_jac(psi_jac(jac_double(p))));
+    out = jac_to_affine(work);
+}
 // hash.go:391-411
 __device__ __noinline__ void hash_g2(G2Aff& out, const u8* msg, size_t len) {
     u32 d[8];
@@ -352,9 +397,16 @@ __device__ __noinline__ void hash_g2(G2Aff& out, const u8* msg, size_t len) {
     G2Aff p1, p2, s;
     swu_g2_helper(p1, t1);
     swu_g2_helper(p2, t2);
-    s = jac_to_affine(jac_add_affine(to_jac(p1), p2));
-    iso3(p1, s);
-    clear_h2(out, p1);
+    const G2Jac sj = jac_add_affine(to_jac(p1), p2);                      // stays Jacobian through iso3 and clearH2
+    G2Jac ij; iso_jac(ij, sj, C_XNUM3, C_XDEN3, C_YNUM3, C_YDEN3);
+    clear_h2_jac(out, ij);
+    if (__any(sj.inf != 0)) {                                              // p2 = -p1: the reference's affine steps, literally
+        G2Aff r;
+        s = jac_to_affine(sj);
+        iso3(p1, s);
+        clear_h2(r, p1);
+        out.x = fp2_select(sj.inf, r.x, out.x); out.y = fp2_select(sj.inf, r.y, out.y); out.inf = (sj.inf & r.inf) | (~sj.inf & out.inf);
+    }
 }
 
 // g2.go:1041-1085: try-and-increment on x0 = (H(m||d||01), H(m||d||02)); favour the y with Parity(),
