@@ -9,6 +9,7 @@
 #include "hash.cuh"
 #include <mutex>
 #include <condition_variable>
+#include <chrono>
 #include <vector>
 #include <algorithm>
 #include <cstring>

@@ -393,3 +393,38 @@ def test_rccl_collectives_world1(eng):
         assert bdist.sharded_verify_aggregate("g2pubs", amsgs, b"".join(apks[::-1]), agg, 0, 1, gather) is False
     finally:
         dist.destroy_process_group()
+
+
+def test_concurrent_single_tuple_calls_are_combined(eng):
+    """The Go API verifies one tuple per call; concurrent callers are merged into shared batch launches by the
+    library (verify_host.inc, request combining).  Every caller must still get exactly its own verdicts."""
+    import threading
+    msgs, pks, sigs, expect = _tuples("g2pubs", 48, 41)
+    m1, p1, s1, e1 = _tuples("g1pubs", 16, 42)
+    results = {}
+
+    def run(idx):
+        try:
+            out = []
+            if idx < 48:
+                for rep in range(3):
+                    ok, bitmap = eng.g2pubs_verify_batch([msgs[idx]], pks[idx], sigs[idx])
+                    out.append(bool(ok[0]) == expect[idx] and bool(bitmap[0] & 1) == expect[idx])
+                j = (idx * 7) % 46                                                   # a 3-tuple request in the same queue
+                ok, _ = eng.g2pubs_verify_batch(msgs[j:j + 3], b"".join(pks[j:j + 3]), b"".join(sigs[j:j + 3]))
+                out.append(list(ok) == expect[j:j + 3])
+            else:
+                k = idx - 48
+                for rep in range(3):
+                    ok, _ = eng.g1pubs_verify_batch([m1[k]], p1[k], s1[k])
+                    out.append(bool(ok[0]) == e1[k])
+            results[idx] = all(out)
+        except Exception as e:  # noqa: BLE001
+            results[idx] = e
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(64)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(results.get(i) is True for i in range(64)), {i: r for i, r in results.items() if r is not True}
