@@ -428,3 +428,26 @@ def test_concurrent_single_tuple_calls_are_combined(eng):
     for t in threads:
         t.join()
     assert all(results.get(i) is True for i in range(64)), {i: r for i, r in results.items() if r is not True}
+
+
+def test_lifecycle_and_argument_errors(eng):
+    """blsmi_shutdown / re-init keeps working (contexts, generator tables and pools are rebuilt), bad arguments are
+    reported as error codes, never crashes."""
+    import ctypes as C
+    from bls_amd import _native
+    lib = _native.load()
+    msgs, pks, sigs, expect = _tuples("g2pubs", 5, 51)
+    ok, _ = eng.g2pubs_verify_batch(msgs, b"".join(pks), b"".join(sigs))
+    assert list(ok) == expect
+    lib.blsmi_shutdown()
+    lib.blsmi_shutdown()                                                   # idempotent
+    ok, _ = eng.g2pubs_verify_batch(msgs, b"".join(pks), b"".join(sigs))   # lazily re-initialises
+    assert list(ok) == expect
+    assert lib.blsmi_init(0) == 0
+    assert lib.blsmi_init(99) != 0                                         # another device than the one in use
+    out = (C.c_uint64 * 72)()
+    assert lib.blsmi_pairing_batch(None, None, out, C.c_size_t(1)) != 0    # NULL inputs with n > 0
+    assert lib.blsmi_pairing_batch(None, None, None, C.c_size_t(0)) == 0   # empty batch is fine
+    okb = (C.c_uint8 * 1)()
+    assert lib.blsmi_g2pubs_verify_batch(None, None, None, None, None, okb, None, C.c_size_t(1)) != 0
+    assert lib.blsmi_last_kernel_ms(None, None) != 0
