@@ -201,6 +201,20 @@ def g1pubs_verify_batch(msgs, pks, sigs, inf_flags=None):
     return _verify_batch(_lib().blsmi_g1pubs_verify_batch, 96, 192, msgs, pks, sigs, inf_flags)
 
 
+def verify_serialized_batch(group, msgs, pks, sigs, check_subgroup=True):
+    """Deserialize + Verify in one device pass: compressed keys / signatures as Serialize() emits them.
+    Returns (ok, err_pk, err_sig); err_* are the per-element deserialisation error codes (0 = fine)."""
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    pkc, sgc = (96, 48) if group == "g2pubs" else (48, 96)
+    p = _u8(pks, pkc * n) if n else np.zeros(1, np.uint8)
+    s = _u8(sigs, sgc * n) if n else np.zeros(1, np.uint8)
+    ok = np.zeros(n, dtype=np.uint8); ep = np.zeros(n, dtype=np.uint8); es = np.zeros(n, dtype=np.uint8)
+    fn = _lib().blsmi_g2pubs_verify_serialized_batch if group == "g2pubs" else _lib().blsmi_g1pubs_verify_serialized_batch
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), _p8(p), _p8(s), C.c_int(1 if check_subgroup else 0), _p8(ok), _p8(ep), _p8(es), C.c_size_t(n)), "verify_serialized_batch")
+    return ok.astype(bool), ep, es
+
+
 def g1pubs_verify_with_domain_batch(msgs32, domain8, pks, sigs, inf_flags=None):
     n = len(msgs32)
     buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n)

@@ -100,6 +100,14 @@ def VerifyBatch(msgs, pubs, sigs):
     return [bool(x) for x in ok]
 
 
+def VerifySerializedBatch(msgs, pub_bytes, sig_bytes):
+    """DeserializePublicKey + DeserializeSignature + Verify per tuple, in one device pass over the 48-byte keys and
+    96-byte signatures of the wire format.  A tuple whose key or signature does not deserialise (the reference returns
+    an error there and Verify is never reached) or is the point at infinity yields False."""
+    ok, _, _ = engine.verify_serialized_batch(__name__.rsplit(".", 1)[-1], msgs, b"".join(pub_bytes), b"".join(sig_bytes), True)
+    return [bool(x) for x in ok]
+
+
 def Verify(m, pub, sig):
     return VerifyBatch([m], [pub], [sig])[0]
 

@@ -116,6 +116,16 @@ int blsmi_fq12_product(const uint64_t *in_fq12 /* n*72 */, size_t n, uint64_t *o
 int blsmi_g2pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
 int blsmi_g1pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
 
+/* ---- Deserialize + Verify in one pass: keys and signatures in the compressed wire format (what
+ * PublicKey.Serialize / Signature.Serialize produce, g2pubs/bls.go:18-20, 67-69): g2pubs pk 96 B + sig 48 B,
+ * g1pubs pk 48 B + sig 96 B.  check_subgroup != 0 applies the subgroup test of DeserializePublicKey /
+ * DeserializeSignature.  ok[i] = 0 when either element fails to deserialise or is the point at infinity;
+ * err_pk / err_sig (n bytes each, may be NULL) receive the error codes of blsmi_g*_decompress_batch. */
+int blsmi_g2pubs_verify_serialized_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, const uint8_t *pks /* n*96 */, const uint8_t *sigs /* n*48 */,
+                                         int check_subgroup, uint8_t *ok /* n */, uint8_t *err_pk, uint8_t *err_sig, size_t n);
+int blsmi_g1pubs_verify_serialized_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, const uint8_t *pks /* n*48 */, const uint8_t *sigs /* n*96 */,
+                                         int check_subgroup, uint8_t *ok /* n */, uint8_t *err_pk, uint8_t *err_sig, size_t n);
+
 /* ---- wire format (CompressG1/G2, DecompressG1/G2 incl. subgroup check; g1.go:185-249, g2.go:219-295)
  * err[i]: 0 ok, 1 unexpected compression mode, 2 bad infinity encoding, 3 not on curve, 4 not in subgroup */
 int blsmi_g1_decompress_batch(const uint8_t *in /* n*48 */, int check_subgroup, uint8_t *out /* n*96 */, uint8_t *out_inf, uint8_t *err, size_t n);

@@ -451,3 +451,31 @@ def test_lifecycle_and_argument_errors(eng):
     okb = (C.c_uint8 * 1)()
     assert lib.blsmi_g2pubs_verify_batch(None, None, None, None, None, okb, None, C.c_size_t(1)) != 0
     assert lib.blsmi_last_kernel_ms(None, None) != 0
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_verify_serialized_batch(eng, group, kats):
+    """Deserialize + Verify in one pass over the compressed wire format equals deserialising with the oracle and
+    verifying; malformed / off-curve / infinity encodings give verdict False with the right error code."""
+    import bls_amd.g1pubs as g1p
+    import bls_amd.g2pubs as g2p
+    mod = g2p if group == "g2pubs" else g1p
+    msgs, pks, sigs, expect = _tuples(group, 37, 61)
+    cpk = RC.g2_compress if group == "g2pubs" else RC.g1_compress
+    csg = RC.g1_compress if group == "g2pubs" else RC.g2_compress
+    pkc = [cpk(p) for p in pks]; sgc = [csg(s) for s in sigs]
+    assert mod.VerifySerializedBatch(msgs, pkc, sgc) == expect
+    # damage some encodings: cleared compression bit, infinity, x not on the curve (the reference's rejected vectors)
+    bad_pk = bytes.fromhex(kats["invalid_pubkey_g2pubs_hex" if group == "g2pubs" else "invalid_pubkey_g1pubs_hex"])
+    pkc2 = list(pkc); sgc2 = list(sgc); exp2 = list(expect)
+    pkc2[0] = bad_pk; exp2[0] = False
+    b = bytearray(sgc2[1]); b[0] &= 0x7f; sgc2[1] = bytes(b); exp2[1] = False
+    pkc2[2] = cpk(None); exp2[2] = False
+    sgc2[4] = csg(None); exp2[4] = False
+    ok, ep, es = eng.verify_serialized_batch(group, msgs, b"".join(pkc2), b"".join(sgc2))
+    assert list(ok) == exp2
+    dpk = RC.g2_decompress if group == "g2pubs" else RC.g1_decompress
+    dsg = RC.g1_decompress if group == "g2pubs" else RC.g2_decompress
+    assert [int(e) for e in ep] == [dpk(c)[0] for c in pkc2]
+    assert [int(e) for e in es] == [dsg(c)[0] for c in sgc2]
+    assert ep[0] != 0 and es[1] != 0 and ep[2] == 0 and es[4] == 0      # infinity deserialises, but cannot be verified
