@@ -127,7 +127,8 @@ int blsmi_g1pubs_verify_serialized_batch(const uint8_t *msgs, const uint64_t *of
                                          int check_subgroup, uint8_t *ok /* n */, uint8_t *err_pk, uint8_t *err_sig, size_t n);
 
 /* ---- wire format (CompressG1/G2, DecompressG1/G2 incl. subgroup check; g1.go:185-249, g2.go:219-295)
- * err[i]: 0 ok, 1 unexpected compression mode, 2 bad infinity encoding, 3 not on curve, 4 not in subgroup */
+ * err[i]: 0 ok, 1 unexpected compression mode, 2 bad infinity encoding, 3 not on curve, 4 not in subgroup  * check_subgroup: 0 = none, 1 = the subgroup test through the curve endomorphisms (the same predicate as the
+ * reference's r*P == infinity for every point on the curve, 4x cheaper), 2 = the r*P form itself. */
 int blsmi_g1_decompress_batch(const uint8_t *in /* n*48 */, int check_subgroup, uint8_t *out /* n*96 */, uint8_t *out_inf, uint8_t *err, size_t n);
 int blsmi_g2_decompress_batch(const uint8_t *in /* n*96 */, int check_subgroup, uint8_t *out /* n*192 */, uint8_t *out_inf, uint8_t *err, size_t n);
 int blsmi_g1_compress_batch(const uint8_t *pts, const uint8_t *in_inf, uint8_t *out /* n*48 */, size_t n);

@@ -313,6 +313,31 @@ def test_wire_format(eng, kats):
     _, _, e_on = eng.g1_decompress_batch(comp, 1, True)
     _, _, e_off = eng.g1_decompress_batch(comp, 1, False)
     assert int(e_on[0]) == 4 and int(e_off[0]) == 0
+    # the endomorphism form of the subgroup test (check = 1) and the reference's r * P form (check = 2) agree on curve
+    # points outside the subgroup (small x) and inside it, for both groups; the oracle agrees on a sample
+    outs1, outs2 = [], []
+    for x in range(60):
+        pt = P.g1_from_x(x, bool(x & 1))
+        if pt is not None:
+            outs1.append((P.g1_compress(pt), P.g1_in_subgroup(pt)))
+    for x0 in range(8):
+        for x1 in range(8):
+            pt = P.g2_from_x((x0, x1), bool(x0 & 1))
+            if pt is not None:
+                outs2.append((P.g2_compress(pt), None))
+    assert len(outs1) > 15 and len(outs2) > 15
+    for dec, cases, extra in ((eng.g1_decompress_batch, outs1, c1), (eng.g2_decompress_batch, outs2, c2)):
+        blob = b"".join(c for c, _ in cases) + extra.tobytes()
+        m = len(cases) + n
+        _, _, e1 = dec(blob, m, 1)
+        _, _, e2 = dec(blob, m, 2)
+        assert [int(v) for v in e1] == [int(v) for v in e2]
+        assert all(int(v) == 0 for v in e1[len(cases):])                   # genuine subgroup points pass
+        assert sum(int(v) == 4 for v in e1[:len(cases)]) >= len(cases) - 2  # small-x points are (almost) never in the subgroup
+        for k, (c, insub) in enumerate(cases):
+            if insub is not None:
+                assert (int(e1[k]) == 0) == insub
+    assert P.g2_in_subgroup(P.g2_from_x((0, 1), False)) == (int(eng.g2_decompress_batch(P.g2_compress(P.g2_from_x((0, 1), False)), 1, 1)[2][0]) == 0) if P.g2_from_x((0, 1), False) is not None else True
     from bls_amd import g2pubs
     with pytest.raises(g2pubs.DeserializeError):
         g2pubs.DeserializePublicKey(bad2)
