@@ -428,21 +428,29 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
     for (int j = 0; j < 8; j++) { wre[j] = dre[7 - j]; wim[j] = dim[7 - j]; }
     for (int j = 8; j < 12; j++) { wre[j] = 0; wim[j] = 0; }
     Fp2S x0; x0.c0 = fp_from_words(wre); x0.c1 = fp_from_words(wim);
+    // The loop only has to DECIDE whether x0^3 + b is a square -- one Fq exponentiation on its norm; the root itself
+    // (a second exponentiation) is taken once, after the loop, for the x0 each lane settled on.  The wave iterates until
+    // its slowest lane is done (about log2(64) + 1 rounds), so halving the cost of a round matters.
     G2Aff pt; pt.x = x0; pt.y = fp2_one(); pt.inf = 0;
+    Fp2S gsel = fp2_zero(); FpS ssel = fp_zero();
     i32 done = 0;
     while (true) {
         const Fp2S gx = fp2_store(fp2_add(fp2_mul(fp2_sqr(x0), x0), C_B2));
-        bool ok;
-        Fp2S y = fp2_sqrt_any(gx, ok);                                     // sign fixed below
+        bool ok; FpS nrm;
+        const FpS s = fp2_norm_root(gx, nrm, ok);
         const i32 take = (ok ? -1 : 0) & ~done;
-        // favour y with Parity() == true (g2.go:1074-1077): parity(y) <=> y > -y (fq2.go:256-260)
-        const i32 y_gt = fp2_sign_is_neg(y);                               // y > (q-1)/2 lexicographically (c1 first) <=> y > -y
-        y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
         pt.x = fp2_select(take, x0, pt.x);
-        pt.y = fp2_select(take, y, pt.y);
+        gsel = fp2_select(take, gx, gsel);
+        ssel = fp_select(take, s, ssel);
         done |= take;
         if (__all(done != 0)) break;
         x0 = fp2_store(fp2_add(x0, fp2_one()));
+    }
+    {
+        Fp2S y = fp2_sqrt_from_norm_root(gsel, ssel);                      // either root: the choice follows
+        // favour y with Parity() == true (g2.go:1074-1077): parity(y) <=> y > -y (fq2.go:256-260)
+        const i32 y_gt = fp2_sign_is_neg(y);                               // y > (q-1)/2 lexicographically (c1 first) <=> y > -y
+        pt.y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
     }
     // ScaleByCofactor multiplies by the 507-bit cofactor h2 with a bit-serial double-and-add (g2.go:104-115, 130-138).
     // Same point, shorter road: clearH2(P) = [3 (x^2 - 1) h2] P on all of E'(Fq2), it lands in G2 where psi acts as x,
