@@ -457,7 +457,7 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
     // so [h2] P = [c] clearH2(P) with c = (3 (x^2 - 1))^-1 mod r = sum d_i |x|^i, i.e. sum (-1)^i d_i psi^i(clearH2(P)):
     // two 64-bit multiplications inside clearH2 plus one 64-step joint ladder instead of 506 doublings + ~250 additions.
     G2Aff q[4];
-    clear_h2(q[0], pt);
+    clear_h2_jac(q[0], to_jac(pt));                                       // same point as clearH2(pt), one inversion instead of two
     psi(q[1], q[0]); psi(q[2], q[1]); psi(q[3], q[2]);
     q[1] = aff_neg(q[1]); q[3] = aff_neg(q[3]);
     G2Jac res = jac_zero<Fp2S>();
