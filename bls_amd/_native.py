@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 _SOURCES = ["blsmi.hip", "fp.cuh", "tower_fwd.cuh", "tower.cuh", "fp2_single.inc", "fp2_pair.inc", "tower_body.inc", "pairing_body.inc", "pair_kernels.inc", "curve.cuh", "pairing.cuh", "hash.cuh", "consts.cuh",
-            "verify_kernels.inc", "verify_host.inc"]
+            "verify_kernels.inc", "verify_host.inc", "msm.inc"]
 
 
 def _stale():

@@ -383,6 +383,7 @@ __device__ void sum_final_body(const i32* src, u8* out, i32* out_inf) {
 KERNEL2 k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<FpS, 96>(src, out, out_inf); }
 KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
 
+#include "msm.inc"
 #include "verify_kernels.inc"
 #include "pair_kernels.inc"
 
@@ -707,19 +708,75 @@ static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* 
 BLSMI_API int blsmi_g1_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[96], int* out_inf) { return sum_host<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, in_inf, n, out, out_inf); }
 BLSMI_API int blsmi_g2_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[192], int* out_inf) { return sum_host<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, in_inf, n, out, out_inf); }
 
-// multi-scalar multiplication sum_i k_i * P_i: the windowed multiples stay on the device and feed the tree sum
+// multi-scalar multiplication sum_i k_i * P_i.  Small batches: per-point windowed multiples feed the tree sum on the
+// device (one launch of latency, ~6 ms up to 64k points).  From BLSMI_MSM_BUCKET_MIN points (default 2^17, where the
+// two cross over) on: the bucket method of msm.inc, whose fixed tail (chunk reduction + 240 serial doublings) is ~6 ms.
+constexpr int BLSMI_E_SKEW = -1000;    // internal: bucket method declined (unbalanced digits)
+struct MsmKernels {
+    void (*bucket)(const u8*, const u32*, const u32*, const u32*, i32*, size_t, int, size_t);
+    void (*chunk)(const i32*, i32*, int, int, size_t, size_t);
+    void (*fold)(const i32*, i32*, size_t, size_t, int);
+    void (*final)(const i32*, int, int, u8*, i32*);
+};
+template <int PB, int W>
+static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s) {
+    // 16-bit windows: n / 2^16 points per bucket, and a 255-bit scalar still fills 15 bits of the top window (a window
+    // size that leaves the top window a few bits wide would pile every point into a handful of buckets there)
+    const int c = 16;
+    const int K = 64;                                                      // buckets per chunk lane
+    const int nwin = (256 + c - 1) / c;
+    const size_t B1 = (size_t)1 << c, nb = B1 * nwin, per_win = B1 / K, nct = per_win * nwin;
+    const size_t jw = (size_t)W * NL + 1;                                  // words of one Jacobian SoA record
+    DBuf hist, offs, cursor, idx, buckets, ch0, ch1, dmax;
+    HIPCHK(hist.alloc(sizeof(u32) * nb)); HIPCHK(offs.alloc(sizeof(u32) * nb)); HIPCHK(cursor.alloc(sizeof(u32) * nb)); HIPCHK(dmax.alloc(sizeof(u32)));
+    HIPCHK(idx.alloc(sizeof(u32) * n * nwin)); HIPCHK(buckets.alloc(sizeof(i32) * jw * nb));
+    HIPCHK(ch0.alloc(sizeof(i32) * jw * nct)); HIPCHK(ch1.alloc(sizeof(i32) * jw * ((per_win + 1) / 2) * nwin));
+    HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
+    HIPCHK(hipMemsetAsync(dmax.p, 0, sizeof(u32), s));
+    hipLaunchKernelGGL(k_msm_hist, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, n, c, nwin, hist.as<u32>());
+    // Skewed scalars (many equal digits) would leave one lane adding a whole bucket by itself: beyond 2048 points in
+    // any bucket the caller falls back to the per-point multiples, whose cost does not depend on the scalars.
+    hipLaunchKernelGGL(k_msm_max, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, dmax.as<u32>());
+    u32 biggest = 0;
+    HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (biggest > 2048) return BLSMI_E_SKEW;
+    hipLaunchKernelGGL(k_msm_scan, dim3(nwin), dim3(256), 0, s, (const u32*)hist.as<u32>(), offs.as<u32>(), cursor.as<u32>(), c);
+    hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, n, c, nwin, cursor.as<u32>(), idx.as<u32>());
+    hipLaunchKernelGGL(k.bucket, dim3(nblocks(nb)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), buckets.as<i32>(), n, c, nb);
+    hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
+    size_t seg = per_win;
+    while (seg > 1) {
+        const size_t half = (seg + 1) / 2;
+        hipLaunchKernelGGL(k.fold, dim3(nblocks(half * nwin)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nwin);
+        std::swap(src, dst);
+        seg = half;
+    }
+    hipLaunchKernelGGL(k.final, dim3(1), dim3(WG), 0, s, (const i32*)src, nwin, c, d_out, d_flag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));                                       // temporaries die with this scope
+    return BLSMI_OK;
+}
 template <int PB, int W, class KM, class K0, class K1, class K2>
-static int msm_host(KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int* out_inf) {
+static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int* out_inf) {
     if (!out || !out_inf || (n && (!pts || !scalars))) return BLSMI_E_ARG;
     if (n == 0) { memset(out, 0, PB); *out_inf = 1; return BLSMI_OK; }
     LOCK_AND_INIT();
-    DBuf dp, ds, dm, dinf, dout, dflag;
-    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dm.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
-    HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
+    static const size_t bucket_min = []{ const char* v = getenv("BLSMI_MSM_BUCKET_MIN"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1 << 17; }();
+    DBuf dp, ds, dout, dflag;
+    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
     HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    hipLaunchKernelGGL(kmul, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), (size_t)PB, ds.as<u8>(), dm.as<u8>(), dinf.as<u8>(), n);
-    int rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    int rc;
+    rc = BLSMI_E_SKEW;
+    if (n >= bucket_min) rc = msm_bucket_dev<PB, W>(mk, dp.as<u8>(), ds.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    if (rc == BLSMI_E_SKEW) {
+        DBuf dm, dinf;
+        HIPCHK(dm.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
+        hipLaunchKernelGGL(kmul, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), (size_t)PB, ds.as<u8>(), dm.as<u8>(), dinf.as<u8>(), n);
+        rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    }
     if (rc) return rc;
     i32 flag = 0;
     HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream));
@@ -728,8 +785,14 @@ static int msm_host(KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const 
     *out_inf = flag;
     return BLSMI_OK;
 }
-BLSMI_API int blsmi_g1_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[96], int* out_inf) { return msm_host<96, 3>(k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, scalars, n, out, out_inf); }
-BLSMI_API int blsmi_g2_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[192], int* out_inf) { return msm_host<192, 6>(k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, scalars, n, out, out_inf); }
+BLSMI_API int blsmi_g1_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[96], int* out_inf) {
+    static const MsmKernels mk{k_g1_msm_bucket, k_g1_msm_chunk, k_g1_msm_fold, k_g1_msm_final};
+    return msm_host<96, 3>(mk, k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, scalars, n, out, out_inf);
+}
+BLSMI_API int blsmi_g2_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[192], int* out_inf) {
+    static const MsmKernels mk{k_g2_msm_bucket, k_g2_msm_chunk, k_g2_msm_fold, k_g2_msm_final};
+    return msm_host<192, 6>(mk, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, scalars, n, out, out_inf);
+}
 
 #include "verify_host.inc"
 

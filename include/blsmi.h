@@ -71,8 +71,9 @@ int blsmi_g2_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out
  * after ToAffine).  *out_inf = 1 for the point at infinity. */
 int blsmi_g1_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t out[96], int *out_inf);
 int blsmi_g2_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t out[192], int *out_inf);
-/* multi-scalar multiplication sum_i k_i * P_i (BASELINE config 3: fixed-window multiples + tree sum, one
- * device pass; equals summing the reference's MulFR results with AddAssign, compared after ToAffine) */
+/* multi-scalar multiplication sum_i k_i * P_i (BASELINE config 3; equals summing the reference's MulFR results with
+ * AddAssign, compared after ToAffine).  Below 2^17 points: fixed-window multiples + tree sum in one device pass;
+ * from there on the bucket method (16-bit windows), with a fallback to the former for degenerate scalar sets. */
 int blsmi_g1_msm(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[96], int *out_inf);
 int blsmi_g2_msm(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[192], int *out_inf);
 
