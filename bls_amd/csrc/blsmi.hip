@@ -723,7 +723,7 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     // 16-bit windows: n / 2^16 points per bucket, and a 255-bit scalar still fills 15 bits of the top window (a window
     // size that leaves the top window a few bits wide would pile every point into a handful of buckets there)
     const int c = 16;
-    const int K = 64;                                                      // buckets per chunk lane
+    const int K = 16;                                                      // buckets per chunk lane: 2^12 chunk lanes per window keep every SIMD busy
     const int nwin = (256 + c - 1) / c;
     const size_t B1 = (size_t)1 << c, nb = B1 * nwin, per_win = B1 / K, nct = per_win * nwin;
     const size_t jw = (size_t)W * NL + 1;                                  // words of one Jacobian SoA record
