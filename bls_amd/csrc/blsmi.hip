@@ -1,9 +1,11 @@
 // blsmi.hip -- kernels and the C ABI (include/blsmi.h) of libblsmi.so.
 //
-// One (message, public key, signature) / (P, Q) tuple per lane; 64-lane workgroups, one wave per
-// SIMD (the per-lane state of a pairing -- f: 180 words, R: 90, P,Q: 90 -- wants the whole 512-entry
-// register file; the measured cost of running one wave per SIMD is ~25 % on the multiply core, see
-// profiles/r01_ubench2_fmul.log).  HBM traffic is the tuple I/O only (864 B per pairing).
+// This translation unit holds the one-tuple-per-lane kernels (hash-to-curve, scalar multiplication, sums, MSM, wire
+// format, and the pairing kernels selectable with BLSMI_LAYOUT=single) and the host side; the default pairing kernels
+// (lane pair per tuple, two waves per SIMD) are in pair_kernels.inc, the verify-path kernels in verify_kernels.inc,
+// the bucket-method MSM in msm.inc, the verify-path host code in verify_host.inc.  64-lane workgroups throughout.
+// A one-tuple-per-lane pairing keeps f (180 words), R (90) and P, Q (90) per lane and wants the whole 512-entry
+// register file, i.e. one wave per SIMD; G1-side kernels fit 256 registers and run two.
 #include "../../include/blsmi.h"
 #include "pairing.cuh"
 #include "hash.cuh"
