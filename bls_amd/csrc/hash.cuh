@@ -3,9 +3,11 @@
 // (g2.go:933-1031), iso11/iso3 (hash.go:185-303), ClearH/clearH2/psi (hash.go:306-389), HashG1/HashG2
 // (hash.go:326-331, 405-411) and HashG2WithDomain (g2.go:1041-1085).
 // Data-dependent branches of the reference (is g(x0) a square? which sign?) become selects: the
-// control flow is the same for all 64 lanes.  Field divisions that the reference performs one by one
-// are merged where the quotient is the same field element (x_num/x_den and y_num/y_den share one
-// inversion): the hashed point is identical.
+// control flow is the same for all 64 lanes.  The algebra is rearranged wherever the result is the same field
+// element or group point ("Hash-to-curve and verify-path algebra"): one exponentiation serves the
+// inversion and the square root of an SWU helper, Fq2 roots come from two Fq exponentiations through the norm, the
+// isogeny and the cofactor clearing run on Jacobian coordinates (one inversion per hash), ScaleByCofactor goes
+// through clearH2 and a psi ladder.  The reference-shaped routines are kept for the inputs those identities exclude.
 #pragma once
 #include "curve.cuh"
 

@@ -1,4 +1,5 @@
-// pairing.cuh -- optimal-ate Miller loop and final exponentiation, one (P, Q) tuple per lane.
+// pairing.cuh -- optimal-ate Miller loop and final exponentiation; the body (pairing_body.inc) is instantiated
+// twice: one (P, Q) tuple per lane (namespace blsmi) and one per lane pair (namespace blsmi::pairl).
 //
 // Reference path: G2AffineToPrepared (g2.go:650-801) stores 68 line-coefficient triples per Q
 // (19.6 KB each), MillerLoop (pairing.go:16-75) replays them, FinalExponentiation
