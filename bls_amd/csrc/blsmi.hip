@@ -250,6 +250,7 @@ KERNEL k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_t n) {
         case BLSMI_OP_FQ12_FROB2: r = fp12_store(fp12_frob<2>(x)); break;
         case BLSMI_OP_FQ12_FROB3: r = fp12_store(fp12_frob<3>(x)); break;
         case BLSMI_OP_FQ12_CYCLO_SQR: r = fp12_cyclotomic_sqr(x); break;
+        case BLSMI_OP_FQ12_CYCLO_RUN16: r = cyc_sqr_run(x, 16); break;
     }
     as<Fp12S>(ro) = r;
     rec_store<12>(out, t, ro);

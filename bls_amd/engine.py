@@ -335,7 +335,7 @@ def g2_compress_batch(pts, n, in_inf=None):
 OPS = dict(FQ_MUL=1, FQ_SQR=2, FQ_ADD=3, FQ_SUB=4, FQ_NEG=5, FQ_INV=6, FQ_SQRT=7,
            FQ2_MUL=16, FQ2_SQR=17, FQ2_INV=18, FQ2_MUL_NR=19, FQ2_SQRT=20, FQ2_SQRT_ANY=21,
            FQ6_MUL=32, FQ6_SQR=33, FQ6_INV=34, FQ6_FROB1=35,
-           FQ12_MUL=48, FQ12_SQR=49, FQ12_INV=50, FQ12_FROB1=51, FQ12_FROB2=52, FQ12_FROB3=53, FQ12_CYCLO_SQR=54,
+           FQ12_MUL=48, FQ12_SQR=49, FQ12_INV=50, FQ12_FROB1=51, FQ12_FROB2=52, FQ12_FROB3=53, FQ12_CYCLO_SQR=54, FQ12_CYCLO_RUN16=55,
            G1_DOUBLE=64, G1_ADD=65, G2_DOUBLE=66, G2_ADD=67, SWU_G1=68, SWU_G2=69)
 
 

@@ -141,7 +141,7 @@ enum blsmi_debug_op {
     BLSMI_OP_FQ_MUL = 1, BLSMI_OP_FQ_SQR, BLSMI_OP_FQ_ADD, BLSMI_OP_FQ_SUB, BLSMI_OP_FQ_NEG, BLSMI_OP_FQ_INV, BLSMI_OP_FQ_SQRT,
     BLSMI_OP_FQ2_MUL = 16, BLSMI_OP_FQ2_SQR, BLSMI_OP_FQ2_INV, BLSMI_OP_FQ2_MUL_NR, BLSMI_OP_FQ2_SQRT, BLSMI_OP_FQ2_SQRT_ANY /* either root */,
     BLSMI_OP_FQ6_MUL = 32, BLSMI_OP_FQ6_SQR, BLSMI_OP_FQ6_INV, BLSMI_OP_FQ6_FROB1,
-    BLSMI_OP_FQ12_MUL = 48, BLSMI_OP_FQ12_SQR, BLSMI_OP_FQ12_INV, BLSMI_OP_FQ12_FROB1, BLSMI_OP_FQ12_FROB2, BLSMI_OP_FQ12_FROB3, BLSMI_OP_FQ12_CYCLO_SQR,
+    BLSMI_OP_FQ12_MUL = 48, BLSMI_OP_FQ12_SQR, BLSMI_OP_FQ12_INV, BLSMI_OP_FQ12_FROB1, BLSMI_OP_FQ12_FROB2, BLSMI_OP_FQ12_FROB3, BLSMI_OP_FQ12_CYCLO_SQR, BLSMI_OP_FQ12_CYCLO_RUN16 /* 16 squarings in compressed form + decompression */,
     BLSMI_OP_G1_DOUBLE = 64, BLSMI_OP_G1_ADD, BLSMI_OP_G2_DOUBLE, BLSMI_OP_G2_ADD,
     BLSMI_OP_SWU_G1 = 68 /* t in word 0 of a 3-Fq record -> (x, y, 0) */, BLSMI_OP_SWU_G2 /* t in words 0-1 of a 6-Fq record -> (x, y, 0) */
 };

@@ -136,6 +136,17 @@ def test_fq6_fq12_ops(eng):
     cyc = np.stack(cyc)
     out, _ = eng.debug_op("FQ12_CYCLO_SQR", cyc)
     assert np.array_equal(out, np.stack([RC.fq12_sqr(c) for c in cyc]))
+    # a run of 16 squarings in Karabina's compressed form (what exp_by_x uses for the long zero runs of |x|), including
+    # the unit element, whose compressed form is all zero
+    one = np.concatenate([mont(1)] + [mont(0)] * 11)
+    cyc2 = np.concatenate([cyc, one[None, :]])
+    out, _ = eng.debug_op("FQ12_CYCLO_RUN16", cyc2)
+    exp = []
+    for c in cyc2:
+        for _ in range(16):
+            c = RC.fq12_sqr(c)
+        exp.append(c)
+    assert np.array_equal(out, np.stack(exp))
 
 
 def _jac(aff_bytes, z, group):
