@@ -352,7 +352,8 @@ BLSMI_DEV FpS fp_pow_const(const Fp<L, V>& a, const u32* ebits, int nbits) {
 // Bernstein-Yang "safegcd" iteration instead (divsteps with 2x2 transition matrices, the formulation popularised by
 // libsecp256k1's modinv), laid out for the 27-bit signed limbs: every batch derives a transition matrix from the low
 // 27 bits of (f, g) with 27 branch-free divsteps, then applies it to (f, g) (exact division by 2^27) and to (d, e)
-// (division mod q).  34 batches of 27 divsteps cover the 879-divstep bound for a 381-bit modulus; control flow and
+// (division mod q).  34 batches of 27 divsteps = 918 cover the bound of 878 divsteps for a 381-bit modulus
+// (floor((45907 * 381 + 26313) / 19929), the half-delta variant started at delta = 1/2); control flow and
 // instruction stream are the same for every lane (~21 k instructions).  inverse(0) = 0, as the power gave.
 // Input: any representative; output: the Montgomery form of the inverse of the value the input stands for.
 BLSMI_DEV FpS fp_inv_fermat(const FpS& a) { return fp_pow_const(a, C_QM2, BLSMI_QM2_BITS); }
