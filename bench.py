@@ -36,10 +36,10 @@ HBM_PEAK_GBS = 8000.0              # MI355X spec (MI355X_MICROARCH.md)
 VALU_PEAK_GMULS = 61.2
 VALU_PEAK_1WAVE_GMULS = 45.6
 # HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-# (r01_rocprof_summary_h.txt: k_final_exp_pair, 65 536 tuples per launch, FETCH_SIZE 5.842e6 KB +
-# WRITE_SIZE 1.063e7 KB, separate --pmc passes; FETCH_SIZE may under-count narrow reads on gfx950 -- guide, HBM
+# (r01_rocprof_summary_i.txt: k_final_exp_pair, 65 536 tuples per launch, FETCH_SIZE 5.886e6 KB +
+# WRITE_SIZE 1.071e7 KB, separate --pmc passes; FETCH_SIZE may under-count narrow reads on gfx950 -- guide, HBM
 # section).  It is per-lane scratch (Fq12 temporaries / spills of the out-of-line tower functions), not tuple I/O.
-MEASURED_TRAFFIC_BYTES = {"k_final_exp_pair": (5.84241e6 + 1.06305e7) * 1024, "k_miller1_pair": (5.19429e6 + 1.02885e7) * 1024,
+MEASURED_TRAFFIC_BYTES = {"k_final_exp_pair": (5.88623e6 + 1.07062e7) * 1024, "k_miller1_pair": (5.18682e6 + 1.02873e7) * 1024,
                           "k_final_exp": (4.08818e6 + 6.64894e6) * 1024, "k_miller1": (4.34452e6 + 8.77347e6) * 1024}
 FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k)
 
@@ -286,7 +286,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8),
                          "traffic": (MEASURED_TRAFFIC_BYTES[dom] * n / 65536.0) if dom in MEASURED_TRAFFIC_BYTES else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_rocprof_summary_h.txt; single-layout kernels: r01_rocprof_pairing_summary.txt)",
+                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_rocprof_summary_i.txt; single-layout kernels: r01_rocprof_pairing_summary.txt)",
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIRING * n,
                          "kernel_ms": {"k_miller1" + suffix: round(ml, 3), "k_final_exp" + suffix: round(fe, 3)},
                          "note": "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"},
