@@ -31,6 +31,12 @@ def test_hash_g1_kat_and_parity(eng, kats):
     many = [b"Hello world! 16 characters %d" % i for i in range(70)]
     out = eng.hash_g1_batch(many)
     assert all(out[i].tobytes() == RC.hash_g1(m) for i, m in enumerate(many))
+    # ragged batch with long messages (many SHA-256 blocks per lane, lanes finishing at different times)
+    ragged = [bytes((i * 7 + j) & 0xff for j in range(n)) for i, n in enumerate((0, 63, 64, 65, 119, 120, 4096, 100003, 1))]
+    out = eng.hash_g1_batch(ragged)
+    assert all(out[i].tobytes() == RC.hash_g1(m) for i, m in enumerate(ragged))
+    out = eng.hash_g2_batch(ragged)
+    assert all(out[i].tobytes() == RC.hash_g2(m) for i, m in enumerate(ragged))
 
 
 def test_hash_g2_kat_and_parity(eng, kats):
