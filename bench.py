@@ -204,6 +204,12 @@ def main():
     ap.add_argument("--no-verify-extra", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE line on stdout.  Libraries print banners there (RCCL announces its version when the first
+    # communicator is built), so stdout is pointed at stderr until the JSON line is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -303,7 +309,10 @@ def main():
             line["verify"] = verify_extra(engine, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g1, g2)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
