@@ -52,3 +52,19 @@ def test_duplicate_argument_checks(lib):
     assert lib.blsmi_pairing_batch(None, None, None, ctypes.c_size_t(1)) == -3
     ok = ctypes.c_int(7)
     assert lib.blsmi_g2pubs_verify_aggregate(None, None, None, None, ctypes.c_size_t(0), ctypes.byref(ok)) == -3
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/blsmi.h must compile as C99 (cgo feeds it to a C compiler) and as C++."""
+    import os
+    import shutil
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "blsmi.h")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    gpp = shutil.which("g++")
+    if gpp:
+        subprocess.check_call([gpp, "-std=c++17", "-fsyntax-only", "-x", "c++", hdr])
