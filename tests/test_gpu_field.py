@@ -49,6 +49,27 @@ def test_fq_ops(eng):
             assert np.array_equal(out[i], e)
 
 
+def test_fq_inverse_many(eng):
+    """The divstep inversion (fp_inv_core) on 4000+ inputs: random, structured (powers of two, all-ones, values next to
+    0, q/2, q and to the limb boundaries of both representations) -- x * inverse(x) == 1 through the device multiply,
+    and agreement with Python's modular inverse."""
+    xs = P.XORShift(105)
+    q = P.Q
+    vals = rand_fq(xs, 3500)
+    vals += [1 << k for k in range(0, 381)] + [(1 << k) - 1 for k in range(1, 381)]
+    vals += [q - (1 << k) for k in range(0, 380, 7)] + [(q >> 1) + d for d in range(-8, 9)] + [q - d for d in range(1, 40)] + list(range(1, 40))
+    vals += [((1 << (27 * k)) - 1) % q for k in range(1, 15)] + [((1 << (64 * k)) + 1) % q for k in range(1, 6)]
+    vals = [v % q for v in vals if v % q]
+    a = pack(vals)
+    out, ok = eng.debug_op("FQ_INV", a)
+    assert ok.all()
+    for i, v in enumerate(vals):
+        assert unmont(out[i]) == pow(v, -1, q), (i, v)
+    prod, _ = eng.debug_op("FQ_MUL", a, out.reshape(-1))
+    one = mont(1)
+    assert all(np.array_equal(prod[i], one) for i in range(len(vals)))
+
+
 def test_fq_carry_stress(eng):
     # limbs of all-ones / alternating patterns exercise every column of the product and the lazy bounds
     vals = [(1 << k) - 1 for k in range(1, 381, 7)] + [P.Q - ((1 << k) - 1) for k in range(1, 380, 11)]
