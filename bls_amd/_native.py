@@ -11,20 +11,49 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
-_SOURCES = ["blsmi.hip", "fp.cuh", "tower_fwd.cuh", "tower.cuh", "fp2_single.inc", "fp2_pair.inc", "tower_body.inc", "pairing_body.inc", "pair_kernels.inc", "curve.cuh", "pairing.cuh", "hash.cuh", "consts.cuh",
-            "verify_kernels.inc", "verify_host.inc", "msm.inc"]
+# translation units of libblsmi.so: the host side + one unit per kernel family, compiled in parallel
+_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_pairing_single.hip", "k_hash.hip", "k_curve.hip"]
+BUILD_DIR = os.path.join(CSRC, "build")
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+
+
+def _deps(unit):
+    """Prerequisites of one object file, from the depfile the previous compilation left (else: everything in csrc/)."""
+    dfile = os.path.join(BUILD_DIR, unit + ".d")
+    if os.path.exists(dfile):
+        txt = open(dfile).read().replace("\\\n", " ")
+        deps = [t for t in txt.split(":", 1)[1].split() if t]
+        if all(os.path.exists(t) for t in deps):
+            return deps
+        return None                                       # a prerequisite vanished: rebuild
+    return None
+
+
+def _unit_stale(unit):
+    obj = os.path.join(BUILD_DIR, unit + ".o")
+    if not os.path.exists(obj):
+        return True
+    deps = _deps(unit)
+    if deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(x) > t for x in deps)
 
 
 def _stale():
     if not os.path.exists(SO_PATH):
         return True
+    if not os.path.isdir(BUILD_DIR):                      # a shipped .so without its objects (the GPU box): trust mtimes of the sources
+        t = os.path.getmtime(SO_PATH)
+        srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".inc", ".h"))] + [HEADER]
+        return any(os.path.getmtime(x) > t for x in srcs)
     t = os.path.getmtime(SO_PATH)
-    deps = [os.path.join(CSRC, s) for s in _SOURCES] + [HEADER]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return any(_unit_stale(u) or os.path.getmtime(os.path.join(BUILD_DIR, u + ".o")) > t for u in _UNITS)
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -> bls_amd/libblsmi.so (in-tree so that it travels to the GPU box)."""
+    """hipcc --offload-arch=gfx950 -> bls_amd/libblsmi.so (in-tree so that it travels to the GPU box).  The units are
+    compiled concurrently (one hipcc process each) and only when a prerequisite changed."""
     consts = os.path.join(CSRC, "consts.cuh")
     gen = os.path.join(CSRC, "gen_consts.py")
     if not os.path.exists(consts) or os.path.getmtime(gen) > os.path.getmtime(consts):
@@ -32,8 +61,20 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
-           "-o", SO_PATH, os.path.join(CSRC, "blsmi.hip")]
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    procs = []
+    for u in _UNITS:
+        if not force and not _unit_stale(u):
+            continue
+        obj = os.path.join(BUILD_DIR, u + ".o")
+        cmd = [hipcc] + _FLAGS + ["-c", "-MD", "-MF", os.path.join(BUILD_DIR, u + ".d"), "-o", obj, os.path.join(CSRC, u)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((u, subprocess.Popen(cmd)))
+    failed = [u for u, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", SO_PATH] + [os.path.join(BUILD_DIR, u + ".o") for u in _UNITS]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

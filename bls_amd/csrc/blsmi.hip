@@ -1,14 +1,8 @@
-// blsmi.hip -- kernels and the C ABI (include/blsmi.h) of libblsmi.so.
-//
-// This translation unit holds the one-tuple-per-lane kernels (hash-to-curve, scalar multiplication, sums, MSM, wire
-// format, and the pairing kernels selectable with BLSMI_LAYOUT=single) and the host side; the default pairing kernels
-// (lane pair per tuple, two waves per SIMD) are in pair_kernels.inc, the verify-path kernels in verify_kernels.inc,
-// the bucket-method MSM in msm.inc, the verify-path host code in verify_host.inc.  64-lane workgroups throughout.
-// A one-tuple-per-lane pairing keeps f (180 words), R (90) and P, Q (90) per lane and wants the whole 512-entry
-// register file, i.e. one wave per SIMD; G1-side kernels fit 256 registers and run two.
+// blsmi.hip -- host side and C ABI (include/blsmi.h) of libblsmi.so.  The kernels live in their own translation units
+// (k_pairing_pair.hip: the default lane-pair pairing kernels; k_pairing_single.hip; k_hash.hip; k_curve.hip), declared in
+// kernels.h; the verify-path host code is in verify_host.inc.
 #include "../../include/blsmi.h"
-#include "pairing.cuh"
-#include "hash.cuh"
+#include "kernels.h"
 #include <mutex>
 #include <condition_variable>
 #include <chrono>
@@ -19,391 +13,29 @@
 #include <cstdlib>
 #include <string>
 
-using namespace blsmi;
-
-#define WG 64
-#ifndef BLSMI_WAVES_PER_SIMD
-#define BLSMI_WAVES_PER_SIMD 1
-#endif
-#define KERNEL __global__ void __launch_bounds__(WG, BLSMI_WAVES_PER_SIMD)
-// G1-side kernels keep far less live state (Fq, not Fq2/Fq12): 256 registers, two waves per SIMD
-#define KERNEL2 __global__ void __launch_bounds__(WG, 2)
-
-// ------------------------------------------------------------------------------------------------
-// device-side I/O helpers
-// ------------------------------------------------------------------------------------------------
-// internal structure-of-arrays buffers: word (e, j) of tuple t lives at buf[(e*NL + j)*n + t]
-BLSMI_DEV void soa_store(i32* buf, size_t n, size_t t, int e, const FpS& x) {
-#pragma unroll
-    for (int j = 0; j < NL; j++) buf[((size_t)e * NL + j) * n + t] = x.v[j];
-}
-BLSMI_DEV FpS soa_load(const i32* buf, size_t n, size_t t, int e) {
-    FpS x;
-#pragma unroll
-    for (int j = 0; j < NL; j++) x.v[j] = buf[((size_t)e * NL + j) * n + t];
-    return x;
-}
-BLSMI_DEV void soa_store12(i32* buf, size_t n, size_t t, const Fp12S& f) {
-    const FpS* c = reinterpret_cast<const FpS*>(&f);
-#pragma unroll
-    for (int e = 0; e < 12; e++) soa_store(buf, n, t, e, c[e]);
-}
-BLSMI_DEV Fp12S soa_load12(const i32* buf, size_t n, size_t t) {
-    Fp12S f;
-    FpS* c = reinterpret_cast<FpS*>(&f);
-#pragma unroll
-    for (int e = 0; e < 12; e++) c[e] = soa_load(buf, n, t, e);
-    return f;
-}
-// 48-byte big-endian field element at p (4-byte aligned) -> Montgomery
-BLSMI_DEV FpS load_be48(const u8* p) {
-    const u32* w32 = reinterpret_cast<const u32*>(p);
-    u32 w[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) w[j] = __builtin_bswap32(w32[11 - j]);
-    return fp_from_words(w);
-}
-template <int L, int V>
-BLSMI_DEV void store_be48(u8* p, const Fp<L, V>& x) {
-    u32 w[12];
-    fp_to_words(x, w);
-    u32* w32 = reinterpret_cast<u32*>(p);
-#pragma unroll
-    for (int j = 0; j < 12; j++) w32[11 - j] = __builtin_bswap32(w[j]);
-}
-BLSMI_DEV FpS load_m384(const u64* p) {
-    const u32* w32 = reinterpret_cast<const u32*>(p);
-    u32 w[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) w[j] = w32[j];
-    return fp_from_mont384_words(w);
-}
-template <int L, int V>
-BLSMI_DEV void store_m384(u64* p, const Fp<L, V>& x) {
-    u32 w[12];
-    fp_to_mont384_words(x, w);
-    u32* w32 = reinterpret_cast<u32*>(p);
-#pragma unroll
-    for (int j = 0; j < 12; j++) w32[j] = w[j];
-}
-// ---- tuple I/O staged through LDS --------------------------------------------------------------------
-// The host-facing records are array-of-structures (96 / 192 / 576 bytes per tuple).  A wave moves its
-// 64 records between HBM and LDS with lane-contiguous dword accesses (256 B per wave instruction,
-// fully coalesced) and each lane then works on its own record inside LDS.  Records are padded by one
-// word in LDS so that the per-lane stride is odd (no bank conflicts on the per-lane side).
-template <int WORDS>
-BLSMI_DEV void tile_load(u32* lds, const u8* gbase, size_t first, size_t n) {
-    const u32* g = reinterpret_cast<const u32*>(gbase) + first * WORDS;
-    const size_t valid = (n - first < (size_t)WG ? n - first : (size_t)WG) * WORDS;
-    for (int idx = threadIdx.x; idx < WG * WORDS; idx += WG)
-        if ((size_t)idx < valid) lds[(idx / WORDS) * (WORDS + 1) + (idx % WORDS)] = g[idx];
-    __syncthreads();
-}
-template <int WORDS>
-BLSMI_DEV void tile_store(const u32* lds, u8* gbase, size_t first, size_t n) {
-    __syncthreads();
-    u32* g = reinterpret_cast<u32*>(gbase) + first * WORDS;
-    const size_t valid = (n - first < (size_t)WG ? n - first : (size_t)WG) * WORDS;
-    for (int idx = threadIdx.x; idx < WG * WORDS; idx += WG)
-        if ((size_t)idx < valid) g[idx] = lds[(idx / WORDS) * (WORDS + 1) + (idx % WORDS)];
-}
-BLSMI_DEV FpS lds_be48(const u32* rec) {                                  // 12 big-endian words of this lane's record
-    u32 w[12];
-#pragma unroll
-    for (int j = 0; j < 12; j++) w[j] = __builtin_bswap32(rec[11 - j]);
-    return fp_from_words(w);
-}
-BLSMI_DEV G1Aff lds_g1(const u32* rec) { G1Aff a; a.x = lds_be48(rec); a.y = lds_be48(rec + 12); a.inf = 0; return a; }
-BLSMI_DEV G2Aff lds_g2(const u32* rec) { G2Aff a; a.x.c0 = lds_be48(rec); a.x.c1 = lds_be48(rec + 12); a.y.c0 = lds_be48(rec + 24); a.y.c1 = lds_be48(rec + 36); a.inf = 0; return a; }
-
-BLSMI_DEV G1Aff load_g1(const u8* p) { G1Aff a; a.x = load_be48(p); a.y = load_be48(p + 48); a.inf = 0; return a; }
-BLSMI_DEV G2Aff load_g2(const u8* p) {
-    G2Aff a; a.x.c0 = load_be48(p); a.x.c1 = load_be48(p + 48); a.y.c0 = load_be48(p + 96); a.y.c1 = load_be48(p + 144); a.inf = 0; return a;
-}
-BLSMI_DEV void store_g1(u8* p, const G1Aff& a) {
-    if (a.inf) { u32* w = reinterpret_cast<u32*>(p); for (int i = 0; i < 24; i++) w[i] = 0; return; }
-    store_be48(p, a.x); store_be48(p + 48, a.y);
-}
-BLSMI_DEV void store_g2(u8* p, const G2Aff& a) {
-    if (a.inf) { u32* w = reinterpret_cast<u32*>(p); for (int i = 0; i < 48; i++) w[i] = 0; return; }
-    store_be48(p, a.x.c0); store_be48(p + 48, a.x.c1); store_be48(p + 96, a.y.c0); store_be48(p + 144, a.y.c1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernels: pairing
-// ------------------------------------------------------------------------------------------------
-// Miller loop for one pair per tuple; f goes to the internal SoA buffer (or nowhere else).
-KERNEL k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
-    __shared__ u32 lds[WG * 49];
-    const size_t first = (size_t)blockIdx.x * WG;
-    const size_t t = first + threadIdx.x;
-    const int rec = (t < n) ? (int)threadIdx.x : (int)(n - 1 - first);   // tail lanes redo the last tuple
-    G1Aff p[1]; G2Aff q[1];
-    tile_load<24>(lds, g1, first, n);
-    p[0] = lds_g1(lds + rec * 25);
-    __syncthreads();
-    tile_load<48>(lds, g2, first, n);
-    q[0] = lds_g2(lds + rec * 49);
-    Fp12S f;
-    miller_loop<1>(f, p, q);
-    if (t < n) soa_store12(fbuf, n, t, f);
-}
-// mode 0: out = FE(f) as Montgomery-384 limbs; mode 1: out = f itself (no final exponentiation)
-KERNEL k_final_exp(const i32* fbuf, u64* out, size_t n, int mode) {
-    __shared__ u32 lds[WG * 145];
-    const size_t first = (size_t)blockIdx.x * WG;
-    const size_t t = first + threadIdx.x;
-    const size_t tt = t < n ? t : n - 1;
-    Fp12S f = soa_load12(fbuf, n, tt);
-    if (mode == 0) final_exponentiation(f);
-    const FpS* c = reinterpret_cast<const FpS*>(&f);
-    for (int e = 0; e < 12; e++) {                                       // this lane's 576-byte record, into LDS
-        u32 w[12];
-        fp_to_mont384_words(c[e], w);
-#pragma unroll
-        for (int j = 0; j < 12; j++) lds[threadIdx.x * 145 + 12 * e + j] = w[j];
-    }
-    tile_store<144>(lds, reinterpret_cast<u8*>(out), first, n);         // coalesced write-out
-}
-KERNEL k_fq12_from_m384(const u64* in, i32* fbuf, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    for (int e = 0; e < 12; e++) soa_store(fbuf, n, t, e, load_m384(in + 72 * t + 6 * e));
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernels: unit-level ops for the parity tests
-// ------------------------------------------------------------------------------------------------
-template <int W> struct Rec { FpS e[W]; };
-template <int W> BLSMI_DEV Rec<W> rec_load(const u64* p, size_t t) { Rec<W> r; for (int i = 0; i < W; i++) r.e[i] = load_m384(p + (size_t)6 * (W * t + i)); return r; }
-template <int W> BLSMI_DEV void rec_store(u64* p, size_t t, const Rec<W>& r) { for (int i = 0; i < W; i++) store_m384(p + (size_t)6 * (W * t + i), r.e[i]); }
-template <class T, int W> BLSMI_DEV T& as(Rec<W>& r) { return *reinterpret_cast<T*>(&r); }
-
-KERNEL k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    const FpS x = load_m384(a + 6 * t);
-    FpS y = fp_zero();
-    if (op == BLSMI_OP_FQ_MUL || op == BLSMI_OP_FQ_ADD || op == BLSMI_OP_FQ_SUB) y = load_m384(b + 6 * t);
-    FpS r = fp_zero();
-    bool ok = true;
-    switch (op) {
-        case BLSMI_OP_FQ_MUL: r = fp_store(fp_mul(x, y)); break;
-        case BLSMI_OP_FQ_SQR: r = fp_store(fp_sqr(x)); break;
-        case BLSMI_OP_FQ_ADD: r = fp_store(fp_add(x, y)); break;
-        case BLSMI_OP_FQ_SUB: r = fp_store(fp_sub(x, y)); break;
-        case BLSMI_OP_FQ_NEG: r = fp_store(fp_neg(x)); break;
-        case BLSMI_OP_FQ_INV: r = fp_inv(x); ok = !fp_is_zero(x); break;
-        case BLSMI_OP_FQ_SQRT: r = fp_sqrt(x, ok); break;
-    }
-    store_m384(out + 6 * t, r);
-    if (flag) flag[t] = ok ? 1 : 0;
-}
-KERNEL k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    Rec<2> ra = rec_load<2>(a, t), rb = ra, ro;
-    if (op == BLSMI_OP_FQ2_MUL) rb = rec_load<2>(b, t);
-    const Fp2S x = as<Fp2S>(ra), y = as<Fp2S>(rb);
-    Fp2S r = fp2_zero();
-    bool ok = true;
-    switch (op) {
-        case BLSMI_OP_FQ2_MUL: r = fp2_store(fp2_mul(x, y)); break;
-        case BLSMI_OP_FQ2_SQR: r = fp2_store(fp2_sqr(x)); break;
-        case BLSMI_OP_FQ2_INV: r = fp2_store(fp2_inv(x)); ok = !fp2_is_zero(x); break;
-        case BLSMI_OP_FQ2_MUL_NR: r = fp2_store(fp2_mul_nr(x)); break;
-        case BLSMI_OP_FQ2_SQRT: r = fp2_sqrt(x, ok); break;
-        case BLSMI_OP_FQ2_SQRT_ANY: r = fp2_sqrt_any(x, ok); break;
-    }
-    as<Fp2S>(ro) = r;
-    rec_store<2>(out, t, ro);
-    if (flag) flag[t] = ok ? 1 : 0;
-}
-KERNEL k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    Rec<6> ra = rec_load<6>(a, t), rb = ra, ro;
-    if (op == BLSMI_OP_FQ6_MUL) rb = rec_load<6>(b, t);
-    const Fp6S x = as<Fp6S>(ra), y = as<Fp6S>(rb);
-    Fp6S r = fp6_zero();
-    switch (op) {
-        case BLSMI_OP_FQ6_MUL: r = fp6_store(fp6_mul(x, y)); break;
-        case BLSMI_OP_FQ6_SQR: r = fp6_store(fp6_sqr(x)); break;
-        case BLSMI_OP_FQ6_INV: r = fp6_store(fp6_inv(x)); break;
-        case BLSMI_OP_FQ6_FROB1: r = fp6_store(fp6_frob<1>(x)); break;
-    }
-    as<Fp6S>(ro) = r;
-    rec_store<6>(out, t, ro);
-}
-KERNEL k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    Rec<12> ra = rec_load<12>(a, t), rb = ra, ro;
-    if (op == BLSMI_OP_FQ12_MUL) rb = rec_load<12>(b, t);
-    const Fp12S x = as<Fp12S>(ra), y = as<Fp12S>(rb);
-    Fp12S r = fp12_one();
-    switch (op) {
-        case BLSMI_OP_FQ12_MUL: r = fp12_store(fp12_mul(x, y)); break;
-        case BLSMI_OP_FQ12_SQR: r = fp12_store(fp12_sqr(x)); break;
-        case BLSMI_OP_FQ12_INV: r = fp12_store(fp12_inv(x)); break;
-        case BLSMI_OP_FQ12_FROB1: r = fp12_store(fp12_frob<1>(x)); break;
-        case BLSMI_OP_FQ12_FROB2: r = fp12_store(fp12_frob<2>(x)); break;
-        case BLSMI_OP_FQ12_FROB3: r = fp12_store(fp12_frob<3>(x)); break;
-        case BLSMI_OP_FQ12_CYCLO_SQR: r = fp12_cyclotomic_sqr(x); break;
-        case BLSMI_OP_FQ12_CYCLO_RUN16: r = cyc_sqr_run(x, 16); break;
-    }
-    as<Fp12S>(ro) = r;
-    rec_store<12>(out, t, ro);
-}
-// Jacobian points as 3 (G1) / 6 (G2) Fq records x,y,z; infinity <=> z == 0 (g1.go:293)
-template <class F, int W>
-BLSMI_DEV void debug_curve(int dbl, const u64* a, const u64* b, u64* out, size_t t) {
-    Rec<W> ra = rec_load<W>(a, t), rb = ra, ro;
-    if (!dbl) rb = rec_load<W>(b, t);
-    Jac<F> p, q, r;
-    p.x = reinterpret_cast<F*>(&ra)[0]; p.y = reinterpret_cast<F*>(&ra)[1]; p.z = reinterpret_cast<F*>(&ra)[2]; p.inf = f_is_zero(p.z) ? -1 : 0;
-    q.x = reinterpret_cast<F*>(&rb)[0]; q.y = reinterpret_cast<F*>(&rb)[1]; q.z = reinterpret_cast<F*>(&rb)[2]; q.inf = f_is_zero(q.z) ? -1 : 0;
-    r = dbl ? jac_double(p) : jac_add(p, q);
-    if (r.inf) r.z = field_consts<F>::zero();
-    reinterpret_cast<F*>(&ro)[0] = r.x; reinterpret_cast<F*>(&ro)[1] = r.y; reinterpret_cast<F*>(&ro)[2] = r.z;
-    rec_store<W>(out, t, ro);
-}
-KERNEL k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
-    else debug_curve<Fp2S, 6>(op == BLSMI_OP_G2_DOUBLE, a, b, out, t);
-}
-// SWU helpers on a caller-chosen t (own kernels: the G1 helper keeps the two-waves-per-SIMD register budget of k_hash_g1)
-KERNEL2 k_debug_swu_g1(const u64* a, u64* out, size_t n) {               // optimizedSWUMapHelper (g1.go:628-714)
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    Rec<3> r = rec_load<3>(a, t);
-    G1Aff p; swu_g1_helper(p, reinterpret_cast<FpS*>(&r)[0]);
-    reinterpret_cast<FpS*>(&r)[0] = p.x; reinterpret_cast<FpS*>(&r)[1] = p.y; reinterpret_cast<FpS*>(&r)[2] = fp_zero();
-    rec_store<3>(out, t, r);
-}
-KERNEL k_debug_swu_g2(const u64* a, u64* out, size_t n) {                // OptimizedSWU2MapHelper (g2.go:933-1031)
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= n) return;
-    Rec<6> r = rec_load<6>(a, t);
-    G2Aff p; swu_g2_helper(p, reinterpret_cast<Fp2S*>(&r)[0]);
-    reinterpret_cast<Fp2S*>(&r)[0] = p.x; reinterpret_cast<Fp2S*>(&r)[1] = p.y; reinterpret_cast<Fp2S*>(&r)[2] = fp2_zero();
-    rec_store<6>(out, t, r);
-}
-
-// ------------------------------------------------------------------------------------------------
-// kernels: scalar multiplication, sums
-// ------------------------------------------------------------------------------------------------
-template <class F> BLSMI_DEV Aff<F> load_aff(const u8* p);
-template <> BLSMI_DEV G1Aff load_aff<FpS>(const u8* p) { return load_g1(p); }
-template <> BLSMI_DEV G2Aff load_aff<Fp2S>(const u8* p) { return load_g2(p); }
-BLSMI_DEV void store_aff(u8* p, const G1Aff& a) { store_g1(p, a); }
-BLSMI_DEV void store_aff(u8* p, const G2Aff& a) { store_g2(p, a); }
-
-// Fixed 4-bit-window scalar multiplication (BASELINE config 3).  The reference multiplies bit-serially
-// (g1.go:80-90, g2.go:92-102: 255 doublings + one addition per set bit); here each lane builds the table
-// {0, P, 2P, ..., 15P} in its scratch (per-lane indexed), then per nibble does four doublings and ONE addition:
-// 252 doublings + 63 + 14 additions, uniform control flow for all 64 lanes.  Same group element, so the
-// affine output is identical to the reference's.
-template <class F, int PB>
-__device__ void mul_batch_body(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    const size_t tt = t < n ? t : n - 1;
-    const Aff<F> p = load_aff<F>(pts + pt_stride * tt);                  // stride 0: one common base point (PrivToPub)
-    const u32* s32 = reinterpret_cast<const u32*>(scalars + 32 * tt);
-    Jac<F> tab[16];
-    tab[0] = jac_zero<F>();
-    tab[1] = to_jac(p);
-    for (int j = 2; j < 16; j++) tab[j] = jac_add_affine(tab[j - 1], p);
-    Jac<F> res = jac_zero<F>();
-    for (int w = 0; w < 8; w++) {                                        // big-endian scalar: word 0 is most significant
-        const u32 kw = __builtin_bswap32(s32[w]);
-        for (int nib = 7; nib >= 0; nib--) {
-            if (w | (7 - nib)) { res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); }
-            res = jac_add(res, tab[(kw >> (4 * nib)) & 15]);
-        }
-    }
-    const Aff<F> a = jac_to_affine(res);
-    if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
-}
-KERNEL2 k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
-KERNEL k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
-
-// Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
-template <class F> struct jac_words { static constexpr int value = sizeof(F) / sizeof(FpS) * 3; };
-template <class F>
-BLSMI_DEV void jac_soa_store(i32* buf, size_t n, size_t t, const Jac<F>& p) {
-    constexpr int W = jac_words<F>::value;
-    const FpS* c = reinterpret_cast<const FpS*>(&p);
-#pragma unroll
-    for (int e = 0; e < W; e++) soa_store(buf, n, t, e, c[e]);
-    buf[(size_t)W * NL * n + t] = p.inf;
-}
-template <class F>
-BLSMI_DEV Jac<F> jac_soa_load(const i32* buf, size_t n, size_t t) {
-    constexpr int W = jac_words<F>::value;
-    Jac<F> p;
-    FpS* c = reinterpret_cast<FpS*>(&p);
-#pragma unroll
-    for (int e = 0; e < W; e++) c[e] = soa_load(buf, n, t, e);
-    p.inf = buf[(size_t)W * NL * n + t];
-    return p;
-}
-template <class F, int PB>
-__device__ void sum_level0_body(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= half) return;
-    Aff<F> a = load_aff<F>(pts + (size_t)PB * t);
-    if (in_inf && in_inf[t]) a.inf = -1;
-    Jac<F> r = to_jac(a);
-    if (t + half < n) {
-        Aff<F> b = load_aff<F>(pts + (size_t)PB * (t + half));
-        if (in_inf && in_inf[t + half]) b.inf = -1;
-        r = jac_add_affine(r, b);
-    }
-    jac_soa_store(buf, half, t, r);
-}
-KERNEL2 k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<FpS, 96>(pts, in_inf, buf, n, half); }
-KERNEL k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<Fp2S, 192>(pts, in_inf, buf, n, half); }
-template <class F>
-__device__ void sum_level_body(const i32* src, i32* dst, size_t n, size_t half) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= half) return;
-    Jac<F> r = jac_soa_load<F>(src, n, t);
-    if (t + half < n) r = jac_add(r, jac_soa_load<F>(src, n, t + half));
-    jac_soa_store(dst, half, t, r);
-}
-KERNEL2 k_g1_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<FpS>(src, dst, n, half); }
-KERNEL k_g2_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<Fp2S>(src, dst, n, half); }
-template <class F, int PB>
-__device__ void sum_final_body(const i32* src, u8* out, i32* out_inf) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const Aff<F> a = jac_to_affine(jac_soa_load<F>(src, 1, 0));
-    store_aff(out, a);
-    *out_inf = a.inf ? 1 : 0;
-}
-KERNEL2 k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<FpS, 96>(src, out, out_inf); }
-KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
-
-#include "msm.inc"
-#include "verify_kernels.inc"
-#include "pair_kernels.inc"
-
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+#include <rccl/rccl.h>                 // types and prototypes only: librccl is dlopen()ed when more than one device is in use
+#include <dlfcn.h>
+#include <atomic>
+#include <thread>
+#include <random>
+
 namespace {
-// Host state. Every entry point leases one call context (a non-blocking stream, a grow-only scratch buffer and
-// timing events) from a small pool, so calls from several OS threads (cgo pins one per goroutine call) run
-// concurrently on separate HIP streams; temporaries come from the device's stream-ordered memory pool, whose
-// release threshold is raised so freed blocks are reused by later calls instead of returning to the driver.
+// Host state.  The library drives a LIST of devices from one process (blsmi_init_devices; blsmi_init binds a single one).
+// Every entry point leases one call context (a non-blocking stream, a grow-only scratch buffer and timing events) from
+// the pool of one device, so calls from several OS threads (cgo pins one per goroutine call) run concurrently on
+// separate HIP streams -- and on separate GPUs when there are several; temporaries come from the device's
+// stream-ordered memory pool, whose release threshold is raised so freed blocks are reused by later calls instead of
+// returning to the driver.  Large verify batches are split by contiguous block over the devices ("shards"), each
+// shard on its own host thread; the only exchanges are the pass/fail bitmap (RCCL all-reduce) and, for one n-way
+// VerifyAggregate, the per-device Fq12 partial products (RCCL all-gather) -- DESIGN.md section 5.
 std::mutex g_mu;
-std::condition_variable g_cv;
+std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
-int g_device = 0;
-char g_version[160] = "blsmi 0.1 (uninitialised)";
+char g_version[200] = "blsmi 0.2 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
@@ -420,81 +52,171 @@ struct Workspace {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+struct Device;
 struct Ctx {
     hipStream_t stream = nullptr;
     Workspace ws;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     bool busy = false;
+    Device* dev = nullptr;
 };
 constexpr int MAX_CTX = 16;
-Ctx g_ctx[MAX_CTX];
-int g_nctx = 4;                         // BLSMI_STREAMS
+constexpr int MAX_DEV = 16;
+// G1/G2 generators in wire form and the generator's prepared lines, written once per device at init (read-only afterwards)
+struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; };
+struct Device {
+    int id = -1;                        // HIP device ordinal
+    int index = 0;                      // position in g_dev
+    Ctx ctx[MAX_CTX];
+    Gens gens;
+    int leased = 0;                     // contexts in use (device choice for unpinned calls)
+    // collectives: one RCCL communicator rank and one stream per device, plus a grow-only exchange buffer
+    ncclComm_t comm = nullptr;
+    hipStream_t coll_stream = nullptr;
+    Workspace coll;
+};
+Device g_dev[MAX_DEV];
+int g_ndev = 0;
+int g_nshards = 0;                      // logical shards of a split batch (BLSMI_SHARDS; default = number of devices)
+size_t g_shard_min = 8192;              // batches below this many tuples are not split (BLSMI_SHARD_MIN)
+bool g_force_rccl = false;              // BLSMI_FORCE_RCCL=1: build the communicator even for one device (exercises the collective path on a 1-GPU box)
+int g_nctx = 4;                         // BLSMI_STREAMS: contexts per device
+int g_rr = 0;                           // round-robin start for unpinned leases
 thread_local Ctx* tl_ctx = nullptr;
 #define g_stream (tl_ctx->stream)
 #define g_ws (tl_ctx->ws)
-// G1/G2 generators in wire form, written once at init (read-only afterwards)
-struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; } g_gens;
+#define g_gens (tl_ctx->dev->gens)
 bool g_use_gen_lines = true;           // BLSMI_GEN_LINES=0 recomputes the generator's lines per tuple (A/B switch)
-// optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline object
-bool g_profile = false;
-float g_last_ms[2] = {0.f, 0.f};
+// optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline object; results are per calling thread
+std::atomic<bool> g_profile{false};
+thread_local float tl_last_ms[2] = {0.f, 0.f};
 
-int ensure_init(int device) {           // caller holds g_mu
-    if (g_ready) return BLSMI_OK;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
-    if (device < 0 || device >= count) return BLSMI_E_ARG;
-    HIPCHK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    snprintf(g_version, sizeof g_version, "blsmi 0.1 %s CUs=%d", prop.gcnArchName, prop.multiProcessorCount);
-    g_device = device;
-    const char* lay = getenv("BLSMI_LAYOUT");
-    g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
-    const char* ns = getenv("BLSMI_STREAMS");
-    if (ns) { int v = atoi(ns); g_nctx = v < 1 ? 1 : (v > MAX_CTX ? MAX_CTX : v); }
+// ---- RCCL, loaded on demand (a single-GPU deployment never needs it) ---------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { fprintf(stderr, "blsmi: cannot load librccl (%s): multi-GPU sharding needs RCCL\n", dlerror()); return false; }
+#define BLSMI_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(h, "nccl" #f)); if (!f) { fprintf(stderr, "blsmi: librccl lacks nccl" #f "\n"); return false; }
+        BLSMI_SYM(CommInitAll) BLSMI_SYM(CommDestroy) BLSMI_SYM(AllReduce) BLSMI_SYM(AllGather) BLSMI_SYM(GroupStart) BLSMI_SYM(GroupEnd) BLSMI_SYM(GetErrorString)
+#undef BLSMI_SYM
+        return true;
+    }
+} g_rccl;
+bool g_have_comm = false;
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, g_rccl.GetErrorString(r_)); return BLSMI_E_RCCL; } } while (0)
+
+int init_device(Device& d) {            // caller holds g_mu
+    HIPCHK(hipSetDevice(d.id));
     hipMemPool_t pool;
-    HIPCHK(hipDeviceGetDefaultMemPool(&pool, device));
+    HIPCHK(hipDeviceGetDefaultMemPool(&pool, d.id));
     uint64_t keep = UINT64_MAX;
     HIPCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-    if (!g_gens.g1) {
-        HIPCHK(hipMalloc((void**)&g_gens.g1, 96)); HIPCHK(hipMalloc((void**)&g_gens.g2, 192));
-        hipLaunchKernelGGL(k_write_generators, dim3(1), dim3(WG), 0, nullptr, g_gens.g1, g_gens.g2);
-        HIPCHK(hipMalloc((void**)&g_gens.lines, sizeof(i32) * 68 * 3 * 2 * NL));
-        hipLaunchKernelGGL(k_prepare_generator_lines, dim3(1), dim3(WG), 0, nullptr, (const u8*)g_gens.g2, g_gens.lines);
+    for (auto& c : d.ctx) c.dev = &d;
+    if (!d.gens.g1) {
+        HIPCHK(hipMalloc((void**)&d.gens.g1, 96)); HIPCHK(hipMalloc((void**)&d.gens.g2, 192));
+        hipLaunchKernelGGL(k_write_generators, dim3(1), dim3(WG), 0, nullptr, d.gens.g1, d.gens.g2);
+        HIPCHK(hipMalloc((void**)&d.gens.lines, sizeof(i32) * 68 * 3 * 2 * NL));
+        hipLaunchKernelGGL(k_prepare_generator_lines, dim3(1), dim3(WG), 0, nullptr, (const u8*)d.gens.g2, d.gens.lines);
         HIPCHK(hipGetLastError());
         HIPCHK(hipDeviceSynchronize());
     }
+    return BLSMI_OK;
+}
+// devs[0..ndev): HIP ordinals.  Caller holds g_mu.
+int ensure_init_list(const int* devs, int ndev) {
+    if (g_ready) return BLSMI_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
+    if (ndev < 1 || ndev > MAX_DEV) return BLSMI_E_ARG;
+    for (int i = 0; i < ndev; i++) {
+        if (devs[i] < 0 || devs[i] >= count) return BLSMI_E_ARG;
+        for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return BLSMI_E_ARG;
+    }
+    const char* lay = getenv("BLSMI_LAYOUT");
+    g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
+    if (const char* ns = getenv("BLSMI_STREAMS")) { int v = atoi(ns); g_nctx = v < 1 ? 1 : (v > MAX_CTX ? MAX_CTX : v); }
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
+    g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
+    for (int i = 0; i < ndev; i++) {
+        g_dev[i].id = devs[i]; g_dev[i].index = i;
+        int rc = init_device(g_dev[i]);
+        if (rc) return rc;
+    }
+    g_ndev = ndev;
+    g_nshards = ndev;
+    if (const char* v = getenv("BLSMI_SHARDS")) { int k = atoi(v); if (k >= 1 && k <= 64) g_nshards = k; }
+    if (const char* v = getenv("BLSMI_SHARD_MIN")) g_shard_min = (size_t)strtoull(v, nullptr, 10);
+    if (ndev > 1 || g_force_rccl) {
+        if (!g_rccl.load()) return BLSMI_E_RCCL;
+        ncclComm_t comms[MAX_DEV];
+        NCCLCHK(g_rccl.CommInitAll(comms, ndev, devs));
+        for (int i = 0; i < ndev; i++) {
+            g_dev[i].comm = comms[i];
+            HIPCHK(hipSetDevice(g_dev[i].id));
+            HIPCHK(hipStreamCreateWithFlags(&g_dev[i].coll_stream, hipStreamNonBlocking));
+        }
+        g_have_comm = true;
+    }
+    HIPCHK(hipSetDevice(g_dev[0].id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g_dev[0].id));
+    snprintf(g_version, sizeof g_version, "blsmi 0.2 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_have_comm ? " rccl" : "");
     g_ready = true;
     return BLSMI_OK;
 }
+int ensure_init_default() {             // lazy initialisation by the first entry point: device 0 only (blsmi_init_devices opts into more)
+    const int d0 = 0;
+    return ensure_init_list(&d0, 1);
+}
 inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
+int device_index_of_ordinal(int ordinal) { for (int i = 0; i < g_ndev; i++) if (g_dev[i].id == ordinal) return i; return -1; }
 
-// Lease of one call context for the duration of an entry point.
+// Lease of one call context for the duration of an entry point.  dev_index < 0: any device (the one with the fewest
+// contexts in use, scanning from a rotating start, so that concurrent callers spread over the GPUs).
 struct CtxLease {
     int rc = BLSMI_OK;
-    CtxLease() {
+    Ctx* mine = nullptr;
+    Ctx* outer = nullptr;                // a lease taken while this thread already holds one (nested entry points) is restored on release
+    explicit CtxLease(int dev_index = -1) {
         std::unique_lock<std::mutex> lk(g_mu);
-        rc = ensure_init(g_device);
+        rc = ensure_init_default();
         if (rc) return;
-        if (hipSetDevice(g_device) != hipSuccess) { rc = BLSMI_E_HIP; return; }     // the current device is per-thread state
+        if (dev_index >= g_ndev) { rc = BLSMI_E_ARG; return; }
         Ctx* c = nullptr;
         for (;;) {
-            for (int i = 0; i < g_nctx && !c; i++) if (!g_ctx[i].busy) c = &g_ctx[i];
+            int best = -1;
+            for (int k = 0; k < g_ndev; k++) {
+                const int i = dev_index >= 0 ? dev_index : (g_rr + k) % g_ndev;
+                if (g_dev[i].leased < g_nctx && (best < 0 || g_dev[i].leased < g_dev[best].leased)) best = i;
+                if (dev_index >= 0) break;
+            }
+            if (best >= 0) { for (int i = 0; i < g_nctx && !c; i++) if (!g_dev[best].ctx[i].busy) c = &g_dev[best].ctx[i]; }
             if (c) break;
             g_cv.wait(lk);
         }
+        if (dev_index < 0) g_rr = (g_rr + 1) % g_ndev;
+        if (hipSetDevice(c->dev->id) != hipSuccess) { rc = BLSMI_E_HIP; return; }      // the current device is per-thread state
         if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = BLSMI_E_HIP; return; }
-        c->busy = true;
-        tl_ctx = c;
+        c->busy = true; c->dev->leased++;
+        outer = tl_ctx;
+        tl_ctx = mine = c;
     }
     ~CtxLease() {
-        if (!tl_ctx) return;
-        { std::lock_guard<std::mutex> lk(g_mu); tl_ctx->busy = false; }
-        tl_ctx = nullptr;
-        g_cv.notify_one();
+        if (!mine) return;
+        { std::lock_guard<std::mutex> lk(g_mu); mine->busy = false; mine->dev->leased--; }
+        tl_ctx = outer;
+        if (outer) (void)hipSetDevice(outer->dev->id);
+        g_cv.notify_all();
     }
 };
 
@@ -504,6 +226,13 @@ struct UseStream {
     explicit UseStream(void* s) : saved(tl_ctx->stream) { if (s) tl_ctx->stream = (hipStream_t)s; }
     ~UseStream() { tl_ctx->stream = saved; }
 };
+// device (index into g_dev) that owns a device pointer handed to a *_dev entry point; -1 if it is not one of ours
+int device_index_of_pointer(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    std::lock_guard<std::mutex> lk(g_mu);
+    return device_index_of_ordinal(a.device);
+}
 
 // RAII device temporary from the stream-ordered pool of the leased context's stream
 struct DBuf {
@@ -513,38 +242,99 @@ struct DBuf {
     ~DBuf() { if (p) (void)hipFreeAsync(p, s); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
-}  // namespace
 
+// ---- sharding ---------------------------------------------------------------------------------------------------
+// A batch of n independent tuples is cut into g_nshards contiguous blocks (block boundaries on multiples of `align`
+// tuples); shard k runs on device k mod g_ndev, on its own host thread (the current device is per-thread state), under
+// its own context lease.  body(shard, lo, hi) returns a BLSMI_* code; the first failure is reported.
+struct ShardPlan { int nshards = 1; size_t n = 0, per = 0; size_t lo(int k) const { return std::min(n, per * (size_t)k); } size_t hi(int k) const { return std::min(n, per * (size_t)(k + 1)); } };
+ShardPlan plan_shards(size_t n, size_t align) {
+    ShardPlan p; p.n = n;
+    int k = g_nshards;
+    if (n < g_shard_min || k <= 1) k = 1;
+    size_t per = (n + k - 1) / k;
+    per = (per + align - 1) / align * align;
+    p.nshards = k; p.per = per ? per : align;
+    return p;
+}
+template <class F>
+int run_shards(const ShardPlan& plan, F&& body) {
+    if (plan.nshards == 1) { CtxLease lease; if (lease.rc) return lease.rc; return body(0, plan.lo(0), plan.hi(0)); }
+    std::vector<int> rcs(plan.nshards, BLSMI_OK);
+    std::vector<std::thread> th;
+    auto run = [&](int k) {
+        if (plan.lo(k) >= plan.hi(k)) return;
+        CtxLease lease(k % g_ndev);
+        rcs[k] = lease.rc ? lease.rc : body(k, plan.lo(k), plan.hi(k));
+    };
+    for (int k = 1; k < plan.nshards; k++) th.emplace_back(run, k);
+    run(0);
+    for (auto& t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return BLSMI_OK;
+}
+}  // namespace
 #define LOCK_AND_INIT() CtxLease lease_; if (lease_.rc) return lease_.rc;
+// *_dev entry points run on the device that owns the caller's buffers
+#define LOCK_AND_INIT_AT(ptr) const int devidx_ = device_index_of_pointer_init(ptr); if (devidx_ < 0) return devidx_ == -1 ? BLSMI_E_ARG : devidx_; CtxLease lease_(devidx_); if (lease_.rc) return lease_.rc;
 
 #define BLSMI_API extern "C" __attribute__((visibility("default")))
 
+namespace {
+int device_index_of_pointer_init(const void* p) {                          // -1: not a pointer on one of the library's devices; < -1: init failure
+    { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc < -1 ? rc : -2; }
+    return device_index_of_pointer(p);
+}
+}  // namespace
+
 BLSMI_API int blsmi_init(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_ready && device != g_device) return BLSMI_E_ARG;
-    return ensure_init(device);
+    if (g_ready) return device_index_of_ordinal(device) >= 0 ? BLSMI_OK : BLSMI_E_ARG;
+    return ensure_init_list(&device, 1);
 }
+BLSMI_API int blsmi_init_devices(int ndev) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
+    if (ndev <= 0) ndev = count;
+    if (ndev > count || ndev > MAX_DEV) return BLSMI_E_ARG;
+    if (g_ready) return ndev == g_ndev ? BLSMI_OK : BLSMI_E_ARG;
+    int devs[MAX_DEV];
+    for (int i = 0; i < ndev; i++) devs[i] = i;
+    return ensure_init_list(devs, ndev);
+}
+BLSMI_API int blsmi_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_ready ? g_ndev : 0; }
+BLSMI_API int blsmi_shard_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_ready ? g_nshards : 0; }
 BLSMI_API void blsmi_shutdown(void) {
     std::unique_lock<std::mutex> lk(g_mu);
     if (!g_ready) return;
     for (;;) {                          // wait for calls in flight
         bool busy = false;
-        for (int i = 0; i < MAX_CTX; i++) busy |= g_ctx[i].busy;
+        for (int d = 0; d < g_ndev; d++) for (int i = 0; i < MAX_CTX; i++) busy |= g_dev[d].ctx[i].busy;
         if (!busy) break;
         g_cv.wait(lk);
     }
-    (void)hipSetDevice(g_device);
-    for (int i = 0; i < MAX_CTX; i++) {
-        Ctx& c = g_ctx[i];
-        if (!c.stream) continue;
-        (void)hipStreamSynchronize(c.stream);
-        c.ws.release();
-        for (auto& e : c.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        (void)hipStreamDestroy(c.stream);
-        c.stream = nullptr;
+    for (int d = 0; d < g_ndev; d++) {
+        Device& dv = g_dev[d];
+        (void)hipSetDevice(dv.id);
+        if (dv.comm) { (void)hipStreamSynchronize(dv.coll_stream); (void)g_rccl.CommDestroy(dv.comm); dv.comm = nullptr; }
+        if (dv.coll_stream) { (void)hipStreamDestroy(dv.coll_stream); dv.coll_stream = nullptr; }
+        dv.coll.release();
+        for (int i = 0; i < MAX_CTX; i++) {
+            Ctx& c = dv.ctx[i];
+            if (!c.stream) continue;
+            (void)hipStreamSynchronize(c.stream);
+            c.ws.release();
+            for (auto& e : c.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            (void)hipStreamDestroy(c.stream);
+            c.stream = nullptr;
+        }
+        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); dv.gens = Gens{}; }
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     }
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, g_device) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+    g_have_comm = false;
+    g_ndev = 0;
     g_ready = false;
 }
 BLSMI_API const char* blsmi_version(void) { return g_version; }
@@ -554,7 +344,7 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     if (n == 0) return BLSMI_OK;
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
-    const bool prof = g_profile;
+    const bool prof = g_profile.load();
     if (prof && !tl_ctx->ev[0]) for (auto& e : tl_ctx->ev) HIPCHK(hipEventCreate(&e));
     if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[0], s));
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
@@ -567,41 +357,46 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));      // blocking entry point: results are ready on return
     if (prof) {
-        HIPCHK(hipEventElapsedTime(&g_last_ms[0], tl_ctx->ev[0], tl_ctx->ev[1]));
-        HIPCHK(hipEventElapsedTime(&g_last_ms[1], tl_ctx->ev[1], tl_ctx->ev[2]));
+        HIPCHK(hipEventElapsedTime(&tl_last_ms[0], tl_ctx->ev[0], tl_ctx->ev[1]));
+        HIPCHK(hipEventElapsedTime(&tl_last_ms[1], tl_ctx->ev[1], tl_ctx->ev[2]));
     }
     return BLSMI_OK;
 }
-// Enable/disable per-kernel HIP-event timing of blsmi_pairing_batch[_dev]; read back with blsmi_last_kernel_ms.
+// Enable/disable per-kernel HIP-event timing of blsmi_pairing_batch[_dev]; read back (by the calling thread, for its own
+// last call) with blsmi_last_kernel_ms.
 BLSMI_API int blsmi_set_profiling(int on) {
-    LOCK_AND_INIT();
-    g_profile = on != 0;
+    g_profile.store(on != 0);
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_last_kernel_ms(float* miller_ms, float* final_exp_ms) {
     if (!miller_ms || !final_exp_ms) return BLSMI_E_ARG;
-    *miller_ms = g_last_ms[0]; *final_exp_ms = g_last_ms[1];
+    *miller_ms = tl_last_ms[0]; *final_exp_ms = tl_last_ms[1];
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_pairing_batch_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, void* stream) {
-    if (n && (!d_g1 || !d_g2 || !d_out)) return BLSMI_E_ARG;
-    LOCK_AND_INIT();
+    if (n == 0) return BLSMI_OK;
+    if (!d_g1 || !d_g2 || !d_out) return BLSMI_E_ARG;
+    LOCK_AND_INIT_AT(d_out);
     UseStream us(stream);
     return pairing_dev(d_g1, d_g2, d_out, n, g_stream, 0);
 }
+// host-buffer form: independent tuples, split over the devices by contiguous block, no exchange at all
 static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n, int mode) {
     if (n && (!g1 || !g2 || !out)) return BLSMI_E_ARG;
-    LOCK_AND_INIT();
     if (n == 0) return BLSMI_OK;
-    DBuf a, b, o;
-    HIPCHK(a.alloc(96 * n)); HIPCHK(b.alloc(192 * n)); HIPCHK(o.alloc(576 * n));
-    HIPCHK(hipMemcpyAsync(a.p, g1, 96 * n, hipMemcpyHostToDevice, g_stream));
-    HIPCHK(hipMemcpyAsync(b.p, g2, 192 * n, hipMemcpyHostToDevice, g_stream));
-    int rc = pairing_dev(a.p, b.p, o.p, n, g_stream, mode);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, o.p, 576 * n, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipStreamSynchronize(g_stream));
-    return BLSMI_OK;
+    { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc; }
+    return run_shards(plan_shards(n, 64), [&](int, size_t lo, size_t hi) -> int {
+        const size_t m = hi - lo;
+        DBuf a, b, o;
+        HIPCHK(a.alloc(96 * m)); HIPCHK(b.alloc(192 * m)); HIPCHK(o.alloc(576 * m));
+        HIPCHK(hipMemcpyAsync(a.p, g1 + 96 * lo, 96 * m, hipMemcpyHostToDevice, g_stream));
+        HIPCHK(hipMemcpyAsync(b.p, g2 + 192 * lo, 192 * m, hipMemcpyHostToDevice, g_stream));
+        int rc = pairing_dev(a.p, b.p, o.p, m, g_stream, mode);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(out + 72 * lo, o.p, 576 * m, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        return BLSMI_OK;
+    });
 }
 BLSMI_API int blsmi_pairing_batch(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n) { return pairing_host(g1, g2, out, n, 0); }
 BLSMI_API int blsmi_miller_loop_batch(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n) { return pairing_host(g1, g2, out, n, 1); }
@@ -621,7 +416,10 @@ BLSMI_API int blsmi_final_exponentiation_batch(const uint64_t* in, uint64_t* out
 }
 
 // ---- unit-level ops -------------------------------------------------------------------------------
-BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flag, size_t n) {
+BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flag, size_t n) {
+    const bool pairl = (op_in & BLSMI_OP_LANE_PAIR) != 0;                 // run the tower op in the lane-pair layout
+    const int op = op_in & ~BLSMI_OP_LANE_PAIR;
+    if (pairl && (op < 16 || op >= 64)) return BLSMI_E_ARG;
     int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
     if (n && (!a || !out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
@@ -633,7 +431,8 @@ BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint6
     if (b) HIPCHK(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(dflag.p, 1, n, g_stream));
     dim3 g(nblocks(n)), w(WG);
-    if (op < 16) hipLaunchKernelGGL(k_debug_fq, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
+    if (pairl) hipLaunchKernelGGL(k_debug_pairl, dim3((unsigned)((n + WG / 2 - 1) / (WG / 2))), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
+    else if (op < 16) hipLaunchKernelGGL(k_debug_fq, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
     else if (op < 32) hipLaunchKernelGGL(k_debug_fq2, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
     else if (op < 48) hipLaunchKernelGGL(k_debug_fq6, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
     else if (op < 64) hipLaunchKernelGGL(k_debug_fq12, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);
@@ -647,13 +446,35 @@ BLSMI_API int blsmi_debug_op(int op, const uint64_t* a, const uint64_t* b, uint6
     return BLSMI_OK;
 }
 
+// G2Prepared of one point as 68 x 3 Fq2 in the Fq wire format (compare with g2.go:650-801)
+BLSMI_API int blsmi_debug_g2_prepare(const uint8_t* g2_aff, int mode, uint64_t* out) {
+    if (!out || (mode != 2 && !g2_aff) || mode < 0 || mode > 2) return BLSMI_E_ARG;
+    LOCK_AND_INIT();
+    DBuf dq, tab, dout;
+    const size_t words = (size_t)68 * 3 * 2 * NL;
+    HIPCHK(dq.alloc(192)); HIPCHK(tab.alloc(sizeof(i32) * words)); HIPCHK(dout.alloc(sizeof(u64) * 68 * 3 * 12));
+    const i32* src = g_gens.lines;
+    if (mode != 2) {
+        HIPCHK(hipMemcpyAsync(dq.p, g2_aff, 192, hipMemcpyHostToDevice, g_stream));
+        if (mode == 0) hipLaunchKernelGGL(k_debug_prepare_single, dim3(1), dim3(WG), 0, g_stream, dq.as<u8>(), tab.as<i32>());
+        else hipLaunchKernelGGL(k_debug_prepare_pair, dim3(1), dim3(WG), 0, g_stream, dq.as<u8>(), tab.as<i32>());
+        src = tab.as<i32>();
+    }
+    hipLaunchKernelGGL(k_debug_lines_to_m384, dim3((68 * 3 * 2 + WG - 1) / WG), dim3(WG), 0, g_stream, src, dout.as<u64>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(u64) * 68 * 3 * 12, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return BLSMI_OK;
+}
+
 // ---- scalar multiplication / sums ----------------------------------------------------------------
 // pts == nullptr: every scalar multiplies the group generator (PrivToPub, g2pubs/bls.go:138-140, g1pubs/bls.go:144-146)
 template <int PB, class K>
-static int mul_batch(K kernel, const uint8_t* pts, const u8* d_gen, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
-    if (n && ((!pts && !d_gen) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
+static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
+    if (n && ((!pts && !gen_group) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
     if (n == 0) return BLSMI_OK;
+    const u8* d_gen = gen_group == 1 ? g_gens.g1 : g_gens.g2;            // the leased device's copy of the generator
     DBuf dp, ds, dout, dinf;
     HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
     if (pts) { HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream)); }
@@ -665,10 +486,10 @@ static int mul_batch(K kernel, const uint8_t* pts, const u8* d_gen, const uint8_
     HIPCHK(hipStreamSynchronize(g_stream));
     return BLSMI_OK;
 }
-BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<96>(k_g1_mul, pts, nullptr, scalars, out, out_inf, n); }
-BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<192>(k_g2_mul, pts, nullptr, scalars, out, out_inf, n); }
-BLSMI_API int blsmi_g1_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, nullptr, g_gens.g1, scalars, out, out_inf, n); }
-BLSMI_API int blsmi_g2_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, g_gens.g2, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<96>(k_g1_mul, pts, 0, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<192>(k_g2_mul, pts, 0, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g1_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, nullptr, 1, scalars, out, out_inf, n); }
+BLSMI_API int blsmi_g2_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, 2, scalars, out, out_inf, n); }
 
 // tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
 template <int PB, int W, class K0, class K1, class K2>
@@ -798,4 +619,5 @@ BLSMI_API int blsmi_g2_msm(const uint8_t* pts, const uint8_t* scalars, size_t n,
 }
 
 #include "verify_host.inc"
+
 

@@ -7,6 +7,8 @@
 #pragma once
 #include "tower.cuh"
 
+#define BLSMI_X_ABS 0xd201000000010000ULL          // |x| of the curve parameter; x < 0: blsIsNegative (g2.go:634-636)
+
 namespace blsmi {
 
 template <class F> struct Jac { F x, y, z; i32 inf; };    // F = FpS (G1) or Fp2S (G2); inf = -1 / 0

@@ -1,0 +1,136 @@
+// k_curve.hip -- scalar multiplication, point sums, the bucket-method MSM, and the Fq6 / curve unit ops of the parity tests.
+#include "tower.cuh"
+#include "device_io.cuh"
+
+KERNEL k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<6> ra = rec_load<6>(a, t), rb = ra, ro;
+    if (op == BLSMI_OP_FQ6_MUL || op == BLSMI_OP_FQ6_MUL_BY_1 || op == BLSMI_OP_FQ6_MUL_BY_01) rb = rec_load<6>(b, t);
+    const Fp6S x = as<Fp6S>(ra), y = as<Fp6S>(rb);
+    Fp6S r = fp6_zero();
+    switch (op) {
+        case BLSMI_OP_FQ6_MUL_BY_1: r = fp6_store(fp6_mul_by_1(x, y.c0)); break;                    // fq6.go:40-57, c1 = first Fq2 of b
+        case BLSMI_OP_FQ6_MUL_BY_01: r = fp6_store(fp6_mul_by_01(x, y.c0, y.c1)); break;            // fq6.go:60-90, (c0, c1) = first two Fq2 of b
+        case BLSMI_OP_FQ6_MUL: r = fp6_store(fp6_mul(x, y)); break;
+        case BLSMI_OP_FQ6_SQR: r = fp6_store(fp6_sqr(x)); break;
+        case BLSMI_OP_FQ6_INV: r = fp6_store(fp6_inv(x)); break;
+        case BLSMI_OP_FQ6_FROB1: r = fp6_store(fp6_frob<1>(x)); break;
+    }
+    as<Fp6S>(ro) = r;
+    rec_store<6>(out, t, ro);
+}
+// Jacobian points as 3 (G1) / 6 (G2) Fq records x,y,z; infinity <=> z == 0 (g1.go:293)
+template <class F, int W>
+BLSMI_DEV void debug_curve(int dbl, const u64* a, const u64* b, u64* out, size_t t) {
+    Rec<W> ra = rec_load<W>(a, t), rb = ra, ro;
+    if (!dbl) rb = rec_load<W>(b, t);
+    Jac<F> p, q, r;
+    p.x = reinterpret_cast<F*>(&ra)[0]; p.y = reinterpret_cast<F*>(&ra)[1]; p.z = reinterpret_cast<F*>(&ra)[2]; p.inf = f_is_zero(p.z) ? -1 : 0;
+    q.x = reinterpret_cast<F*>(&rb)[0]; q.y = reinterpret_cast<F*>(&rb)[1]; q.z = reinterpret_cast<F*>(&rb)[2]; q.inf = f_is_zero(q.z) ? -1 : 0;
+    r = dbl ? jac_double(p) : jac_add(p, q);
+    if (r.inf) r.z = field_consts<F>::zero();
+    reinterpret_cast<F*>(&ro)[0] = r.x; reinterpret_cast<F*>(&ro)[1] = r.y; reinterpret_cast<F*>(&ro)[2] = r.z;
+    rec_store<W>(out, t, ro);
+}
+KERNEL k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    if (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD) debug_curve<FpS, 3>(op == BLSMI_OP_G1_DOUBLE, a, b, out, t);
+    else debug_curve<Fp2S, 6>(op == BLSMI_OP_G2_DOUBLE, a, b, out, t);
+}
+// ------------------------------------------------------------------------------------------------
+// kernels: scalar multiplication, sums
+// ------------------------------------------------------------------------------------------------
+template <class F> BLSMI_DEV Aff<F> load_aff(const u8* p);
+template <> BLSMI_DEV G1Aff load_aff<FpS>(const u8* p) { return load_g1(p); }
+template <> BLSMI_DEV G2Aff load_aff<Fp2S>(const u8* p) { return load_g2(p); }
+BLSMI_DEV void store_aff(u8* p, const G1Aff& a) { store_g1(p, a); }
+BLSMI_DEV void store_aff(u8* p, const G2Aff& a) { store_g2(p, a); }
+
+// Fixed 4-bit-window scalar multiplication (BASELINE config 3).  The reference multiplies bit-serially
+// (g1.go:80-90, g2.go:92-102: 255 doublings + one addition per set bit); here each lane builds the table
+// {0, P, 2P, ..., 15P} in its scratch (per-lane indexed), then per nibble does four doublings and ONE addition:
+// 252 doublings + 63 + 14 additions, uniform control flow for all 64 lanes.  Same group element, so the
+// affine output is identical to the reference's.
+template <class F, int PB>
+__device__ void mul_batch_body(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;
+    const Aff<F> p = load_aff<F>(pts + pt_stride * tt);                  // stride 0: one common base point (PrivToPub)
+    const u32* s32 = reinterpret_cast<const u32*>(scalars + 32 * tt);
+    Jac<F> tab[16];
+    tab[0] = jac_zero<F>();
+    tab[1] = to_jac(p);
+    for (int j = 2; j < 16; j++) tab[j] = jac_add_affine(tab[j - 1], p);
+    Jac<F> res = jac_zero<F>();
+    for (int w = 0; w < 8; w++) {                                        // big-endian scalar: word 0 is most significant
+        const u32 kw = __builtin_bswap32(s32[w]);
+        for (int nib = 7; nib >= 0; nib--) {
+            if (w | (7 - nib)) { res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); }
+            res = jac_add(res, tab[(kw >> (4 * nib)) & 15]);
+        }
+    }
+    const Aff<F> a = jac_to_affine(res);
+    if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
+}
+KERNEL2 k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
+KERNEL k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
+
+// Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
+template <class F> struct jac_words { static constexpr int value = sizeof(F) / sizeof(FpS) * 3; };
+template <class F>
+BLSMI_DEV void jac_soa_store(i32* buf, size_t n, size_t t, const Jac<F>& p) {
+    constexpr int W = jac_words<F>::value;
+    const FpS* c = reinterpret_cast<const FpS*>(&p);
+#pragma unroll
+    for (int e = 0; e < W; e++) soa_store(buf, n, t, e, c[e]);
+    buf[(size_t)W * NL * n + t] = p.inf;
+}
+template <class F>
+BLSMI_DEV Jac<F> jac_soa_load(const i32* buf, size_t n, size_t t) {
+    constexpr int W = jac_words<F>::value;
+    Jac<F> p;
+    FpS* c = reinterpret_cast<FpS*>(&p);
+#pragma unroll
+    for (int e = 0; e < W; e++) c[e] = soa_load(buf, n, t, e);
+    p.inf = buf[(size_t)W * NL * n + t];
+    return p;
+}
+template <class F, int PB>
+__device__ void sum_level0_body(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= half) return;
+    Aff<F> a = load_aff<F>(pts + (size_t)PB * t);
+    if (in_inf && in_inf[t]) a.inf = -1;
+    Jac<F> r = to_jac(a);
+    if (t + half < n) {
+        Aff<F> b = load_aff<F>(pts + (size_t)PB * (t + half));
+        if (in_inf && in_inf[t + half]) b.inf = -1;
+        r = jac_add_affine(r, b);
+    }
+    jac_soa_store(buf, half, t, r);
+}
+KERNEL2 k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<FpS, 96>(pts, in_inf, buf, n, half); }
+KERNEL k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<Fp2S, 192>(pts, in_inf, buf, n, half); }
+template <class F>
+__device__ void sum_level_body(const i32* src, i32* dst, size_t n, size_t half) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= half) return;
+    Jac<F> r = jac_soa_load<F>(src, n, t);
+    if (t + half < n) r = jac_add(r, jac_soa_load<F>(src, n, t + half));
+    jac_soa_store(dst, half, t, r);
+}
+KERNEL2 k_g1_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<FpS>(src, dst, n, half); }
+KERNEL k_g2_sum(const i32* src, i32* dst, size_t n, size_t half) { sum_level_body<Fp2S>(src, dst, n, half); }
+template <class F, int PB>
+__device__ void sum_final_body(const i32* src, u8* out, i32* out_inf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Aff<F> a = jac_to_affine(jac_soa_load<F>(src, 1, 0));
+    store_aff(out, a);
+    *out_inf = a.inf ? 1 : 0;
+}
+KERNEL2 k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<FpS, 96>(src, out, out_inf); }
+KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
+
+#include "msm.inc"

@@ -1,3 +1,7 @@
+// k_hash.hip -- hash-to-curve kernels, the compressed wire format, and the Fq / Fq2-level unit ops of the parity tests.
+#include "hash.cuh"
+#include "device_io.cuh"
+
 // verify_kernels.inc -- kernels behind the g1pubs / g2pubs verify surface, the hash-to-curve batch
 // entry points and the compressed wire format.  Included by blsmi.hip.
 
@@ -23,66 +27,12 @@ KERNEL k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n) {
     hash_g2_with_domain(h, msgs32 + 32 * tt, domain);
     if (t < n) store_g2(out + 192 * t, h);
 }
-// G2Prepared of the generator (g2.go:639-801): 68 line-coefficient triples for the fixed-Q Miller loop of g2pubs.Verify
-KERNEL k_prepare_generator_lines(const u8* g2, i32* table) {
-    if (threadIdx.x != 0) return;
-    const G2Aff q = load_g2(g2);
-    prepare_lines(q.x, q.y, table);
-}
 KERNEL k_write_generators(u8* g1, u8* g2) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     G1Aff a; a.x = C_G1X; a.y = C_G1Y; a.inf = 0;
     G2Aff b; b.x = C_G2X; b.y = C_G2Y; b.inf = 0;
     store_g1(g1, a);
     store_g2(g2, b);
-}
-
-// ---- CompareTwoPairings (pairing.go:140-147): f = ML((P0,Q0), (-P1,Q1)); strides in bytes, 0 = broadcast
-// `pre` != nullptr: Q0 is the G2 generator and its line coefficients come from the start-up table
-KERNEL k_miller2(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre) {
-    __shared__ u32 lds[WG * 49];
-    const size_t first = (size_t)blockIdx.x * WG;
-    const size_t t = first + threadIdx.x;
-    const size_t tt = t < n ? t : n - 1;
-    const int rec = (t < n) ? (int)threadIdx.x : (int)(n - 1 - first);
-    G1Aff p[2]; G2Aff q[2];
-    // stride 0 = one broadcast record (a generator); otherwise stage the wave's 64 records through LDS
-    if (sp0) { tile_load<24>(lds, p0, first, n); p[0] = lds_g1(lds + rec * 25); __syncthreads(); } else p[0] = load_g1(p0);
-    if (sq0) { tile_load<48>(lds, q0, first, n); q[0] = lds_g2(lds + rec * 49); __syncthreads(); } else q[0] = load_g2(q0);
-    tile_load<24>(lds, p1, first, n); p[1] = aff_neg(lds_g1(lds + rec * 25)); __syncthreads();
-    tile_load<48>(lds, q1, first, n); q[1] = lds_g2(lds + rec * 49);
-    (void)tt; (void)sp1; (void)sq1;
-    Fp12S f;
-    if (pre) miller_loop<2, true>(f, p, q, pre);
-    else miller_loop<2>(f, p, q);
-    if (t < n) soa_store12(fbuf, n, t, f);
-}
-// ok[t] = FinalExponentiation(f_t) == 1, and 0 for tuples flagged as containing a point at infinity
-KERNEL k_final_exp_is_one(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    const size_t tt = t < n ? t : n - 1;
-    Fp12S f = soa_load12(fbuf, n, tt);
-    final_exponentiation(f);
-    const bool one = fp12_eq(f, fp12_one());
-    if (t < n) ok[t] = (one && !(inf_flags && inf_flags[t])) ? 1 : 0;
-}
-// Fq12 product tree for VerifyAggregate: dst[t] = src[t] * src[t + half]
-KERNEL k_fq12_prod_level(const i32* src, i32* dst, size_t n, size_t half) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (t >= half) return;
-    Fp12S a = soa_load12(src, n, t);
-    if (t + half < n) { const Fp12S b = soa_load12(src, n, t + half); nf_fp12_mul(a, a, b); }
-    soa_store12(dst, half, t, a);
-}
-KERNEL k_fq12_one(i32* f) { if (blockIdx.x == 0 && threadIdx.x == 0) soa_store12(f, 1, 0, fp12_one()); }
-// two-element compare for VerifyAggregate: ok = FE(a) == FE(b)
-KERNEL k_final_exp_equal(const i32* a, const i32* b, i32* ok) {
-    if (blockIdx.x != 0) return;
-    Fp12S x = soa_load12(a, 1, 0), y = soa_load12(b, 1, 0);
-    final_exponentiation(x);
-    final_exponentiation(y);
-    const bool e = fp12_eq(x, y);
-    if (threadIdx.x == 0) *ok = e ? 1 : 0;
 }
 
 // ---- compressed wire format (g1.go:185-249, g2.go:219-295) ----------------------------------------
@@ -176,6 +126,32 @@ KERNEL k_merge_flags(const u8* inf_pk, const u8* err_pk, const u8* inf_sig, cons
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     if (t < n) flags[t] = (u8)(((inf_pk[t] | err_pk[t]) ? 1 : 0) | ((inf_sig[t] | err_sig[t]) ? 2 : 0));
 }
+// tuple flags of a verify batch: the caller's flags (may be null) OR-ed with "the key / signature record is all zero", the
+// library's encoding of the point at infinity; *any (may be null) is raised when some tuple is flagged
+KERNEL k_flag_zero_records(const u8* pks, int pk_words, const u8* sigs, int sig_words, const u8* in_flags, u8* flags, int* any, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    u32 a = 0, b = 1;
+    const u32* p = reinterpret_cast<const u32*>(pks) + (size_t)pk_words * t;
+    for (int i = 0; i < pk_words; i++) a |= p[i];
+    if (sigs) {
+        b = 0;
+        const u32* q = reinterpret_cast<const u32*>(sigs) + (size_t)sig_words * t;
+        for (int i = 0; i < sig_words; i++) b |= q[i];
+    }
+    const u8 f = (u8)((in_flags ? in_flags[t] : 0) | (a ? 0 : 1) | (b ? 0 : 2));
+    flags[t] = f;
+    if (f && any) atomicOr(any, 1);
+}
+// verdict bytes -> bits, LSB first: bitmap[b] holds tuples 8b .. 8b+7 (the layout of the bitmap all-reduce; `bitmap` points
+// at this shard's first byte, shards start on multiples of 8 tuples)
+KERNEL k_pack_bitmap(const u8* ok, u8* bitmap, size_t n) {
+    const size_t b = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (8 * b >= n) return;
+    u32 v = 0;
+    for (int i = 0; i < 8; i++) if (8 * b + i < n && ok[8 * b + i]) v |= 1u << i;
+    bitmap[b] = (u8)v;
+}
 KERNEL k_g1_compress(const u8* pts, const u8* in_inf, u8* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     if (t >= n) return;
@@ -196,3 +172,73 @@ KERNEL k_g2_compress(const u8* pts, const u8* in_inf, u8* out, size_t n) {
     Fp2S y; y.c0 = load_be48(p + 96); y.c1 = load_be48(p + 144);
     o[0] |= 0x80 | (fp2_sign_is_neg(y) ? 0x20 : 0);                        // g2.go:278-284
 }
+
+KERNEL k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    const FpS x = load_m384(a + 6 * t);
+    FpS y = fp_zero();
+    if (op == BLSMI_OP_FQ_MUL || op == BLSMI_OP_FQ_ADD || op == BLSMI_OP_FQ_SUB || op == BLSMI_OP_FQ_CMP) y = load_m384(b + 6 * t);
+    FpS r = fp_zero();
+    bool ok = true;
+    int code = -1;
+    switch (op) {
+        case BLSMI_OP_FQ_DBL: r = fp_store(fp_dbl(x)); break;                                       // fq.go:140-143
+        case BLSMI_OP_FQ_CMP: {                                                                      // fq.go:134-137: order of the normal forms
+            u32 wx[12], wy[12];
+            fp_to_words(x, wx); fp_to_words(y, wy);
+            int c = 0;
+            for (int j = 0; j < 12; j++) if (wx[j] != wy[j]) c = wx[j] > wy[j] ? 1 : -1;           // most significant difference wins
+            code = c + 1; r = x; break;
+        }
+        case BLSMI_OP_FQ_PARITY: code = fp_gt_half(x) ? 1 : 0; r = x; break;                        // fq.go:269-273: a > -a
+        case BLSMI_OP_FQ_MUL: r = fp_store(fp_mul(x, y)); break;
+        case BLSMI_OP_FQ_SQR: r = fp_store(fp_sqr(x)); break;
+        case BLSMI_OP_FQ_ADD: r = fp_store(fp_add(x, y)); break;
+        case BLSMI_OP_FQ_SUB: r = fp_store(fp_sub(x, y)); break;
+        case BLSMI_OP_FQ_NEG: r = fp_store(fp_neg(x)); break;
+        case BLSMI_OP_FQ_INV: r = fp_inv(x); ok = !fp_is_zero(x); break;
+        case BLSMI_OP_FQ_SQRT: r = fp_sqrt(x, ok); break;
+    }
+    store_m384(out + 6 * t, r);
+    if (flag) flag[t] = code >= 0 ? (u8)code : (ok ? 1 : 0);
+}
+KERNEL k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<2> ra = rec_load<2>(a, t), rb = ra, ro;
+    if (op == BLSMI_OP_FQ2_MUL) rb = rec_load<2>(b, t);
+    const Fp2S x = as<Fp2S>(ra), y = as<Fp2S>(rb);
+    Fp2S r = fp2_zero();
+    bool ok = true;
+    switch (op) {
+        case BLSMI_OP_FQ2_MUL: r = fp2_store(fp2_mul(x, y)); break;
+        case BLSMI_OP_FQ2_SQR: r = fp2_store(fp2_sqr(x)); break;
+        case BLSMI_OP_FQ2_INV: r = fp2_store(fp2_inv(x)); ok = !fp2_is_zero(x); break;
+        case BLSMI_OP_FQ2_MUL_NR: r = fp2_store(fp2_mul_nr(x)); break;
+        case BLSMI_OP_FQ2_SQRT: r = fp2_sqrt(x, ok); break;
+        case BLSMI_OP_FQ2_SQRT_ANY: r = fp2_sqrt_any(x, ok); break;
+        case BLSMI_OP_FQ2_PARITY: ok = fp2_sign_is_neg(x) != 0; r = x; break;                        // fq2.go:256-260: a > -a, c1 first
+    }
+    as<Fp2S>(ro) = r;
+    rec_store<2>(out, t, ro);
+    if (flag) flag[t] = ok ? 1 : 0;
+}
+// SWU helpers on a caller-chosen t (own kernels: the G1 helper keeps the two-waves-per-SIMD register budget of k_hash_g1)
+KERNEL2 k_debug_swu_g1(const u64* a, u64* out, size_t n) {               // optimizedSWUMapHelper (g1.go:628-714)
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<3> r = rec_load<3>(a, t);
+    G1Aff p; swu_g1_helper(p, reinterpret_cast<FpS*>(&r)[0]);
+    reinterpret_cast<FpS*>(&r)[0] = p.x; reinterpret_cast<FpS*>(&r)[1] = p.y; reinterpret_cast<FpS*>(&r)[2] = fp_zero();
+    rec_store<3>(out, t, r);
+}
+KERNEL k_debug_swu_g2(const u64* a, u64* out, size_t n) {                // OptimizedSWU2MapHelper (g2.go:933-1031)
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    Rec<6> r = rec_load<6>(a, t);
+    G2Aff p; swu_g2_helper(p, reinterpret_cast<Fp2S*>(&r)[0]);
+    reinterpret_cast<Fp2S*>(&r)[0] = p.x; reinterpret_cast<Fp2S*>(&r)[1] = p.y; reinterpret_cast<Fp2S*>(&r)[2] = fp2_zero();
+    rec_store<6>(out, t, r);
+}
+

@@ -1,0 +1,69 @@
+// kernels.h -- declarations of the kernels defined in the k_*.hip translation units, for the host side (blsmi.hip).
+// Generated from the definitions by tools/gen_kernel_decls.py; the launch bounds live with the definitions.
+#pragma once
+#include "fp.cuh"
+using namespace blsmi;
+#define WG 64
+constexpr int PT = WG / 2;          // tuples per workgroup of the lane-pair kernels
+// k_pairing_single.hip
+__global__ void k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n);
+__global__ void k_final_exp(const i32* fbuf, u64* out, size_t n, int mode);
+__global__ void k_fq12_from_m384(const u64* in, i32* fbuf, size_t n);
+__global__ void k_prepare_generator_lines(const u8* g2, i32* table);
+__global__ void k_miller2(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
+__global__ void k_final_exp_is_one(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+__global__ void k_fq12_prod_level(const i32* src, i32* dst, size_t n, size_t half);
+__global__ void k_fq12_aos_to_soa(const i32* aos, i32* soa, size_t n);
+__global__ void k_fq12_one(i32* f);
+__global__ void k_final_exp_equal(const i32* a, const i32* b, i32* ok);
+__global__ void k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_t n);
+__global__ void k_debug_prepare_single(const u8* g2, i32* table);
+__global__ void k_debug_lines_to_m384(const i32* table, u64* out);
+// k_pairing_pair.hip
+__global__ void k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size_t n);
+__global__ void k_debug_prepare_pair(const u8* g2, i32* table);
+// pair_kernels.inc
+__global__ void k_miller1_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
+__global__ void k_final_exp_pair(const i32* fbuf, u64* out, size_t n, int mode);
+__global__ void k_miller2_pair(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
+__global__ void k_final_exp_is_one_pair(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+// k_hash.hip
+__global__ void k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n);
+__global__ void k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n);
+__global__ void k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n);
+__global__ void k_write_generators(u8* g1, u8* g2);
+__global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
+__global__ void k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
+__global__ void k_merge_flags(const u8* inf_pk, const u8* err_pk, const u8* inf_sig, const u8* err_sig, u8* flags, size_t n);
+__global__ void k_flag_zero_records(const u8* pks, int pk_words, const u8* sigs, int sig_words, const u8* in_flags, u8* flags, int* any, size_t n);
+__global__ void k_pack_bitmap(const u8* ok, u8* bitmap, size_t n);
+__global__ void k_g1_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
+__global__ void k_g2_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
+__global__ void k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
+__global__ void k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
+__global__ void k_debug_swu_g1(const u64* a, u64* out, size_t n);
+__global__ void k_debug_swu_g2(const u64* a, u64* out, size_t n);
+// k_curve.hip
+__global__ void k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n);
+__global__ void k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n);
+__global__ void k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
+__global__ void k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
+__global__ void k_g1_sum(const i32* src, i32* dst, size_t n, size_t half);
+__global__ void k_g2_sum(const i32* src, i32* dst, size_t n, size_t half);
+__global__ void k_g1_sum_final(const i32* src, u8* out, i32* out_inf);
+__global__ void k_g2_sum_final(const i32* src, u8* out, i32* out_inf);
+// msm.inc
+__global__ void k_msm_hist(const u8* scalars, size_t n, int c, int nwin, u32* hist);
+__global__ void k_msm_scan(const u32* hist, u32* offs, u32* cursor, int c);
+__global__ void k_msm_max(const u32* hist, size_t nb, u32* out);
+__global__ void k_msm_scatter(const u8* scalars, size_t n, int c, int nwin, u32* cursor, u32* idx);
+__global__ void k_g1_msm_bucket(const u8* pts, const u32* idx, const u32* offs, const u32* hist, i32* buckets, size_t n, int c, size_t nb);
+__global__ void k_g2_msm_bucket(const u8* pts, const u32* idx, const u32* offs, const u32* hist, i32* buckets, size_t n, int c, size_t nb);
+__global__ void k_g1_msm_chunk(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nct);
+__global__ void k_g2_msm_chunk(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nct);
+__global__ void k_g1_msm_fold(const i32* src, i32* dst, size_t seg, size_t half, int nwin);
+__global__ void k_g2_msm_fold(const i32* src, i32* dst, size_t seg, size_t half, int nwin);
+__global__ void k_g1_msm_final(const i32* wins, int nwin, int c, u8* out, i32* out_inf);
+__global__ void k_g2_msm_final(const i32* wins, int nwin, int c, u8* out, i32* out_inf);

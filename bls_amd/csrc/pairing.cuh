@@ -14,7 +14,6 @@
 
 namespace blsmi {
 
-#define BLSMI_X_ABS 0xd201000000010000ULL          // |x|, blsIsNegative (g2.go:634-636)
 #define BLSMI_NOINLINE __device__ __noinline__
 
 #include "pairing_body.inc"

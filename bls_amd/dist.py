@@ -58,24 +58,40 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     rejection) and the 576-byte Fq12 partials -- after which every rank multiplies the partials, runs the
     signature-side Miller loop and one final exponentiation, and compares.  Returns the same boolean on
     every rank.  `all_gather_bytes(b: bytes) -> list[bytes]` is the collective (RCCL via torch.distributed
-    in production, gloo in the CPU test); `engine` defaults to bls_amd.engine."""
+    in production, gloo in the CPU test); `engine` defaults to bls_amd.engine.
+
+    Screens, agreed on by all ranks before any of them can return (a one-byte status rides on the first
+    all-gather): a shard whose key and message counts differ (g2pubs/bls.go:241-243), an empty message, a key or
+    the signature at infinity (all-zero record; the reference panics in MillerLoop there) -> False everywhere.
+    Duplicate rejection compares SHA-256 digests of the messages across ranks, not the message bytes: equal
+    messages always collide, distinct ones never in practice (a collision would need a SHA-256 collision)."""
     import hashlib
     if engine is None:
         from . import engine as _e
         engine = _e
+    pk_bytes = 192 if group == "g2pubs" else 96
+    pk_raw = bytes(shard_pks)
+    status = 0
+    if len(pk_raw) != pk_bytes * len(shard_msgs):
+        status |= 2                                            # len(pubKeys) != len(msgs)
+    if any(len(m) == 0 for m in shard_msgs):
+        status |= 1
+    if not any(bytes(sig)):
+        status |= 4                                            # signature at infinity
     digests = b"".join(hashlib.sha256(bytes(m)).digest() for m in shard_msgs)
-    empties = any(len(m) == 0 for m in shard_msgs)
-    gathered = all_gather_bytes(digests + (b"\x01" if empties else b"\x00"))
+    gathered = all_gather_bytes(digests + bytes([status]))
     alld = []
-    any_empty = False
+    any_status = 0
     for g in gathered:
-        any_empty |= g[-1:] == b"\x01"
+        any_status |= g[-1]
         alld.extend(g[i:i + 32] for i in range(0, len(g) - 1, 32))
-    if any_empty or len(set(alld)) != len(alld):              # duplicate (or empty) message: reject, like the reference
+    if any_status or len(set(alld)) != len(alld):             # duplicate (or empty) message, bad shard: reject on every rank
         return False
-    part = engine.aggregate_partial(group, shard_msgs, shard_pks)
-    parts = all_gather_bytes(part.tobytes())
-    rhs = engine.fq12_product(np.frombuffer(b"".join(parts), dtype=np.uint64))
+    part, bad = engine.aggregate_partial(group, shard_msgs, pk_raw)
+    parts = all_gather_bytes(part.tobytes() + bytes([1 if bad else 0]))
+    if any(p[-1] for p in parts):                              # a key at infinity on some rank
+        return False
+    rhs = engine.fq12_product(np.frombuffer(b"".join(p[:-1] for p in parts), dtype=np.uint64))
     if group == "g2pubs":
         lhs = engine.miller_loop_batch(sig, engine_generator(engine, 2), 1)[0]
     else:

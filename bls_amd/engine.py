@@ -14,7 +14,7 @@ class BlsmiError(RuntimeError):
     pass
 
 
-_ERR = {-1: "no usable HIP device", -2: "HIP runtime call failed", -3: "bad argument", -4: "out of memory"}
+_ERR = {-1: "no usable HIP device", -2: "HIP runtime call failed", -3: "bad argument", -4: "out of memory", -5: "RCCL unavailable or collective failed"}
 
 
 def _check(rc, what):
@@ -38,7 +38,27 @@ def _p8(a):
 
 
 def init(device=0):
+    """Bind this process to one device (one rank per GPU under torchrun)."""
     _check(_lib().blsmi_init(int(device)), "blsmi_init")
+
+
+def init_devices(ndev=0):
+    """Drive the first ndev devices (0 = all visible) from this one process: large verify / pairing batches are split
+    over them inside the library (RCCL bitmap all-reduce / partial-product all-gather), see include/blsmi.h."""
+    _check(_lib().blsmi_init_devices(int(ndev)), "blsmi_init_devices")
+
+
+def device_count():
+    return int(_lib().blsmi_device_count())
+
+
+def shard_count():
+    return int(_lib().blsmi_shard_count())
+
+
+def shutdown():
+    _lib().blsmi_shutdown.restype = None
+    _lib().blsmi_shutdown()
 
 
 def version():
@@ -279,15 +299,17 @@ def g1pubs_verify_aggregate_common_with_domain(msg32, domain8, pks, sig, n):
 
 
 def aggregate_partial(group, msgs, pks):
-    """Shard-level half of VerifyAggregate: prod_i MillerLoop(H(m_i), pk_i) as (72,) uint64 (wire format)."""
+    """Shard-level half of VerifyAggregate: (prod_i MillerLoop(H(m_i), pk_i) as (72,) uint64 in the wire format,
+    True if some key was the point at infinity)."""
     n = len(msgs)
     buf, off = _msgs(msgs)
     pkb = 192 if group == "g2pubs" else 96
     p = _u8(pks, pkb * n) if n else np.zeros(1, np.uint8)
     out = np.zeros(72, dtype=np.uint64)
+    bad = C.c_int(0)
     fn = _lib().blsmi_g2pubs_aggregate_partial if group == "g2pubs" else _lib().blsmi_g1pubs_aggregate_partial
-    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), _p8(p), C.c_size_t(n), out.ctypes.data_as(_u64p)), "aggregate_partial")
-    return out
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), _p8(p), C.c_size_t(n), out.ctypes.data_as(_u64p), C.byref(bad)), "aggregate_partial")
+    return out, bool(bad.value)
 
 
 def fq12_product(vals):
@@ -332,14 +354,27 @@ def g2_compress_batch(pts, n, in_inf=None):
 
 
 # ---- unit-level device ops (parity tests) -------------------------------------------------------------
-OPS = dict(FQ_MUL=1, FQ_SQR=2, FQ_ADD=3, FQ_SUB=4, FQ_NEG=5, FQ_INV=6, FQ_SQRT=7,
-           FQ2_MUL=16, FQ2_SQR=17, FQ2_INV=18, FQ2_MUL_NR=19, FQ2_SQRT=20, FQ2_SQRT_ANY=21,
-           FQ6_MUL=32, FQ6_SQR=33, FQ6_INV=34, FQ6_FROB1=35,
+OPS = dict(FQ_MUL=1, FQ_SQR=2, FQ_ADD=3, FQ_SUB=4, FQ_NEG=5, FQ_INV=6, FQ_SQRT=7, FQ_DBL=8, FQ_CMP=9, FQ_PARITY=10,
+           FQ2_MUL=16, FQ2_SQR=17, FQ2_INV=18, FQ2_MUL_NR=19, FQ2_SQRT=20, FQ2_SQRT_ANY=21, FQ2_PARITY=22,
+           FQ6_MUL=32, FQ6_SQR=33, FQ6_INV=34, FQ6_FROB1=35, FQ6_MUL_BY_1=36, FQ6_MUL_BY_01=37,
            FQ12_MUL=48, FQ12_SQR=49, FQ12_INV=50, FQ12_FROB1=51, FQ12_FROB2=52, FQ12_FROB3=53, FQ12_CYCLO_SQR=54, FQ12_CYCLO_RUN16=55,
+           FQ12_MUL_BY_014=56, FQ12_MUL_BY_LINE_PAIR=57,
            G1_DOUBLE=64, G1_ADD=65, G2_DOUBLE=66, G2_ADD=67, SWU_G1=68, SWU_G2=69)
 
 
-def debug_op(name, a, b=None):
+LANE_PAIR = 0x100
+
+
+def debug_g2_prepare(g2_aff=None, mode=0):
+    """G2AffineToPrepared of one point -> (68, 3, 12) uint64.  mode 0 / 1: computed by the one-tuple-per-lane / lane-pair
+    steps; mode 2: the generator table the library prepared at start-up."""
+    out = np.zeros(68 * 3 * 12, dtype=np.uint64)
+    q = _u8(g2_aff, 192) if g2_aff is not None else None
+    _check(_lib().blsmi_debug_g2_prepare(_p8(q), C.c_int(mode), out.ctypes.data_as(_u64p)), "blsmi_debug_g2_prepare")
+    return out.reshape(68, 3, 12)
+
+
+def debug_op(name, a, b=None, lane_pair=False, raw_flag=False):
     op = OPS[name]
     width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 else (3 if op in (64, 65, 68) else 6)
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 6 * width)
@@ -351,5 +386,5 @@ def debug_op(name, a, b=None):
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 6 * width)
         assert b.shape == a.shape
         bp = b.ctypes.data_as(_u64p)
-    _check(_lib().blsmi_debug_op(op, a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
-    return out, flag.astype(bool)
+    _check(_lib().blsmi_debug_op(op | (LANE_PAIR if lane_pair else 0), a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
+    return out, (flag.copy() if raw_flag else flag.astype(bool))

@@ -35,10 +35,23 @@ extern "C" {
 #define BLSMI_E_HIP (-2)        /* a HIP runtime call failed */
 #define BLSMI_E_ARG (-3)        /* bad argument (null pointer with n > 0, ...) */
 #define BLSMI_E_NOMEM (-4)
+#define BLSMI_E_RCCL (-5)       /* librccl could not be loaded, or a collective failed (multi-GPU only) */
 
-/* Bind the calling process to `device` (>= 0) and create the library's stream and workspace.
+/* Bind the calling process to ONE device (HIP ordinal >= 0) and create the library's streams and tables.
  * Idempotent; every other host entry point calls it lazily with device 0. */
 int blsmi_init(int device);
+/* Drive the first `ndev` devices of this node from this one process (ndev <= 0: every visible device).  Large
+ * verify / pairing batches are then split by contiguous block over the devices -- one host thread, stream context
+ * and memory pool per shard -- so a single call to blsmi_g{1,2}pubs_verify_batch / _verify_aggregate /
+ * blsmi_pairing_batch uses all of them; the only exchanges are the pass/fail bitmap (one RCCL all-reduce over
+ * xGMI) and, for an n-way VerifyAggregate, the per-device Fq12 partial products (one RCCL all-gather of 720 bytes
+ * per device).  Smaller calls go to the least busy device.  Must be the first call (or repeat the same ndev).
+ * Environment: BLSMI_SHARDS (logical shards, default ndev; more shards than devices share devices),
+ * BLSMI_SHARD_MIN (smallest batch that is split, default 8192), BLSMI_FORCE_RCCL=1 (build the communicator even
+ * for one device).  librccl is loaded with dlopen only when ndev > 1 (or forced): BLSMI_E_RCCL if that fails. */
+int blsmi_init_devices(int ndev);
+int blsmi_device_count(void);   /* devices in use (0 before initialisation) */
+int blsmi_shard_count(void);
 void blsmi_shutdown(void);
 /* "gfx950", CU count, and the library version string */
 const char *blsmi_version(void);
@@ -109,8 +122,8 @@ int blsmi_g1pubs_verify_aggregate_common_with_domain(const uint8_t msg32[32], co
 /* Multi-GPU VerifyAggregate: each rank computes the product of its shard's Miller loops
  * prod_i ML(H(m_i), pk_i) (no final exponentiation) as one Fq12 in the wire format; the ranks all-gather
  * the 576-byte partials, multiply them (blsmi_fq12_product) and finish with one final exponentiation. */
-int blsmi_g2pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */);
-int blsmi_g1pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */);
+int blsmi_g2pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */, int *bad /* may be NULL: 1 if a key is infinity */);
+int blsmi_g1pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */, int *bad);
 int blsmi_fq12_product(const uint64_t *in_fq12 /* n*72 */, size_t n, uint64_t *out_fq12 /* 72 */);
 
 /* device-pointer forms of the verify batches (inputs resident in HBM; ok is n bytes on the device) */
@@ -139,13 +152,21 @@ int blsmi_g2_compress_batch(const uint8_t *pts, const uint8_t *in_inf, uint8_t *
  * arrays of n records of `width` Fq values, each Fq as 6 LE uint64 Montgomery(2^384) limbs. -------- */
 enum blsmi_debug_op {
     BLSMI_OP_FQ_MUL = 1, BLSMI_OP_FQ_SQR, BLSMI_OP_FQ_ADD, BLSMI_OP_FQ_SUB, BLSMI_OP_FQ_NEG, BLSMI_OP_FQ_INV, BLSMI_OP_FQ_SQRT,
-    BLSMI_OP_FQ2_MUL = 16, BLSMI_OP_FQ2_SQR, BLSMI_OP_FQ2_INV, BLSMI_OP_FQ2_MUL_NR, BLSMI_OP_FQ2_SQRT, BLSMI_OP_FQ2_SQRT_ANY /* either root */,
+    BLSMI_OP_FQ_DBL /* DoubleAssign fq.go:140-143 */, BLSMI_OP_FQ_CMP /* Cmp fq.go:134-137: flag = 0/1/2 for a <,=,> b */, BLSMI_OP_FQ_PARITY /* fq.go:269-273: flag */,
+    BLSMI_OP_FQ2_MUL = 16, BLSMI_OP_FQ2_SQR, BLSMI_OP_FQ2_INV, BLSMI_OP_FQ2_MUL_NR, BLSMI_OP_FQ2_SQRT, BLSMI_OP_FQ2_SQRT_ANY /* either root */, BLSMI_OP_FQ2_PARITY /* fq2.go:256-260: flag */,
     BLSMI_OP_FQ6_MUL = 32, BLSMI_OP_FQ6_SQR, BLSMI_OP_FQ6_INV, BLSMI_OP_FQ6_FROB1,
+    BLSMI_OP_FQ6_MUL_BY_1 /* fq6.go:40-57, c1 = b[0..1] */, BLSMI_OP_FQ6_MUL_BY_01 /* fq6.go:60-90, (c0, c1) = b[0..3] */,
     BLSMI_OP_FQ12_MUL = 48, BLSMI_OP_FQ12_SQR, BLSMI_OP_FQ12_INV, BLSMI_OP_FQ12_FROB1, BLSMI_OP_FQ12_FROB2, BLSMI_OP_FQ12_FROB3, BLSMI_OP_FQ12_CYCLO_SQR, BLSMI_OP_FQ12_CYCLO_RUN16 /* 16 squarings in compressed form + decompression */,
+    BLSMI_OP_FQ12_MUL_BY_014 /* fq12.go:32-47, (c0, c1, c4) = b[0..5] */, BLSMI_OP_FQ12_MUL_BY_LINE_PAIR /* a * (014 element b[0..5]) * (014 element b[6..11]) through the fused two-line product */,
     BLSMI_OP_G1_DOUBLE = 64, BLSMI_OP_G1_ADD, BLSMI_OP_G2_DOUBLE, BLSMI_OP_G2_ADD,
     BLSMI_OP_SWU_G1 = 68 /* t in word 0 of a 3-Fq record -> (x, y, 0) */, BLSMI_OP_SWU_G2 /* t in words 0-1 of a 6-Fq record -> (x, y, 0) */
 };
+#define BLSMI_OP_LANE_PAIR 0x100 /* OR into an FQ2 / FQ6 / FQ12 op: run it in the lane-pair layout of the pairing kernels */
 int blsmi_debug_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *flag /* n, may be NULL */, size_t n);
+/* G2AffineToPrepared (g2.go:650-801) of one affine G2 point: 68 line-coefficient triples, each Fq2 as 12 LE uint64 Montgomery(2^384)
+ * limbs, in Miller-loop order.  mode 0: computed by the one-tuple-per-lane doubling/addition steps; 1: by the lane-pair
+ * steps; 2: the table of the G2 generator the library prepared at start-up for g2pubs.Verify (g2_aff ignored). */
+int blsmi_debug_g2_prepare(const uint8_t *g2_aff /* 192 */, int mode, uint64_t *out /* 68*3*12 */);
 
 #ifdef __cplusplus
 }

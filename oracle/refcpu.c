@@ -1069,6 +1069,13 @@ API void rc_fq12_mul_by_014(const u64 a[72], const u64 c0[12], const u64 c1[12],
     fq12 x, r; fq2 k0, k1, k4; memcpy(&x, a, 576); memcpy(&k0, c0, 96); memcpy(&k1, c1, 96); memcpy(&k4, c4, 96);
     fq12_mul_by_014(&r, &x, &k0, &k1, &k4); memcpy(out, &r, 576);
 }
+/* sparse Fq6 products (fq6.go:40-57, 60-90) and the normal-form comparisons (fq.go:134-137, 269-273; fq2.go:31-37, 256-260) */
+API void rc_fq6_mul_by_1(const u64 a[36], const u64 c1[12], u64 out[36]) { fq6 x, r; fq2 k1; memcpy(&x, a, 288); memcpy(&k1, c1, 96); fq6_mul_by_1(&r, &x, &k1); memcpy(out, &r, 288); }
+API void rc_fq6_mul_by_01(const u64 a[36], const u64 c0[12], const u64 c1[12], u64 out[36]) { fq6 x, r; fq2 k0, k1; memcpy(&x, a, 288); memcpy(&k0, c0, 96); memcpy(&k1, c1, 96); fq6_mul_by_01(&r, &x, &k0, &k1); memcpy(out, &r, 288); }
+API int rc_fq_cmp(const u64 a[6], const u64 b[6]) { fq x, y; memcpy(x.l, a, 48); memcpy(y.l, b, 48); return fq_cmp(&x, &y); }
+API int rc_fq_parity(const u64 a[6]) { fq x; memcpy(x.l, a, 48); return fq_parity(&x); }
+API int rc_fq2_cmp(const u64 a[12], const u64 b[12]) { fq2 x, y; memcpy(&x, a, 96); memcpy(&y, b, 96); return fq2_cmp(&x, &y); }
+API int rc_fq2_parity(const u64 a[12]) { fq2 x; memcpy(&x, a, 96); return fq2_parity(&x); }
 API void rc_fq12_exp_u64(const u64 a[72], u64 e, u64 out[72]) { fq12 x, r; memcpy(&x, a, 576); fq12_exp_u64(&r, &x, e); memcpy(out, &r, 576); }
 API int rc_final_exponentiation(const u64 a[72], u64 out[72]) { fq12 x, r; memcpy(&x, a, 576); memset(&r, 0, 576); int ok = final_exponentiation(&r, &x); memcpy(out, &r, 576); return ok; }
 

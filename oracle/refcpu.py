@@ -14,8 +14,15 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "librefcpu.so"])
 
 
-def _load():
+def _stale():
     if not os.path.exists(_SO):
+        return True
+    t = os.path.getmtime(_SO)
+    return any(os.path.getmtime(os.path.join(_HERE, f)) > t for f in ("refcpu.c", "refcpu_curve.inc") if os.path.exists(os.path.join(_HERE, f)))
+
+
+def _load():
+    if _stale():
         build()
     return C.CDLL(_SO)
 
@@ -55,7 +62,8 @@ for _n in ["rc_fq2_inverse", "rc_fq2_sqrt", "rc_fq6_inverse", "rc_fq12_inverse",
            "rc_g2_jac_to_affine_bytes", "rc_g1_mul", "rc_g2_mul", "rc_g1_sum", "rc_g2_sum", "rc_g1_decompress", "rc_g2_decompress", "rc_hash_g2",
            "rc_g2_prepare", "rc_pairing_batch", "rc_g2pubs_verify", "rc_g2pubs_verify_aggregate", "rc_g2pubs_verify_aggregate_common",
            "rc_g1pubs_verify", "rc_g1pubs_verify_with_domain", "rc_g1pubs_verify_aggregate", "rc_g1pubs_verify_aggregate_common",
-           "rc_g1pubs_verify_aggregate_common_with_domain", "rc_g1pubs_verify_aggregate_with_domain"]:
+           "rc_g1pubs_verify_aggregate_common_with_domain", "rc_g1pubs_verify_aggregate_with_domain",
+           "rc_fq_cmp", "rc_fq_parity", "rc_fq2_cmp", "rc_fq2_parity"]:
     getattr(lib, _n).restype = C.c_int
 
 
@@ -128,6 +136,12 @@ def fq12_sqr(a): return _op(lib.rc_fq12_sqr, 72, a)
 def fq12_inverse(a): return _op(lib.rc_fq12_inverse, 72, a, ret=True)
 def fq12_frobenius(a, p): return _op(lib.rc_fq12_frobenius, 72, a, extra=(C.c_uint(p),))
 def fq12_mul_by_014(a, c0, c1, c4): return _op(lib.rc_fq12_mul_by_014, 72, a, c0, c1, c4)
+def fq6_mul_by_1(a, c1): return _op(lib.rc_fq6_mul_by_1, 36, a, c1)
+def fq6_mul_by_01(a, c0, c1): return _op(lib.rc_fq6_mul_by_01, 36, a, c0, c1)
+def fq_cmp(a, b): return int(lib.rc_fq_cmp(_p64(_a64(a, 6)), _p64(_a64(b, 6))))
+def fq_parity(a): return bool(lib.rc_fq_parity(_p64(_a64(a, 6))))
+def fq2_cmp(a, b): return int(lib.rc_fq2_cmp(_p64(_a64(a, 12)), _p64(_a64(b, 12))))
+def fq2_parity(a): return bool(lib.rc_fq2_parity(_p64(_a64(a, 12))))
 def fq12_exp_u64(a, e): return _op(lib.rc_fq12_exp_u64, 72, a, extra=(C.c_uint64(e),))
 def final_exponentiation(a): return _op(lib.rc_final_exponentiation, 72, a, ret=True)
 def g1_double(p): return _op(lib.rc_g1_double, 18, p)

@@ -77,9 +77,11 @@ class _OracleEngine:
         from oracle import refcpu as RC
         n = len(msgs)
         if n == 0:
-            one = np.zeros(72, dtype=np.uint64); one[:6] = RC.fq_from_repr([1, 0, 0, 0, 0, 0]); return one
+            one = np.zeros(72, dtype=np.uint64); one[:6] = RC.fq_from_repr([1, 0, 0, 0, 0, 0]); return one, False
         pk = b"".join(pks) if isinstance(pks, list) else bytes(pks)
         pb = 192 if group == "g2pubs" else 96
+        if any(not any(pk[pb * i:pb * i + pb]) for i in range(n)):
+            return np.zeros(72, dtype=np.uint64), True            # a key at infinity (all-zero record)
         acc = None
         for i, m in enumerate(msgs):
             if group == "g2pubs":
@@ -87,7 +89,7 @@ class _OracleEngine:
             else:
                 f = RC.miller_loop(pk[pb * i:pb * i + pb], RC.hash_g2(m), 1)
             acc = f if acc is None else RC.fq12_mul(acc, f)
-        return acc
+        return acc, False
 
     @staticmethod
     def fq12_product(vals):
@@ -128,7 +130,14 @@ def _agg_worker(rank, world, port, q):
         ok_dup = bdist.sharded_verify_aggregate("g2pubs", dup[lo:hi], b"".join(pks[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
         swapped = [pks[1], pks[0]] + pks[2:]
         ok_bad = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(swapped[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
-        q.put((rank, ok, ok_dup, ok_bad, RC.g2pubs.verify_aggregate(agg, pks, msgs)))
+        # screens that must hold on EVERY rank even when only one shard sees the problem (no rank may block in a collective)
+        short = pks[:n - 1] if rank == world - 1 else pks         # the last shard is one key short
+        lo2, hi2 = lo, min(hi, len(short))
+        ok_len = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(short[lo2:hi2]), agg, rank, world, gather, engine=_OracleEngine)
+        infk = [bytes(192)] + pks[1:]                              # key 0 is the point at infinity (rank 0's shard only)
+        ok_inf = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(infk[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
+        ok_infsig = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(pks[lo:hi]), bytes(96), rank, world, gather, engine=_OracleEngine)
+        q.put((rank, ok, ok_dup, ok_bad or ok_len or ok_inf or ok_infsig, RC.g2pubs.verify_aggregate(agg, pks, msgs)))
     finally:
         dist.destroy_process_group()
 

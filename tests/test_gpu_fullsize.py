@@ -134,3 +134,34 @@ def test_config5_g1pubs_256k(eng):
     assert np.array_equal(np.unpackbits(bitmap, bitorder="little")[:n].astype(bool), expect)
     for i in (15, 31, 47, 100):
         assert RC.g1pubs.verify(msgs2[i], pk2[i].tobytes(), sg2[i].tobytes()) == bool(expect[i])
+
+
+def test_config5_literal_g1pubs_256k_verify_aggregate(eng):
+    """BASELINE configs[4] as worded: "g1pubs path (G2 pubkeys, G1 sigs): 256k aggregate verify" -- ONE
+    (*Signature).VerifyAggregate over 262 144 distinct messages (g1pubs/bls.go:252-282): true, one swapped pair of keys
+    -> false, a duplicated message -> false.  Exercises the k_miller1 + Fq12 product tree path with G2 hashes at size."""
+    n = 262144
+    nk = 256
+    sk = scalars(nk, 55)
+    pks, _ = eng.g1_mul_batch(RC.g1_generator() * nk, sk.reshape(-1), nk)
+    for j in (0, nk - 1):
+        assert pks[j].tobytes() == RC.g1pubs.priv_to_pub(sk[j].tobytes())
+    msgs = _distinct_msgs(n)
+    h = eng.hash_g2_batch(msgs)
+    for i in (0, 131071, n - 1):
+        assert h[i].tobytes() == RC.hash_g2(msgs[i])
+    sks = np.tile(sk, (n // nk, 1))
+    sig_pts, inf = eng.g2_mul_batch(h.reshape(-1), sks.reshape(-1), n)
+    assert not inf.any()
+    assert sig_pts[777].tobytes() == RC.g1pubs.sign(msgs[777], sks[777].tobytes())
+    agg = eng.g2_sum(sig_pts.reshape(-1), n)
+    all_pks = np.tile(pks, (n // nk, 1))
+    assert eng.g1pubs_verify_aggregate(msgs, all_pks.reshape(-1), agg) is True
+    bad = all_pks.copy(); bad[200001] = all_pks[200002]; bad[200002] = all_pks[200001]
+    assert eng.g1pubs_verify_aggregate(msgs, bad.reshape(-1), agg) is False
+    dup = list(msgs); dup[n - 1] = dup[17]
+    assert eng.g1pubs_verify_aggregate(dup, all_pks.reshape(-1), agg) is False
+    # the small-n form of the same entry point agrees with the oracle's VerifyAggregate (n + 1 full pairings)
+    m8, p8 = msgs[:8], [all_pks[i].tobytes() for i in range(8)]
+    a8 = eng.g2_sum(sig_pts[:8].reshape(-1), 8)
+    assert eng.g1pubs_verify_aggregate(m8, b"".join(p8), a8) is True and RC.g1pubs.verify_aggregate(a8, p8, m8) is True

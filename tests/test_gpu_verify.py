@@ -380,7 +380,7 @@ def test_sharded_verify_aggregate_single_process(eng):
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
                     dig = b"".join(hashlib.sha256(m).digest() for m in msgs[lo:hi]) + b"\x00"
-                    part = eng.aggregate_partial(group, msgs[lo:hi], b"".join(pk_list[lo:hi])).tobytes()
+                    part = eng.aggregate_partial(group, msgs[lo:hi], b"".join(pk_list[lo:hi]))[0].tobytes() + b"\x00"
                     contrib.append((dig, part))
                 outs = []
                 for r in range(world):
@@ -392,7 +392,8 @@ def test_sharded_verify_aggregate_single_process(eng):
             assert run(pks) is True
             assert run([pks[1], pks[0]] + pks[2:]) is False
     # partial product of an empty shard is 1, and fq12_product agrees with the oracle
-    one = eng.aggregate_partial("g2pubs", [], b"")
+    one, bad = eng.aggregate_partial("g2pubs", [], b"")
+    assert not bad
     assert np.array_equal(eng.fq12_product(np.stack([one, one])), one)
 
 
