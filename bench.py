@@ -7,14 +7,26 @@ synthetic input resident in HBM: BASELINE.json configs[1] -- 65 536 independent 
 (Miller loop + final exponentiation, the reference's bls.Pairing) per GPU.  W untimed steps, then
 exactly K timed steps bracketed by barrier + synchronize on both sides, MAX over ranks, one JSON line
 from rank 0.  Units shard across ranks with no data-path collective (weak scaling: 64k pairings per GPU).
+After the timed region every rank compares rows of its output with the oracle and the run FAILS on a mismatch.
 
 Extra objects on the line:
-  roofline     -- dominant kernel (final exponentiation), algorithmic bytes (864 B per pairing,
-                  SURVEY 8d) / its HIP-event duration measured on the launch stream, vs 8 TB/s HBM.
-                  This path is integer-VALU bound, not HBM bound; `valu` gives the fraction of the
-                  measured v_mad_i64_i32 issue peak (profiles/r01_ubench2_fmul.log).
-  cpu_baseline -- the oracle (C restatement of the reference algorithm, oracle/refcpu.c) timed on
-                  this box's host cores on a bounded sample of the same workload (rank 0, N = 1).
+  roofline     -- dominant kernel, algorithmic bytes (864 B per pairing) / its HIP-event duration measured
+                  on the launch stream, vs 8 TB/s HBM; `traffic` = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3
+                  PMC passes of this same command (profiles/rNN_counters.json).
+  valu         -- the bound that binds (integer VALU issue): measured VALU wave-instructions per launch from the same
+                  profile -> lane-instructions per pairing, and the nominal Fq-multiplication rate against the measured
+                  ceiling of the multiply core (profiles/r01_ubench2_fmul_15x27.log).
+  cpu_baseline -- the oracle (C restatement of the reference algorithm, oracle/refcpu.c) timed on this box's host cores
+                  on a bounded sample of the same workload (rank 0, N = 1).
+  verify_bench -- the batch-VERIFY workload under the same discipline (timed steps between fences, MAX over ranks):
+                  every rank verifies 65 536 (message, key, signature) tuples -- hash-to-curve, 2-pair Miller loop, final
+                  exponentiation, compare -- and, when N > 1, the RCCL all-reduce of the pass/fail bitmap is INSIDE every
+                  timed step (the north-star's only collective).
+  aggregate_bench -- BASELINE configs[3]: ONE 2^20-signature g2pubs VerifyAggregate (distinct messages) sharded over
+                  the N ranks (2^20 / N tuples per rank; partial products all-gathered, one final exponentiation).
+  reference_shapes -- the reference's own benchmark shapes (pairing_test.go:60-152, g2pubs/bls_test.go:215-256,
+                  g1pubs/verify_benchmark_test.go:15-85), GPU single-call latency and batch throughput beside the CPU
+                  restatement on ONE core (the reference's benchmarks are single-threaded).  N = 1 only.
 """
 import argparse
 import ctypes
@@ -32,29 +44,28 @@ PAIRINGS_PER_GPU = 65536
 BYTES_PER_PAIRING = 864            # 96 B G1 + 192 B G2 in, 576 B Fq12 out
 HBM_PEAK_GBS = 8000.0              # MI355X spec (MI355X_MICROARCH.md)
 # measured integer-VALU ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip,
-# profiles/r01_ubench2_fmul_15x27.log): 61.2e9 mul/s at 4 waves/SIMD, 45.6e9 at the 1 wave/SIMD the pairing kernels run at
+# profiles/r01_ubench2_fmul_15x27.log): 61.2e9 mul/s at 4 waves/SIMD, 56.7e9 at 2, 45.6e9 at 1
 VALU_PEAK_GMULS = 61.2
-VALU_PEAK_1WAVE_GMULS = 45.6
-# HBM traffic of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-# (r01_rocprof_summary_i.txt: k_final_exp_pair, 65 536 tuples per launch, FETCH_SIZE 5.886e6 KB +
-# WRITE_SIZE 1.071e7 KB, separate --pmc passes; FETCH_SIZE may under-count narrow reads on gfx950 -- guide, HBM
-# section).  It is per-lane scratch (Fq12 temporaries / spills of the out-of-line tower functions), not tuple I/O.
-MEASURED_TRAFFIC_BYTES = {"k_final_exp_pair": (5.88623e6 + 1.07062e7) * 1024, "k_miller1_pair": (5.18682e6 + 1.02873e7) * 1024,
-                          "k_final_exp": (4.08818e6 + 6.64894e6) * 1024, "k_miller1": (4.34452e6 + 8.77347e6) * 1024}
-FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k)
+VALU_PEAK_2WAVE_GMULS = 56.7
+FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k): the nominal work unit of `valu`
+R_ORDER = 52435875175126190479447740508185965837690552500527637822603658699938581184513
 
 
-def synth_inputs(engine, n, seed):
-    """n (P_i, Q_i) pairs: P = a_j G1, Q = b_j G2 for 512 seeded scalars, tiled with a row rotation so that all
-    n combinations are distinct.  Generated on the device by the library's own scalar multiplication."""
-    import hashlib
-    base = 512
-    sc = [hashlib.sha256(b"blsmi-bench-%d-%d" % (seed, i)).digest() for i in range(2 * base)]
-    sc = [(int.from_bytes(s, "big") % 52435875175126190479447740508185965837690552500527637822603658699938581184512 + 1).to_bytes(32, "big") for s in sc]
-    from bls_amd import _native
-    lib = _native.load()
-    g = np.zeros(96 + 192, dtype=np.uint8)
-    # generators via the public API: 1 * G is obtained from the verify path's generator table through hash-free means:
+def profile_counters():
+    """Per-kernel rocprofv3 counters of the newest committed profile round (profiles/rNN*_counters.json, written by
+    tools/rocpd_summary.py from separate --pmc passes of this same bench command).  bench.py cannot read PMCs itself:
+    it reports the committed measurement and names the file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))
+    if not files:
+        return None, {}
+    try:
+        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, {}
+
+
+def _gens():
     g1gen = bytes.fromhex(
         "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
         "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")
@@ -63,6 +74,17 @@ def synth_inputs(engine, n, seed):
         "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
         "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801"
         "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be")
+    return g1gen, g2gen
+
+
+def synth_inputs(engine, n, seed):
+    """n (P_i, Q_i) pairs: P = a_j G1, Q = b_j G2 for 512 seeded scalars, tiled with a row rotation so that all
+    n combinations are distinct.  Generated on the device by the library's own scalar multiplication."""
+    import hashlib
+    base = 512
+    sc = [hashlib.sha256(b"blsmi-bench-%d-%d" % (seed, i)).digest() for i in range(2 * base)]
+    sc = [(int.from_bytes(s, "big") % (R_ORDER - 1) + 1).to_bytes(32, "big") for s in sc]
+    g1gen, g2gen = _gens()
     g1b, _ = engine.g1_mul_batch(g1gen * base, b"".join(sc[:base]), base)
     g2b, _ = engine.g2_mul_batch(g2gen * base, b"".join(sc[base:]), base)
     reps = (n + base - 1) // base
@@ -71,13 +93,13 @@ def synth_inputs(engine, n, seed):
     return np.ascontiguousarray(g1), np.ascontiguousarray(g2)
 
 
-def _verify_inputs(engine, dev, group, n):
+def _verify_inputs(engine, dev, group, n, tag=0):
     """n valid (message, public key, signature) tuples of one package, resident in HBM (signed on the device)."""
     import hashlib
     import torch
     nk = 256
     sk = b"".join(hashlib.sha256(b"bench-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
-    msgs = [b"Hello world! 16 characters %d" % i for i in range(n)]
+    msgs = [b"Hello world! 16 characters %d" % (i + tag * n) for i in range(n)]
     buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(m) for m in msgs])
     g1gen, g2gen = _gens()
@@ -93,62 +115,93 @@ def _verify_inputs(engine, dev, group, n):
     return [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (buf.copy(), off.view(np.int64), allpk, sigs)]
 
 
-def verify_extra(engine, dev, n=65536):
-    """Outside the timed region: throughput of the full Verify path (hash-to-curve + 2-pair Miller loop + final
-    exponentiation + compare) on n device-resident tuples, both packages.  1 Verify = 2 Miller-loop pairs + 1 final exp + 1 hash."""
+def verify_bench(engine, dev, rank, world, dist, use_dist, steps=5, warmup=1, n=65536):
+    """The batch-verify workload under bench.py's own timing discipline, both packages.  With a process group the
+    bitmap all-reduce (SUM over disjoint bit ownership == OR, RCCL) runs inside every timed step."""
     import torch
-    out = {}
+    out = {"tuples_per_gpu": n, "steps": steps, "warmup": warmup,
+           "collective": ("one all_reduce(SUM, int32 lanes, disjoint bit ownership) of the %d-byte bitmap over RCCL inside every timed step" % (world * n // 8)) if use_dist else "none (one GPU)"}
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=dev)
     for group in ("g2pubs", "g1pubs"):
-        d = _verify_inputs(engine, dev, group, n)
+        d = _verify_inputs(engine, dev, group, n, tag=rank)
         d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-        best = 1e9
-        for _ in range(3):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
+        full = torch.zeros(world * n // 8, dtype=torch.int32, device=dev)
+
+        def step():
             engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
-            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            if use_dist:
+                full.zero_()
+                full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
+                dist.all_reduce(full, op=dist.ReduceOp.SUM)
+
+        def fence():
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            step()
+        fence(); t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence(); dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            assert bool((full == 255).all().item()), "every rank's tuples must verify and land in the shared bitmap"
         assert bool(d_ok.all().item()), "synthetic tuples must all verify"
-        out[group + "_verifies_per_s"] = round(n / best, 1)
-    out["tuples"] = n
-    out["note"] = "all tuples valid; inputs resident in HBM; includes hash-to-curve on the GPU"
+        dt = float(t.item())
+        out[group + "_verifies_per_s"] = round(world * n * steps / dt, 1)
+        out[group + "_ms_per_step"] = round(dt / steps * 1e3, 3)
+    out["note"] = "all tuples valid; inputs resident in HBM; hash-to-curve on the GPU included; 1 Verify = 2 Miller-loop pairs + 1 final exponentiation + 1 hash"
     return out
 
 
-def sharded_verify_extra(engine, dev, rank, world, dist, n=65536):
-    """Outside the timed region, every rank: the north-star's multi-GPU batch verify -- each rank verifies its own
-    block of n g2pubs tuples, packs the verdicts into its slice of the world*n-bit bitmap, and ONE RCCL all-reduce
-    (sum over disjoint bit ownership == OR) gives every rank the full bitmap.  Returns whole-job verifies/s (max time
-    over ranks) on rank 0."""
+def aggregate_bench(engine, dev, rank, world, dist, use_dist, n_total=1 << 20, reps=2):
+    """BASELINE configs[3]: one n_total-signature g2pubs VerifyAggregate over distinct 32-byte messages, block-sharded over the
+    ranks.  Per rank: duplicate screening, hash-to-curve, n/N Miller loops and the Fq12 product tree on its GPU; then the
+    digests and the 576-byte partial products are all-gathered (bls_amd/dist.py) and every rank finishes with one final
+    exponentiation.  Host buffers (what a caller of the Go API holds), so PCIe is included."""
+    import hashlib
     import torch
-    d = _verify_inputs(engine, dev, "g2pubs", n)
-    d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=dev)
-    full = torch.zeros(world * n // 8, dtype=torch.int32, device=dev)
+    from bls_amd import dist as bdist
+    n = n_total // world
+    lo = rank * n
+    nk = 256
+    sk = b"".join(hashlib.sha256(b"agg-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
+    msgs = [hashlib.sha256(int(i).to_bytes(8, "little")).digest() for i in range(lo, lo + n)]
+    _, g2gen = _gens()
+    pks, _ = engine.g2_mul_batch(g2gen * nk, sk, nk)
+    allpk = np.ascontiguousarray(np.tile(pks, (n // nk, 1))).reshape(-1)
+    h = engine.hash_g1_batch(msgs)
+    sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
+    part = engine.g1_sum(sigs.reshape(-1), n)                              # this rank's share of the aggregate signature
+    if use_dist:
+        gather = bdist.torch_all_gather_bytes(dev)
+        parts = gather(part)
+        agg = engine.g1_sum(b"".join(parts), world)
+    else:
+        gather = None
+        agg = part
     best = 1e9
-    for _ in range(3):
-        full.zero_()
-        dist.barrier(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        engine.verify_batch_dev("g2pubs", d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
-        full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
-        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    ok = None
+    for _ in range(reps + 1):                                              # first repetition warms the pools
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if use_dist:
+            ok = bdist.sharded_verify_aggregate("g2pubs", msgs, allpk, agg, rank, world, gather)
+            dist.barrier()
+        else:
+            ok = engine.g2pubs_verify_aggregate(msgs, allpk, agg)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
         best = min(best, float(t.item()))
-    assert bool((full == 255).all().item()), "every rank's tuples must verify and land in the shared bitmap"
-    return {"g2pubs_verifies_per_s": round(world * n / best, 1), "tuples_per_gpu": n, "bitmap_bytes": world * n // 8,
-            "collective": "one all_reduce(SUM, int32 lanes, disjoint bit ownership) over RCCL per batch"}
-
-
-def _gens():
-    g1gen = bytes.fromhex(
-        "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
-        "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")
-    g2gen = bytes.fromhex(
-        "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"
-        "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
-        "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801"
-        "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be")
-    return g1gen, g2gen
+    assert ok is True, "the synthetic aggregate must verify"
+    return {"signatures": n * world, "signatures_per_gpu": n, "ms": round(best * 1e3, 2), "signatures_per_s": round(n * world / best, 1),
+            "exchange": ("all-gather of 32-byte digests (global duplicate rejection) + all-gather of %d x 576-byte Fq12 partial products over RCCL" % world) if use_dist else "none (one GPU)",
+            "note": "host buffers: PCIe included; min over %d repetitions; verdict True (false-verdict cases: tests/test_gpu_fullsize.py)" % reps}
 
 
 def usable_cores():
@@ -194,6 +247,18 @@ def cpu_baseline(g1, g2, budget_s=12.0):
             "single_core_pairings_per_s": round(1.0 / per, 2)}
 
 
+def self_check(engine, d_out, g1, g2, n):
+    """Outside the timed region: rows of the device output against the oracle's Pairing(), bit for bit (576 bytes each)."""
+    from oracle import refcpu as RC
+    idx = sorted({0, 1, 63, 64, n // 3, n // 2, n - 65, n - 1} & set(range(n)))
+    got = d_out[idx].cpu().numpy().view(np.uint64)
+    for k, i in enumerate(idx):
+        want = RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]
+        if not np.array_equal(got[k], want):
+            return False, i, len(idx)
+    return True, -1, len(idx)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,7 +266,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairings", type=int, default=PAIRINGS_PER_GPU, help="pairings per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify-extra", action="store_true")
+    ap.add_argument("--no-verify-extra", action="store_true", help="skip verify_bench / aggregate_bench / reference_shapes")
+    ap.add_argument("--no-aggregate", action="store_true")
+    ap.add_argument("--no-ref-shapes", action="store_true")
     args = ap.parse_args()
 
     # The contract is ONE line on stdout.  Libraries print banners there (RCCL announces its version when the first
@@ -266,47 +333,78 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    sharded = None
-    if use_dist and not args.no_verify_extra:                       # all ranks take part in the collective
-        try:
-            sharded = sharded_verify_extra(engine, dev, rank, world, dist)
-        except Exception as e:  # noqa: BLE001 -- an extra must never cost the headline line
-            sharded = {"error": repr(e)[:300]}
-    # cross-rank sanity outside the timed region: every rank holds finite, distinct outputs; rank 0 checks a sample
+    # parity gate, outside the timed region, on every rank: a fast kernel with different results is not a result
+    good, bad_row, nrows = self_check(engine, d_out, g1, g2, n)
+    flag = torch.tensor([0 if good else 1], dtype=torch.int32, device=dev)
+    if use_dist:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        print("bench.py: SELF-CHECK FAILED: device output differs from the oracle's Pairing() (rank %d row %d)" % (rank, bad_row), file=sys.stderr)
+        sys.exit(3)
+
+    extras = {}
+    if not args.no_verify_extra:                                     # all ranks take part in the collectives
+        for name, fn in (("verify_bench", lambda: verify_bench(engine, dev, rank, world, dist, use_dist)),
+                         ("aggregate_bench", None if args.no_aggregate else (lambda: aggregate_bench(engine, dev, rank, world, dist, use_dist)))):
+            if fn is None:
+                continue
+            try:
+                extras[name] = fn()
+            except Exception as e:  # noqa: BLE001 -- an extra must never cost the headline line
+                extras[name] = {"error": repr(e)[:300]}
     checksum = int(d_out[::997].sum().item()) & 0xffffffff
     if rank == 0:
         ml = float(np.mean([k[0] for k in kms])); fe = float(np.mean([k[1] for k in kms]))
         suffix = "" if os.environ.get("BLSMI_LAYOUT") == "single" else "_pair"
-        dom, dom_ms = ("k_final_exp" + suffix, fe) if fe >= ml else ("k_miller1" + suffix, ml)
+        kname = {"ml": "k_miller1" + suffix, "fe": "k_final_exp" + suffix}
+        dom, dom_ms = (kname["fe"], fe) if fe >= ml else (kname["ml"], ml)
         achieved = BYTES_PER_PAIRING * n / (dom_ms * 1e-3) / 1e9
         value = world * n * args.steps / dt
         per_gpu = value / world
+        cfile, ctr = profile_counters()
+        scale = n / 65536.0
+
+        def traffic_of(k):
+            c = ctr.get(k, {})
+            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * scale if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+        valu_insts = [ctr.get(kname[k], {}).get("SQ_INSTS_VALU") for k in ("ml", "fe")]
+        lane_instr = (sum(valu_insts) * 64 / 65536.0) if all(v is not None for v in valu_insts) else None
         line = {
             "metric": "BLS12-381 pairings/sec (batch verify)", "value": round(value, 1), "unit": "pairings/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (15 x 27-bit limbs, int64 accumulate)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exp) per GPU per step, inputs resident in HBM, "
-                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py)" % n, "pairings_per_gpu": n, "parallelism": "shard%d" % world,
+                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py; %d rows per rank re-checked against the oracle after the timed region)" % (n, nrows),
+                       "pairings_per_gpu": n, "parallelism": "shard%d" % world,
                        "layout": "one tuple per lane" if suffix == "" else "lane pair per tuple (one Fq2 coefficient per lane), 2 waves/SIMD"},
+            "self_check": {"rows_per_rank": nrows, "against": "oracle Pairing() (oracle/refcpu.c), bit-exact 576-byte Fq12", "passed": True},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8),
-                         "traffic": (MEASURED_TRAFFIC_BYTES[dom] * n / 65536.0) if dom in MEASURED_TRAFFIC_BYTES else None,
-                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, profiles/r01_rocprof_summary_i.txt; single-layout kernels: r01_rocprof_pairing_summary.txt)",
+                         "traffic": traffic_of(dom),
+                         "traffic_unit": "bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes) of %s" % cfile,
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIRING * n,
-                         "kernel_ms": {"k_miller1" + suffix: round(ml, 3), "k_final_exp" + suffix: round(fe, 3)},
+                         "kernel_ms": {kname["ml"]: round(ml, 3), kname["fe"]: round(fe, 3)},
+                         "traffic_all": {kname[k]: traffic_of(kname[k]) for k in ("ml", "fe")},
                          "note": "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"},
-            "valu": {"bound": "int32 VALU (v_mad_i64_i32)", "achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
+            "valu": {"bound": "int32 VALU issue (v_mad_i64_i32)",
+                     "lane_instructions_per_pairing": None if lane_instr is None else round(lane_instr),
+                     "lane_instructions_source": "SQ_INSTS_VALU (wave-instructions per 65 536-pairing launch) x 64 / 65 536, both pairing kernels, %s" % cfile,
+                     "giga_lane_instructions_per_s": None if lane_instr is None else round(per_gpu * lane_instr / 1e9, 1),
+                     "achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
                      "peak": VALU_PEAK_GMULS, "unit": "G Fq-mul/s", "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_GMULS, 4),
-                     "frac_of_1wave_per_simd_peak": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_1WAVE_GMULS, 4),
+                     "frac_of_2wave_per_simd_peak": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_2WAVE_GMULS, 4),
                      "note": "peak = measured issue ceiling of the 15x27 Montgomery multiply core per GPU (profiles/r01_ubench2_fmul_15x27.log); "
-                             "achieved = pairings/s x 14.6k Fq multiplications per pairing (SURVEY 8d)"},
+                             "achieved = pairings/s x 14.6k nominal Fq multiplications per pairing (SURVEY 8d); the instruction count is a measurement"},
             "checksum": checksum,
         }
-        if sharded is not None:
-            line["sharded_verify"] = sharded
-        if world == 1 and not args.no_verify_extra:
-            line["verify"] = verify_extra(engine, dev)
+        line.update(extras)
+        if world == 1 and not args.no_verify_extra and not args.no_ref_shapes:
+            try:
+                from tools import reference_shapes
+                line["reference_shapes"] = reference_shapes.run(engine)
+            except Exception as e:  # noqa: BLE001
+                line["reference_shapes"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(g1, g2)
         sys.stdout.flush()

@@ -1,0 +1,115 @@
+"""The reference's own benchmark shapes, measured on the GPU library and -- beside it -- on the CPU restatement of the
+reference algorithm (oracle/refcpu.c, ONE core: the reference's Go benchmarks are single-threaded).
+
+    pairing_test.go:60-152                    BenchmarkG2Prepare / MillerLoop / FinalExponentiation / Pairing
+    g2pubs/bls_test.go:215-256                BenchmarkBLSAggregateSignature / BLSSign / BLSVerify
+    g1pubs/verify_benchmark_test.go:15-85     BenchmarkVerifyWithDomain / VerifyAggregateCommonWithDomain (128 signers) /
+                                              VerifyAggregateMultipleWithDomain (128 signers, distinct messages)
+
+For every shape: `cpu_ms_per_op` (what `go test -bench` would report per op, restated in C), `gpu_ms_single_call` (the
+latency of ONE call through the C ABI with host buffers, the shape of the Go API) and, where the op batches,
+`gpu_batch_ops_per_s` (one call carrying 65 536 of them, host buffers, PCIe included).  Called by bench.py (N = 1) and
+runnable alone on the GPU box: python tools/reference_shapes.py
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _best(fn, reps):
+    fn()
+    b = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); b = min(b, time.perf_counter() - t0)
+    return b
+
+
+def run(engine, batch=65536):
+    from oracle import refcpu as RC                     # the CPU baseline leg (kind "port"): checker code, timed here as the reference's stand-in
+    from bls_amd import g1pubs as G1P
+    g1gen, g2gen = RC.g1_generator(), RC.g2_generator()
+    sk = [hashlib.sha256(b"refshape-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(256)]
+    p1 = RC.g1_mul(g1gen, sk[0]); q1 = RC.g2_mul(g2gen, sk[1])
+    out = {"cores": 1, "cpu_kind": "port (oracle/refcpu.c, gcc -O2, one thread)", "batch": batch, "shapes": {}}
+    S = out["shapes"]
+    # ---- pairing_test.go:60-152
+    t_prep = _best(lambda: RC.g2_prepare(q1), 5)
+    t_mlp = _best(lambda: RC.miller_loop(p1, q1, 1), 5)
+    ml1 = RC.miller_loop(p1, q1, 1)
+    t_fe = _best(lambda: RC.final_exponentiation(ml1), 3)
+    t_pair = _best(lambda: RC.pairing_batch(p1, q1, 1), 3)
+    nb = batch
+    g1b, _ = engine.g1_mul_batch(g1gen * 256, b"".join(sk), 256); g2b, _ = engine.g2_mul_batch(g2gen * 256, b"".join(sk[::-1]), 256)
+    G1 = np.ascontiguousarray(np.tile(g1b, (nb // 256, 1))).reshape(-1); G2 = np.ascontiguousarray(np.tile(g2b, (nb // 256, 1))).reshape(-1)
+    S["G2Prepare"] = {"ref": "pairing_test.go:60-81", "cpu_ms_per_op": round(t_prep * 1e3, 4), "gpu": "fused into the Miller-loop kernels (the 68 triples never exist in memory); the g2pubs generator table is built once at start-up"}
+    S["MillerLoop"] = {"ref": "pairing_test.go:83-108", "cpu_ms_per_op": round(max(t_mlp - t_prep, 0) * 1e3, 4), "cpu_ms_per_op_incl_prepare": round(t_mlp * 1e3, 4),
+                       "gpu_ms_single_call": round(_best(lambda: engine.miller_loop_batch(p1, q1, 1), 3) * 1e3, 3),
+                       "gpu_batch_ops_per_s": round(nb / _best(lambda: engine.miller_loop_batch(G1, G2, nb), 2), 1), "gpu_note": "includes the G2 preparation (fused)"}
+    mlb = engine.miller_loop_batch(G1[:96 * 4096], G2[:192 * 4096], 4096)
+    mlb = np.ascontiguousarray(np.tile(mlb, (nb // 4096, 1)))
+    S["FinalExponentiation"] = {"ref": "pairing_test.go:110-131", "cpu_ms_per_op": round(t_fe * 1e3, 4),
+                                "gpu_ms_single_call": round(_best(lambda: engine.final_exponentiation_batch(mlb[:1]), 3) * 1e3, 3),
+                                "gpu_batch_ops_per_s": round(nb / _best(lambda: engine.final_exponentiation_batch(mlb), 2), 1)}
+    S["Pairing"] = {"ref": "pairing_test.go:133-152", "cpu_ms_per_op": round(t_pair * 1e3, 4),
+                    "gpu_ms_single_call": round(_best(lambda: engine.pairing_batch(p1, q1, 1), 3) * 1e3, 3),
+                    "gpu_batch_ops_per_s": round(nb / _best(lambda: engine.pairing_batch(G1, G2, nb), 2), 1)}
+    # ---- g2pubs/bls_test.go:215-256
+    msg = b">16 character identical message"
+    pk = RC.g2pubs.priv_to_pub(sk[5]); sig = RC.g2pubs.sign(msg, sk[5])
+    t_ver = _best(lambda: RC.g2pubs.verify(msg, pk, sig), 3)
+    t_sign = _best(lambda: RC.g2pubs.sign(b"Hello world! 16 characters 7", sk[6]), 3)
+    t_add = _best(lambda: RC.g1_sum(sig + sig, 2), 5)
+    msgs = [b"Hello world! 16 characters %d" % i for i in range(nb)]
+    h = engine.hash_g1_batch(msgs)
+    sigs, _ = engine.g1_mul_batch(h.reshape(-1), b"".join(sk) * (nb // 256), nb)
+    pks = np.ascontiguousarray(np.tile(engine.g2_mul_batch(g2gen * 256, b"".join(sk), 256)[0], (nb // 256, 1))).reshape(-1)
+    assert engine.g2pubs_verify_batch([msg], pk, sig)[0][0] and engine.g2pubs_verify_batch(msgs[:4], pks[:4 * 192], sigs[:4].reshape(-1))[0].all()
+    S["BLSVerify"] = {"ref": "g2pubs/bls_test.go:244-256", "cpu_ms_per_op": round(t_ver * 1e3, 4),
+                      "gpu_ms_single_call": round(_best(lambda: engine.g2pubs_verify_batch([msg], pk, sig), 5) * 1e3, 3),
+                      "gpu_batch_ops_per_s": round(nb / _best(lambda: engine.g2pubs_verify_batch(msgs, pks, sigs.reshape(-1)), 2), 1)}
+
+    def sign_batch(ms, sks):                              # g2pubs.Sign = sk * HashG1(m) (g2pubs/bls.go:132-135), both steps on the device
+        hh = engine.hash_g1_batch(ms)
+        return engine.g1_mul_batch(hh.reshape(-1), sks, len(ms))
+    S["BLSSign"] = {"ref": "g2pubs/bls_test.go:227-242", "cpu_ms_per_op": round(t_sign * 1e3, 4),
+                    "gpu_ms_single_call": round(_best(lambda: sign_batch(msgs[:1], sk[6]), 3) * 1e3, 3),
+                    "gpu_batch_ops_per_s": round(nb / _best(lambda: sign_batch(msgs, b"".join(sk) * (nb // 256)), 2), 1)}
+    S["BLSAggregateSignature"] = {"ref": "g2pubs/bls_test.go:215-225", "cpu_ms_per_op": round(t_add / 2 * 1e3, 5), "cpu_note": "one Jacobian addition (two per timed call incl. the affine conversion)",
+                                  "gpu_batch_ops_per_s": round(nb / _best(lambda: engine.g1_sum(sigs.reshape(-1), nb), 2), 1), "gpu_note": "tree sum of 65 536 signatures in one call"}
+    # ---- g1pubs/verify_benchmark_test.go:15-85
+    dom = bytes([42, 0, 0, 0, 0, 0, 0, 0])
+    m32 = b"Some msg".ljust(32, b"\0")
+    pk1 = RC.g1pubs.priv_to_pub(sk[9]); sg1 = RC.g1pubs.sign_with_domain(m32, sk[9], dom)
+    t_vwd = _best(lambda: RC.g1pubs.verify_with_domain(m32, pk1, sg1, dom), 3)
+    assert engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sg1)[0]
+    S["VerifyWithDomain"] = {"ref": "g1pubs/verify_benchmark_test.go:15-31", "cpu_ms_per_op": round(t_vwd * 1e3, 4),
+                             "gpu_ms_single_call": round(_best(lambda: engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sg1), 5) * 1e3, 3)}
+    nsig = 128
+    mc = b"Some message".ljust(32, b"\0")
+    pk128 = [RC.g1pubs.priv_to_pub(s) for s in sk[:nsig]]
+    sig_c = RC.g2_sum(b"".join(RC.g1pubs.sign_with_domain(mc, s, dom) for s in sk[:nsig]), nsig)
+    t_vac = _best(lambda: RC.g1pubs.verify_aggregate_common_with_domain(sig_c, pk128, mc, dom), 2)
+    assert engine.g1pubs_verify_aggregate_common_with_domain(mc, dom, b"".join(pk128), sig_c, nsig) is True
+    S["VerifyAggregateCommonWithDomain_128"] = {"ref": "g1pubs/verify_benchmark_test.go:33-56", "cpu_ms_per_op": round(t_vac * 1e3, 3),
+                                                "gpu_ms_single_call": round(_best(lambda: engine.g1pubs_verify_aggregate_common_with_domain(mc, dom, b"".join(pk128), sig_c, nsig), 3) * 1e3, 3)}
+    mm = [(b"Some message %d" % i).ljust(32, b"\0") for i in range(nsig)]
+    sig_m = RC.g2_sum(b"".join(RC.g1pubs.sign_with_domain(m, s, dom) for m, s in zip(mm, sk[:nsig])), nsig)
+    t_vam = _best(lambda: RC.g1pubs.verify_aggregate_with_domain(sig_m, pk128, mm, dom), 1)
+    assert engine.g1pubs_verify_aggregate_with_domain(mm, dom, b"".join(pk128), sig_m) is True
+    S["VerifyAggregateMultipleWithDomain_128"] = {"ref": "g1pubs/verify_benchmark_test.go:58-85", "cpu_ms_per_op": round(t_vam * 1e3, 3),
+                                                  "gpu_ms_single_call": round(_best(lambda: engine.g1pubs_verify_aggregate_with_domain(mm, dom, b"".join(pk128), sig_m), 3) * 1e3, 3)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    from bls_amd import engine
+    engine.init(0)
+    print(json.dumps(run(engine), indent=1))

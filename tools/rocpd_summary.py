@@ -17,6 +17,12 @@ def pmcs(db):
            group by s.kernel_name, p.name order by 1, 2"""
     return list(db.execute(q))
 
+import json, re
+counters = {}            # kernel (demangled short name) -> {field: value}: the machine-readable twin of the text summary (bench.py reads it)
+def short(name):
+    m = re.match(r"_Z(\d+)", name)                        # Itanium mangling: _Z<length><identifier><parameters>
+    return name[m.end():m.end() + int(m.group(1))] if m else name.split("(")[0]
+
 out = open(sys.argv[1], "w")
 for path in sys.argv[2:]:
     db = sqlite3.connect(path)
@@ -27,6 +33,9 @@ for path in sys.argv[2:]:
     for k in ks:
         if k[5] / tot < 0.002: continue
         out.write("%-52s %6d %12.0f %12d %12d %6.2f%% %5d %5d %5d %8d %8d\n" % (k[0][:52], k[1], k[2], k[3], k[4], 100.0 * k[5] / tot, k[6], k[7], k[8], k[9], k[10]))
+        if "kt" in path.split("/")[-1] or "prof_" in path:
+            c = counters.setdefault(short(k[0]), {})
+            c.update(calls=k[1], avg_ns=k[2], min_ns=k[3], vgpr_rocprof=k[6], agpr=k[7], sgpr=k[8], scratch_bytes_per_lane=k[9], grid=k[10])
     pm = pmcs(db)
     if pm:
         out.write("-- PMC (per-dispatch average, summed over instances/XCDs as stored)\n")
@@ -38,6 +47,13 @@ for path in sys.argv[2:]:
             out.write("%s (dispatches=%d)\n" % (kn[:70], n_disp))
             for pn, c, av, sm in rows:
                 out.write("    %-28s samples=%-6d sum/dispatch=%.6g\n" % (pn, c, sm / n_disp))
+                counters.setdefault(short(kn), {})[pn] = sm / n_disp
+                grid = [k[10] for k in ks if k[0] == kn]
+                if grid: counters[short(kn)].setdefault("pmc_grid", grid[0])
     out.write("\n")
 out.close()
+jpath = sys.argv[1].rsplit(".", 1)[0].replace("_rocprof_summary", "") + "_counters.json"
+json.dump({"note": "per-kernel averages per dispatch from rocprofv3 (kernel trace + separate --pmc passes; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them); written by tools/rocpd_summary.py",
+           "kernels": {k: v for k, v in counters.items() if k.startswith("k_")}}, open(jpath, "w"), indent=1, sort_keys=True)
 print(open(sys.argv[1]).read())
+print("wrote", jpath)
