@@ -12,7 +12,8 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 # translation units of libblsmi.so: the host side + one unit per kernel family, compiled in parallel
-_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_pairing_single.hip", "k_hash.hip", "k_curve.hip"]
+_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_pairing_single.hip", "k_hash.hip", "k_curve.hip", "k_lat.hip"]
+LAT_BIN = os.path.join(CSRC, "lat_programs.bin")          # level programs of the latency path (gen_lat.py), embedded into blsmi.hip.o
 BUILD_DIR = os.path.join(CSRC, "build")
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 
@@ -36,6 +37,8 @@ def _unit_stale(unit):
     deps = _deps(unit)
     if deps is None:
         return True
+    if unit == "blsmi.hip":
+        deps = deps + [LAT_BIN]                           # .incbin: not in the compiler's depfile
     t = os.path.getmtime(obj)
     return any(os.path.getmtime(x) > t for x in deps)
 
@@ -58,6 +61,9 @@ def build(force=False, verbose=False):
     gen = os.path.join(CSRC, "gen_consts.py")
     if not os.path.exists(consts) or os.path.getmtime(gen) > os.path.getmtime(consts):
         subprocess.check_call(["python3", gen])
+    genlat = os.path.join(CSRC, "gen_lat.py")
+    if not os.path.exists(LAT_BIN) or os.path.getmtime(genlat) > os.path.getmtime(LAT_BIN):
+        subprocess.check_call(["python3", genlat])
     if not force and not _stale():
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -68,6 +74,8 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(BUILD_DIR, u + ".o")
         cmd = [hipcc] + _FLAGS + ["-c", "-MD", "-MF", os.path.join(BUILD_DIR, u + ".d"), "-o", obj, os.path.join(CSRC, u)]
+        if u == "blsmi.hip":
+            cmd.insert(1, '-DBLSMI_LAT_BIN="%s"' % LAT_BIN)
         if verbose:
             print(" ".join(cmd))
         procs.append((u, subprocess.Popen(cmd)))

@@ -3,6 +3,7 @@
 // kernels.h; the verify-path host code is in verify_host.inc.
 #include "../../include/blsmi.h"
 #include "kernels.h"
+#include "lat_programs.h"
 #include <mutex>
 #include <condition_variable>
 #include <chrono>
@@ -21,6 +22,12 @@
 #include <atomic>
 #include <thread>
 #include <random>
+
+// The level programs of the latency path (gen_lat.py -> lat_programs.bin), embedded in the host object.
+#if !defined(__HIP_DEVICE_COMPILE__)
+__asm__(".section .rodata\n.balign 256\n.global blsmi_lat_blob\n.hidden blsmi_lat_blob\nblsmi_lat_blob:\n.incbin \"" BLSMI_LAT_BIN "\"\n.previous\n");
+#endif
+extern "C" const unsigned char blsmi_lat_blob[];
 
 namespace {
 // Host state.  The library drives a LIST of devices from one process (blsmi_init_devices; blsmi_init binds a single one).
@@ -63,7 +70,7 @@ struct Ctx {
 constexpr int MAX_CTX = 16;
 constexpr int MAX_DEV = 16;
 // G1/G2 generators in wire form and the generator's prepared lines, written once per device at init (read-only afterwards)
-struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; };
+struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; u8* lat = nullptr; };   // lat: the latency-path programs (k_lat.hip)
 struct Device {
     int id = -1;                        // HIP device ordinal
     int index = 0;                      // position in g_dev
@@ -127,10 +134,16 @@ int init_device(Device& d) {            // caller holds g_mu
         HIPCHK(hipMalloc((void**)&d.gens.lines, sizeof(i32) * 68 * 3 * 2 * NL));
         hipLaunchKernelGGL(k_prepare_generator_lines, dim3(1), dim3(WG), 0, nullptr, (const u8*)d.gens.g2, d.gens.lines);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipMalloc((void**)&d.gens.lat, LAT_TOTAL_BYTES));
+        HIPCHK(hipMemcpy(d.gens.lat, blsmi_lat_blob, LAT_TOTAL_BYTES, hipMemcpyHostToDevice));
         HIPCHK(hipDeviceSynchronize());
     }
     return BLSMI_OK;
 }
+// Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
+// (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
+size_t g_lat_max = 4096;                // BLSMI_LAT_MAX, blsmi_set_latency_threshold
+inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
     if (g_ready) return BLSMI_OK;
@@ -146,6 +159,7 @@ int ensure_init_list(const int* devs, int ndev) {
     if (const char* ns = getenv("BLSMI_STREAMS")) { int v = atoi(ns); g_nctx = v < 1 ? 1 : (v > MAX_CTX ? MAX_CTX : v); }
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
+    if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
     for (int i = 0; i < ndev; i++) {
         g_dev[i].id = devs[i]; g_dev[i].index = i;
@@ -329,7 +343,7 @@ BLSMI_API void blsmi_shutdown(void) {
             (void)hipStreamDestroy(c.stream);
             c.stream = nullptr;
         }
-        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); dv.gens = Gens{}; }
+        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); (void)hipFree(dv.gens.lat); dv.gens = Gens{}; }
         hipMemPool_t pool;
         if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     }
@@ -342,6 +356,14 @@ BLSMI_API const char* blsmi_version(void) { return g_version; }
 // ---- pairing ------------------------------------------------------------------------------------
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;
+    if (mode == 0 && n <= g_lat_max) {                                     // small call: one pairing per wave (k_lat.hip)
+        hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(LAT_PAIRING1_OFFSET), s, (const u8*)g_gens.lat + LAT_PAIRING1_OFFSET,
+                           (const u8*)d_g1, (size_t)96, (const u8*)d_g2, (size_t)192, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                           (const u8*)nullptr, (u8*)nullptr, (u64*)d_out, n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return BLSMI_OK;
+    }
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
     const bool prof = g_profile.load();
@@ -364,6 +386,12 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
 }
 // Enable/disable per-kernel HIP-event timing of blsmi_pairing_batch[_dev]; read back (by the calling thread, for its own
 // last call) with blsmi_last_kernel_ms.
+// Batches of at most `max_tuples` tuples take the latency path (one tuple per wave, k_lat.hip); 0 switches it off.
+BLSMI_API int blsmi_set_latency_threshold(size_t max_tuples) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_lat_max = max_tuples;
+    return BLSMI_OK;
+}
 BLSMI_API int blsmi_set_profiling(int on) {
     g_profile.store(on != 0);
     return BLSMI_OK;

@@ -1,0 +1,710 @@
+#!/usr/bin/env python3
+"""gen_lat.py -- programs of the LATENCY path (k_lat.hip): one pairing / one Verify spread across a whole wave.
+
+The throughput kernels give every (message, key, signature) tuple one lane pair, so a call costs the time one lane pair
+needs to walk the whole path (~15 ms) however few tuples it carries.  The Go API is one tuple per call
+(g2pubs/bls.go:159-162), so small calls get a different decomposition: ONE tuple per 64-lane wave, the tuple's field
+elements staged in LDS, and the pairing written as a straight-line program of LEVELS.  In a level every lane executes
+the same code on its own job:
+
+    MUL   S[dst] = montmul( sum_i cx_i S[sx_i] , sum_j cy_j S[sy_j] )        one Fq Montgomery product per lane
+    LIN   S[dst] = normalise( sum_i c_i S[s_i] )  (value-reduced when asked)   recombination of products
+    INV   S[dst] = 1 / S[s]                                                    (one lane; safegcd)
+    LOAD  S[dst] = input record element           OUT / CHECK: results leave LDS
+
+S = LDS slots of one Fq each (15 signed 27-bit limbs, Montgomery R = 2^405, the representation of fp.cuh).  This script
+builds the programs: the pairing is written below in a small symbolic tower DSL (Fq values are integer linear
+combinations of job results), every product becomes a MUL job, the combinations between products are folded into the
+operand gathers or, when they get long / large, materialised by LIN jobs; jobs are levelled as-soon-as-possible into
+64-lane levels, LDS slots are allocated by live range.  The limb / value bounds that fp.cuh tracks in its types are
+tracked here per linear combination (L = sum |c|, V = sum |c| V_node) and enforced when a job is emitted.
+
+The same file holds an exact big-integer simulator of the level programs (slot reuse included); tests/test_lat_program.py
+runs it against the oracle, and the GPU tests run the real kernel against the oracle.
+
+Reference path this replaces for small calls: MillerLoop (pairing.go:16-75), FinalExponentiation (pairing.go:79-129),
+CompareTwoPairings (pairing.go:140-147).  The Miller loop here uses homogeneous projective doubling / mixed addition
+(depth-2 recurrences instead of the depth-3 Jacobian steps of g2.go:655-772); its value differs from the reference's
+Miller value by a factor in Fq2*, which the final exponentiation removes: FinalExponentiation(MillerLoop) -- the only
+thing that leaves this path -- is the same field element, bit for bit.
+"""
+import struct
+import sys
+
+Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+X_ABS = 0xd201000000010000
+NLIMB, LB = 15, 27
+RMONT = 1 << (NLIMB * LB)
+
+# job / level kinds (shared with k_lat.hip)
+K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1 = 0, 1, 2, 3, 4, 5
+LANES = 64
+TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
+TLIN = 14             # terms of a LIN job (both operand fields)
+LPROD_MAX = 33        # fp.cuh: 15*(La*Lb+1)*2^54 < 2^63
+LMAX = 15             # fp.cuh: L*(2^27+64) < 2^31
+VPROD_MAX = 1 << 23
+V_REDUCE_AT = 512     # a LIN result whose value bound would exceed this is value-reduced (fp_reduce -> V = 3)
+CMAX = 15             # |coefficient| of a gathered term
+
+
+class Node:
+    __slots__ = ("id", "kind", "x", "y", "V", "level", "slot", "last", "aux", "reduce", "pin")
+
+    def __init__(self, nid, kind, x=None, y=None, V=2, aux=None):
+        self.id, self.kind, self.x, self.y, self.V, self.aux = nid, kind, x, y, V, aux
+        self.level = self.slot = None
+        self.last = -1
+        self.reduce = False
+        self.pin = False
+
+
+class Lin(dict):
+    """integer linear combination of nodes: {node: coefficient}"""
+
+    def __add__(self, o):
+        r = Lin(self)
+        for k, c in o.items():
+            v = r.get(k, 0) + c
+            if v:
+                r[k] = v
+            else:
+                r.pop(k, None)
+        return r
+
+    def __neg__(self):
+        return Lin({k: -c for k, c in self.items()})
+
+    def __sub__(self, o):
+        return self + (-o)
+
+    def scale(self, s):
+        return Lin({k: c * s for k, c in self.items()}) if s else Lin()
+
+    def L(self):
+        return sum(abs(c) for c in self.values())
+
+    def V(self):
+        return sum(abs(c) * k.V for k, c in self.items())
+
+    def cmax(self):
+        return max((abs(c) for c in self.values()), default=0)
+
+
+class Builder:
+    def __init__(self):
+        self.nodes = []
+        self.consts = {}
+        self.inputs = []
+        self.out = None
+
+    def _node(self, kind, x=None, y=None, V=2, aux=None):
+        n = Node(len(self.nodes), kind, x, y, V, aux)
+        self.nodes.append(n)
+        return n
+
+    def const(self, v):
+        v %= Q
+        if v not in self.consts:
+            self.consts[v] = self._node("const", V=1, aux=v)
+        return Lin({self.consts[v]: 1})
+
+    def inp(self, buf, elem, name=""):
+        n = self._node("in", V=1, aux=(buf, elem))
+        self.inputs.append(n)
+        return Lin({n: 1})
+
+    # ---- materialisation ----------------------------------------------------------------------------------------
+    def lin(self, x, force_reduce=False):
+        """S = normalise(x): a node again (L = 1)."""
+        if len(x) == 1 and not force_reduce:
+            (k, c), = x.items()
+            if c == 1:
+                return Lin(x)
+        while len(x) > TLIN or x.L() > LMAX or x.cmax() > CMAX:
+            # too long / too large for one gather: materialise a chunk that satisfies the limits, keep the rest
+            chunk, rest, l = Lin(), Lin(), 0
+            for k, c in sorted(x.items(), key=lambda kc: -abs(kc[1])):
+                take = max(-CMAX, min(CMAX, c))
+                if len(chunk) < TLIN and l + abs(take) <= LMAX:
+                    chunk[k] = take; l += abs(take)
+                    if c != take:
+                        rest[k] = c - take
+                else:
+                    rest[k] = c
+            assert chunk
+            x = rest + self.lin(chunk)
+        red = force_reduce or x.V() > V_REDUCE_AT
+        n = self._node("lin", x=Lin(x), V=3 if red else x.V())
+        n.reduce = red
+        return Lin({n: 1})
+
+    def fit(self, x, tmax):
+        if len(x) > tmax or x.cmax() > CMAX or x.L() > LMAX:
+            return self.lin(x)
+        return x
+
+    def mul(self, x, y):
+        if not x or not y:
+            return Lin()
+        x, y = self.fit(x, TMAX), self.fit(y, TMAX)
+        while x.L() * y.L() > LPROD_MAX or x.V() * y.V() > VPROD_MAX:
+            if x.L() >= y.L() and (len(x) > 1 or x.L() > 1):
+                x = self.lin(x, force_reduce=x.V() > 2896)
+            elif len(y) > 1 or y.L() > 1:
+                y = self.lin(y, force_reduce=y.V() > 2896)
+            else:
+                x = self.lin(x, force_reduce=True); y = self.lin(y, force_reduce=True)
+        return Lin({self._node("mul", x=x, y=y, V=2): 1})
+
+    def inv(self, x):
+        x = self.lin(x, force_reduce=True) if (len(x) != 1 or x.L() != 1) else x
+        return Lin({self._node("inv", x=x, V=2): 1})
+
+
+# ---- tower over Lin (Fq2 = (c0, c1), Fq6 = (a0, a1, a2) of Fq2, Fq12 = (c0, c1) of Fq6) ---------------------------
+class Tower:
+    def __init__(self, b):
+        self.b = b
+        self.frob_c1 = [self.k2(f2pow((1, 1), (Q**k - 1) // 3)) for k in range(6)]
+        self.frob_c2 = [self.k2(f2pow((1, 1), (2 * Q**k - 2) // 3)) for k in range(6)]
+        self.frob12_k = [self.k2(f2pow((1, 1), (Q**k - 1) // 6)) for k in range(12)]
+
+    def k2(self, v):
+        return (self.b.const(v[0]) if v[0] % Q else Lin(), self.b.const(v[1]) if v[1] % Q else Lin())
+
+    # Fq2
+    @staticmethod
+    def add2(a, b): return (a[0] + b[0], a[1] + b[1])
+    @staticmethod
+    def sub2(a, b): return (a[0] - b[0], a[1] - b[1])
+    @staticmethod
+    def neg2(a): return (-a[0], -a[1])
+    @staticmethod
+    def sc2(a, s): return (a[0].scale(s), a[1].scale(s))
+    @staticmethod
+    def nr2(a): return (a[0] - a[1], a[0] + a[1])                   # * (1 + u)   (fq2.go:41-45)
+    @staticmethod
+    def conj2(a): return (a[0], -a[1])
+
+    def mul2(self, a, b, kar=False):
+        m = self.b.mul
+        if kar:                                                          # fq2.go:116-130
+            p0, p1 = m(a[0], b[0]), m(a[1], b[1])
+            p2 = m(a[0] + a[1], b[0] + b[1])
+            return (p0 - p1, p2 - p0 - p1)
+        return (m(a[0], b[0]) - m(a[1], b[1]), m(a[0], b[1]) + m(a[1], b[0]))
+
+    def sqr2(self, a):                                                   # fq2.go:75-89, the factor 2 rides on an operand
+        m = self.b.mul
+        return (m(a[0] + a[1], a[0] - a[1]), m(a[0].scale(2), a[1]))
+
+    def mul2_fq(self, a, s):
+        return (self.b.mul(a[0], s), self.b.mul(a[1], s))
+
+    def lin2(self, a, force_reduce=False):
+        return (self.b.lin(a[0], force_reduce), self.b.lin(a[1], force_reduce))
+
+    # Fq6
+    def add6(self, a, b): return tuple(self.add2(x, y) for x, y in zip(a, b))
+    def sub6(self, a, b): return tuple(self.sub2(x, y) for x, y in zip(a, b))
+    def neg6(self, a): return tuple(self.neg2(x) for x in a)
+    def nr6(self, a): return (self.nr2(a[2]), a[0], a[1])               # * v   (fq6.go:34-37)
+    def lin6(self, a, fr=False): return tuple(self.lin2(x, fr) for x in a)
+
+    def mul6(self, a, b, kar2=False):                                    # fq6.go:255-292 (Karatsuba over Fq2)
+        M = lambda x, y: self.mul2(x, y, kar2)
+        aa, bb, cc = M(a[0], b[0]), M(a[1], b[1]), M(a[2], b[2])
+        t1 = self.add2(self.nr2(self.sub2(self.sub2(M(self.add2(a[1], a[2]), self.add2(b[1], b[2])), bb), cc)), aa)
+        t3 = self.sub2(self.add2(self.sub2(M(self.add2(a[0], a[2]), self.add2(b[0], b[2])), aa), bb), cc)
+        t2 = self.add2(self.sub2(self.sub2(M(self.add2(a[0], a[1]), self.add2(b[0], b[1])), aa), bb), self.nr2(cc))
+        return (t1, t2, t3)
+
+    def mul6_school(self, a, b):
+        """schoolbook over Fq2 (9 products, no operand sums): small L for operands that are sums already"""
+        M = self.mul2
+        p = [[M(a[i], b[j]) for j in range(3)] for i in range(3)]
+        c0 = self.add2(p[0][0], self.nr2(self.add2(p[1][2], p[2][1])))
+        c1 = self.add2(self.add2(p[0][1], p[1][0]), self.nr2(p[2][2]))
+        c2 = self.add2(self.add2(p[0][2], p[1][1]), p[2][0])
+        return (c0, c1, c2)
+
+    def sqr6(self, a):                                                   # fq6.go:221-252
+        s0 = self.sqr2(a[0]); s1 = self.sc2(self.mul2(a[0], a[1]), 2)
+        s2 = self.sqr2(self.add2(self.sub2(a[0], a[1]), a[2]))
+        s3 = self.sc2(self.mul2(a[1], a[2]), 2); s4 = self.sqr2(a[2])
+        return (self.add2(self.nr2(s3), s0), self.add2(self.nr2(s4), s1),
+                self.sub2(self.sub2(self.add2(self.add2(s1, s2), s3), s0), s4))
+
+    def inv2(self, a):                                                   # fq2.go:133-147
+        a = self.lin2(a)
+        n = self.b.mul(a[0], a[0]) + self.b.mul(a[1], a[1])
+        t = self.b.inv(n)
+        return (self.b.mul(a[0], t), -self.b.mul(a[1], t))
+
+    def inv6(self, a):                                                   # fq6.go:295-336
+        a = self.lin6(a)
+        c0 = self.lin2(self.sub2(self.sqr2(a[0]), self.nr2(self.mul2(a[1], a[2]))))
+        c1 = self.lin2(self.sub2(self.nr2(self.sqr2(a[2])), self.mul2(a[0], a[1])))
+        c2 = self.lin2(self.sub2(self.sqr2(a[1]), self.mul2(a[0], a[2])))
+        t = self.add2(self.nr2(self.add2(self.mul2(a[2], c1), self.mul2(a[1], c2))), self.mul2(a[0], c0))
+        ti = self.lin2(self.inv2(t))
+        return (self.mul2(ti, c0), self.mul2(ti, c1), self.mul2(ti, c2))
+
+    # Fq12
+    def lin12(self, a, fr=False): return (self.lin6(a[0], fr), self.lin6(a[1], fr))
+    def conj12(self, a): return (a[0], self.neg6(a[1]))                 # fq12.go:27-29
+
+    def mul12(self, a, b):                                               # fq12.go:198-213
+        sa, sb = self.lin6(self.add6(a[0], a[1])), self.lin6(self.add6(b[0], b[1]))   # sums first: all 54 products then share one level
+        aa = self.mul6(a[0], b[0], kar2=True)
+        bb = self.mul6(a[1], b[1], kar2=True)
+        t = self.mul6(sa, sb, kar2=True)
+        return self.lin12((self.add6(self.nr6(bb), aa), self.sub6(self.sub6(t, aa), bb)))
+
+    def sqr12(self, a):                                                  # fq12.go:180-195
+        s1 = self.lin6(self.add6(self.nr6(a[1]), a[0])); s2 = self.lin6(self.add6(a[0], a[1]))
+        ab = self.mul6(a[0], a[1], kar2=True)
+        t = self.mul6(s1, s2, kar2=True)
+        return self.lin12((self.sub6(self.sub6(t, ab), self.nr6(ab)), self.add6(ab, ab)))
+
+    def inv12(self, a):                                                  # fq12.go:216-237
+        a = self.lin12(a)
+        t = self.inv6(self.lin6(self.sub6(self.sqr6(a[0]), self.nr6(self.lin6(self.sqr6(a[1]))))))
+        t = self.lin6(t)
+        return self.lin12((self.mul6(t, a[0]), self.neg6(self.mul6(t, a[1]))))
+
+    def frob12(self, a, p):                                              # fq12.go:171-177, fq6.go:211-218, fq2.go:156-158
+        fr2 = (lambda z: self.conj2(z)) if p % 2 else (lambda z: z)
+        def frob6(c):
+            return (fr2(c[0]), self.mul2(fr2(c[1]), self.frob_c1[p % 6]), self.mul2(fr2(c[2]), self.frob_c2[p % 6]))
+        c0 = frob6(a[0]); c1 = self.lin6(frob6(a[1]))
+        k = self.frob12_c(p)
+        return self.lin12((c0, tuple(self.mul2(z, k) for z in c1)))
+
+    def frob12_c(self, p):
+        return self.frob12_k[p % 12]
+
+    def cyc_sqr(self, f):
+        """Granger-Scott squaring on the cyclotomic subgroup (same element as fq12.go:180-195 there): for each Fq4 pair
+        (a, b): a^2 and b^2 by two products each, ab by four; every output is ONE linear job of <= 6 terms, L <= 14."""
+        z0, z4, z3 = f[0]; z2, z1, z5 = f[1]
+        def fp4(a, b):
+            a2, b2 = self.sqr2(a), self.sqr2(b)
+            v3 = self.mul2(self.sc2(a, 3), b)                             # 3ab: the factor of the outputs rides on an operand
+            return self.add2(a2, self.nr2(b2)), v3                        # (a^2 + xi b^2, 3ab)
+        a0, a1 = fp4(z0, z1); b0, b1 = fp4(z2, z3); c0, c1 = fp4(z4, z5)
+        L2 = lambda t: self.lin2(t, False)
+        r00 = L2(self.sub2(self.sc2(a0, 3), self.sc2(z0, 2)))
+        r11 = L2(self.add2(self.sc2(a1, 2), self.sc2(z1, 2)))             # 3 * 2ab + 2 z1
+        r01 = L2(self.sub2(self.sc2(b0, 3), self.sc2(z4, 2)))
+        r12 = L2(self.add2(self.sc2(b1, 2), self.sc2(z5, 2)))
+        r10 = L2(self.add2(self.sc2(self.nr2(c1), 2), self.sc2(z2, 2)))   # 3 xi (2ab) + 2 z2
+        r02 = L2(self.sub2(self.sc2(c0, 3), self.sc2(z3, 2)))
+        return ((r00, r01, r02), (r10, r11, r12))
+
+    def mul12_sparse5(self, f, l0, l1, l2, l4, l5):
+        """f * (l0 + l1 v + l2 v^2 + (l4 v + l5 v^2) w)  (the product of two line values, tower_body.inc:fp12_mul_by_line_pair)"""
+        m0 = (l0, l1, l2)
+        m01 = self.lin6((l0, self.add2(l1, l4), self.add2(l2, l5)))
+        fs = self.lin6(self.add6(f[0], f[1]))
+        t0 = self.mul6(f[0], m0, kar2=True)
+        # (a0 + a1 v + a2 v^2)(b1 v + b2 v^2)
+        a = f[1]
+        p11, p22 = self.mul2(a[1], l4, True), self.mul2(a[2], l5, True)
+        cross = self.sub2(self.sub2(self.mul2(self.add2(a[1], a[2]), self.add2(l4, l5), True), p11), p22)
+        t1 = (self.nr2(cross), self.add2(self.mul2(a[0], l4, True), self.nr2(p22)), self.add2(self.mul2(a[0], l5, True), p11))
+        t2 = self.mul6(fs, m01, kar2=True)
+        return self.lin12((self.add6(self.nr6(t1), t0), self.sub6(self.sub6(t2, t0), t1)))
+
+    def mul12_by_014(self, f, c0, c1, c4):                               # fq12.go:32-47
+        def by01(a, k0, k1):
+            aa, bb = self.mul2(a[0], k0, True), self.mul2(a[1], k1, True)
+            t1 = self.add2(self.nr2(self.sub2(self.mul2(k1, self.add2(a[1], a[2]), True), bb)), aa)
+            t3 = self.add2(self.sub2(self.mul2(k0, self.add2(a[0], a[2]), True), aa), bb)
+            t2 = self.sub2(self.sub2(self.mul2(self.add2(k0, k1), self.add2(a[0], a[1]), True), aa), bb)
+            return (t1, t2, t3)
+        def by1(a, k1):
+            bb = self.mul2(a[1], k1, True)
+            t1 = self.nr2(self.sub2(self.mul2(k1, self.add2(a[1], a[2]), True), bb))
+            t2 = self.sub2(self.mul2(k1, self.add2(a[0], a[1]), True), bb)
+            return (t1, t2, bb)
+        fs, c14 = self.lin6(self.add6(f[1], f[0])), self.lin2(self.add2(c1, c4))
+        aa = by01(f[0], c0, c1); bb = by1(f[1], c4)
+        t = by01(fs, c0, c14)
+        return self.lin12((self.add6(self.nr6(bb), aa), self.sub6(self.sub6(t, aa), bb)))
+
+    def line_pair(self, a, b):
+        """product of two line values a0 + a1 v + a4 v w (given as (c0, c1, c4)): five coefficients l0, l1, l2, l4, l5"""
+        M = lambda x, y: self.mul2(x, y, True)
+        p00, p11, p44 = M(a[0], b[0]), M(a[1], b[1]), M(a[2], b[2])
+        l0 = self.add2(p00, self.nr2(p44))
+        l1 = self.sub2(self.sub2(M(self.add2(a[0], a[1]), self.add2(b[0], b[1])), p00), p11)
+        l4 = self.sub2(self.sub2(M(self.add2(a[0], a[2]), self.add2(b[0], b[2])), p00), p44)
+        l5 = self.sub2(self.sub2(M(self.add2(a[1], a[2]), self.add2(b[1], b[2])), p11), p44)
+        return tuple(self.lin2(z) for z in (l0, l1, p11, l4, l5))
+
+
+def f2mul(a, b): return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+def f2pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1: r = f2mul(r, a)
+        a = f2mul(a, a); e >>= 1
+    return r
+
+
+# ---- pairing programs ------------------------------------------------------------------------------------------------
+B_TWIST = (4, 4)                       # E': y^2 = x^3 + 4(1 + u)   (g2.go:12-16)
+
+
+class Pairing:
+    def __init__(self, b):
+        self.b = b
+        self.T = Tower(b)
+        self.b3 = self.T.k2(f2mul((3, 0), B_TWIST))          # 3 b'
+
+    def dbl_step(self, R):
+        """homogeneous projective doubling on E' (y^2 = x^3 + b', b' = 4 xi) and the tangent line at R, as (c0, o1, o0) of the
+        line value c0 + (o1 xP) v + (o0 yP) v w (the 0/1/4 coefficients of pairing.go:28-39):
+            A = XY, B = Y^2, E = 3 b' Z^2 = 12 xi Z^2, H = 2YZ, F = 3E, G = B + F
+            X3 = 2 A (B - F),  Y3 = G^2 - 12 E^2,  Z3 = 4 B H          line: (B - E) - 3 X^2 xP v + H yP v w
+        Two product levels deep.  E comes straight out of the first level: 12 (z0+z1)(z0-z1) and 24 z0 z1 are products of
+        scaled operands, (z0+z1) and (z0-z1) having been materialised together with Z."""
+        T, m = self.T, self.b.mul
+        X, Y, Z, zs, zd = R
+        A = T.mul2(X, Y)
+        Bq = T.sqr2(Y); X2 = T.sqr2(X)
+        H = T.sc2(T.mul2(Y, Z), 2)
+        p12 = m(zs.scale(4), zd.scale(3)); r24 = m(Z[0].scale(4), Z[1].scale(6))
+        E = (p12 - r24, p12 + r24)                                    # 12 xi Z^2
+        F = T.sc2(E, 3)
+        G = T.add2(Bq, F)
+        gs, gd = self.b.lin(G[0] + G[1]), self.b.lin(G[0] - G[1])
+        Gl = T.lin2(G)
+        X3 = T.mul2(T.sc2(A, 2), T.sub2(Bq, F))
+        G2 = (m(gs, gd), m(Gl[0].scale(2), Gl[1]))
+        Y3 = T.sub2(G2, T.sc2(T.sqr2(E), 12))
+        Z3 = T.mul2(T.sc2(Bq, 4), H)
+        Z3l = T.lin2(Z3)
+        line = (T.lin2(T.sub2(Bq, E)), T.sc2(X2, -3), H)
+        return (T.lin2(X3), T.lin2(Y3), Z3l, self.b.lin(Z3[0] + Z3[1]), self.b.lin(Z3[0] - Z3[1])), line
+
+    def add_step(self, R, Qa):
+        """mixed addition R + Q (Q affine) and the chord through R and Q"""
+        T = self.T
+        X, Y, Z = R[0], R[1], R[2]
+        xq, yq = Qa
+        th = T.lin2(T.sub2(Y, T.mul2(yq, Z))); la = T.lin2(T.sub2(X, T.mul2(xq, Z)))
+        C = T.lin2(T.sqr2(th)); D = T.lin2(T.sqr2(la))
+        E = T.lin2(T.mul2(la, D)); F = T.lin2(T.mul2(Z, C)); G = T.lin2(T.mul2(X, D))
+        Hh = T.lin2(T.sub2(T.add2(E, F), T.sc2(G, 2)))
+        X3 = T.mul2(la, Hh)
+        Y3 = T.sub2(T.mul2(th, T.lin2(T.sub2(G, Hh))), T.mul2(E, Y))
+        Z3 = T.mul2(Z, E)
+        line = (T.lin2(T.sub2(T.mul2(th, xq), T.mul2(la, yq))), T.neg2(th), la)
+        return (T.lin2(X3), T.lin2(Y3), T.lin2(Z3), self.b.lin(Z3[0] + Z3[1]), self.b.lin(Z3[0] - Z3[1])), line
+
+    def eval_line(self, line, P):
+        """(c0, o1, o0) at P = (xP, yP): the 014 element (c0, o1 xP, o0 yP)"""
+        T = self.T
+        return (line[0], T.lin2(T.mul2_fq(line[1], P[0])), T.lin2(T.mul2_fq(line[2], P[1])))
+
+    def miller(self, pairs):
+        """prod_k MillerLoop(P_k, Q_k) for 1 or 2 pairs: g <- g^2 * lines, lines of a step multiplied together first"""
+        T = self.T
+        one = self.b.const(1)
+        Rs = [(q[0], q[1], (one, Lin()), one, one) for _, q in pairs]            # (X, Y, Z, z0 + z1, z0 - z1) with Z = 1
+        g = None
+        xr = X_ABS >> 1
+
+        def absorb(g, lines, square):
+            if len(lines) == 2:
+                m = T.line_pair(lines[0], lines[1])
+                if g is None:
+                    z = (Lin(), Lin())
+                    return ((m[0], m[1], m[2]), (z, m[3], m[4]))
+                if square:
+                    g = T.sqr12(g)
+                return T.mul12_sparse5(g, *m)
+            l = lines[0]
+            if g is None:
+                z = (Lin(), Lin())
+                return ((l[0], l[1], z), (z, l[2], z))
+            if square:
+                g = T.sqr12(g)
+            return T.mul12_by_014(g, l[0], l[1], l[2])
+
+        steps = []
+        for i in range(61, -1, -1):
+            steps.append("dbl")
+            if (xr >> i) & 1:
+                steps.append("add")
+        steps.append("dbl")
+        # g_k = g_{k-1}^2 * l_k for doubling steps (the reference's f <- (f l)^2 shifted by one, same sequence of values up to
+        # the last squaring it does not do either), g_k = g_{k-1} * l_k for addition steps
+        for s in steps:
+            lines = []
+            for k, (P, Qa) in enumerate(pairs):
+                Rs[k], ln = (self.dbl_step(Rs[k]) if s == "dbl" else self.add_step(Rs[k], Qa))
+                lines.append(self.eval_line(ln, P))
+            g = absorb(g, lines, square=(s == "dbl"))
+        return T.conj12(g)                                          # x < 0 (pairing.go:71-73)
+
+    def exp_by_x(self, f, e):                                          # pairing.go:92-98
+        T = self.T
+        res = f
+        for i in range(e.bit_length() - 2, -1, -1):
+            res = T.cyc_sqr(res)
+            if (e >> i) & 1:
+                res = T.mul12(res, f)
+        return T.conj12(res)
+
+    def final_exp(self, r):                                            # pairing.go:79-129 (same chain, same power 3 (q^12 - 1) / r)
+        T = self.T
+        r = T.lin12(r, True)
+        f2 = T.inv12(r)
+        r = T.mul12(T.conj12(r), f2)
+        f2 = T.frob12(r, 2)
+        r = T.mul12(f2, r)
+        x = X_ABS
+        y0 = T.cyc_sqr(r)
+        y1 = self.exp_by_x(y0, x)
+        y2 = self.exp_by_x(y1, x >> 1)
+        y3 = T.conj12(r)
+        y1 = T.mul12(y1, y3)
+        y1 = T.conj12(y1)
+        y1 = T.mul12(y1, y2)
+        y2 = self.exp_by_x(y1, x)
+        y3 = self.exp_by_x(y2, x)
+        y1 = T.conj12(y1)
+        y3 = T.mul12(y3, y1)
+        y1 = T.conj12(y1)
+        y1 = T.frob12(y1, 3)
+        y2 = T.frob12(y2, 2)
+        y1 = T.mul12(y1, y2)
+        y2 = self.exp_by_x(y3, x)
+        y2 = T.mul12(y2, y0)
+        y2 = T.mul12(y2, r)
+        y1 = T.mul12(y1, y2)
+        y3 = T.frob12(y3, 1)
+        return T.mul12(y1, y3)
+
+
+def flat12(f):
+    return [f[0][0][0], f[0][0][1], f[0][1][0], f[0][1][1], f[0][2][0], f[0][2][1],
+            f[1][0][0], f[1][0][1], f[1][1][0], f[1][1][1], f[1][2][0], f[1][2][1]]
+
+
+def build_program(kind):
+    """kind: 'verify2' -- inputs P0 (buf 0, 2 Fq), Q0 (buf 1, 4 Fq), P1 (buf 2), Q1 (buf 3); verdict = FE(ML((P0,Q0),(-P1,Q1))) == 1
+             'pairing1' -- inputs P (buf 0), Q (buf 1); output FE(ML(P, Q)) as 12 Fq"""
+    b = Builder()
+    pr = Pairing(b)
+    if kind == "verify2":
+        P0 = (b.inp(0, 0), b.inp(0, 1)); Q0 = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        P1 = (b.inp(2, 0), -b.inp(2, 1)); Q1 = ((b.inp(3, 0), b.inp(3, 1)), (b.inp(3, 2), b.inp(3, 3)))
+        f = pr.final_exp(pr.miller([(P0, Q0), (P1, Q1)]))
+        outs = flat12(pr.T.lin12(f, True))
+        b.out = ("check1", outs)
+    else:
+        P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        f = pr.final_exp(pr.miller([(P, Qa)]))
+        outs = flat12(pr.T.lin12(f, True))
+        b.out = ("out12", outs)
+    return b
+
+
+# ---- levelling, slot allocation ---------------------------------------------------------------------------------------
+class Program:
+    pass
+
+
+def schedule(b):
+    """as-soon-as-possible levels of one kind each (<= 64 jobs, INV: 1), then slots by live range.  Dead nodes are dropped."""
+    outs = b.out[1]
+    for o in outs:
+        assert len(o) == 1 and list(o.values()) == [1], "outputs must be materialised"
+    out_nodes = [list(o.keys())[0] for o in outs]
+    # liveness: mark reachable
+    live = set()
+    stack = list(out_nodes)
+    while stack:
+        n = stack.pop()
+        if n.id in live:
+            continue
+        live.add(n.id)
+        for lin in (n.x, n.y):
+            if lin:
+                stack.extend(lin.keys())
+    nodes = [n for n in b.nodes if n.id in live]
+    levels = []                          # [kind, [nodes]]
+    kind_of = {"mul": K_MUL, "lin": K_LIN, "inv": K_INV, "in": K_LOAD}
+    cap = {K_MUL: LANES, K_LIN: LANES, K_INV: 1, K_LOAD: LANES}
+    consts = [n for n in nodes if n.kind == "const"]
+    for n in consts:
+        n.level = -1
+    for n in nodes:
+        if n.kind == "const":
+            continue
+        k = kind_of[n.kind]
+        e = 0
+        for lin in (n.x, n.y):
+            if lin:
+                for d in lin:
+                    e = max(e, d.level + 1)
+        lv = None
+        for i in range(e, len(levels)):
+            if levels[i][0] == k and len(levels[i][1]) < cap[k]:
+                lv = i
+                break
+        if lv is None:
+            levels.append([k, []])
+            lv = len(levels) - 1
+            assert lv >= e
+        levels[lv][1].append(n)
+        n.level = lv
+    nlev = len(levels)
+    # last use
+    for n in nodes:
+        for lin in (n.x, n.y):
+            if lin:
+                for d in lin:
+                    d.last = max(d.last, n.level)
+    for n in out_nodes:
+        n.last = nlev                    # read by the output level
+    # slots: constants first (live for ever), then linear scan; a slot freed at level l (last read at l) is reusable by a
+    # job WRITING at level >= l (reads of a level precede its writes in the wave's program order)
+    nslot = 0
+    for n in consts:
+        n.slot = nslot; nslot += 1
+    free = []
+    expiring = {}
+    for n in nodes:
+        if n.kind != "const":
+            expiring.setdefault(n.last, []).append(n)
+    for li, (k, jobs) in enumerate(levels):
+        for n in expiring.get(li - 1, []):  # values last read in an EARLIER level are dead (a multi-wave workgroup gathers and
+            free.append(n.slot)             # stores of one level without a barrier in between: no reuse within the level)
+        for n in jobs:
+            if free:
+                n.slot = free.pop()
+            else:
+                n.slot = nslot; nslot += 1
+    p = Program()
+    p.levels, p.consts, p.nslot, p.out, p.out_nodes, p.nodes = levels, consts, nslot, b.out[0], out_nodes, nodes
+    return p
+
+
+# ---- exact simulator (field arithmetic on Python integers, slots reused exactly as scheduled) --------------------------
+def simulate(p, inputs):
+    """inputs: {buf: [Fq ints]} -> list of 12 output values (normal form)"""
+    S = [None] * p.nslot
+    for n in p.consts:
+        S[n.slot] = n.aux
+    def ev(lin):
+        return sum(c * S[d.slot] for d, c in lin.items()) % Q
+    for k, jobs in p.levels:
+        res = []
+        for n in jobs:
+            if n.kind == "in":
+                res.append(inputs[n.aux[0]][n.aux[1]] % Q)
+            elif n.kind == "mul":
+                res.append(ev(n.x) * ev(n.y) % Q)
+            elif n.kind == "lin":
+                res.append(ev(n.x))
+            elif n.kind == "inv":
+                v = ev(n.x)
+                res.append(pow(v, -1, Q) if v else 0)
+        for n, r in zip(jobs, res):
+            S[n.slot] = r
+    return [S[n.slot] for n in p.out_nodes]
+
+
+# ---- binary image ---------------------------------------------------------------------------------------------------------
+def mont_limbs(v):
+    v = v * RMONT % Q
+    return [(v >> (LB * i)) & ((1 << LB) - 1) for i in range(NLIMB)]
+
+
+def encode(p):
+    """header: magic, nlevels, nslot, nconst, out kind; per level: kind, ntx, nty, njobs; per (level, lane): 16 x u16
+    [dst, 7 x-terms, 7 y-terms, flags]; term = slot | (coef + 16) << 11; constants: slot + 15 limbs."""
+    assert p.nslot < 2048
+    def term(d, c):
+        assert -CMAX <= c <= CMAX and c != 0
+        return d.slot | ((c + 16) << 11)
+    hdr = []
+    desc = bytearray()
+    NOTERM = 16 << 11                       # coefficient 0, slot 0
+    dummy = p.nslot                         # idle lanes write to a spare slot
+    for k, jobs in p.levels:
+        ntx = nty = 0
+        rows = []
+        for n in jobs:
+            xs = [term(d, c) for d, c in n.x.items()] if n.x else []
+            ys = [term(d, c) for d, c in n.y.items()] if n.y else []
+            flags = 0
+            if k == K_LIN:
+                assert len(xs) <= TLIN
+                xs, ys = xs[:7], xs[7:]
+                flags = 1 if n.reduce else 0
+            elif k == K_LOAD:
+                xs = [n.aux[0] | (n.aux[1] << 4)]; ys = []
+            assert len(xs) <= 7 and len(ys) <= 7
+            ntx, nty = max(ntx, len(xs)), max(nty, len(ys))
+            rows.append([n.slot] + xs + [NOTERM] * (7 - len(xs)) + ys + [NOTERM] * (7 - len(ys)) + [flags])
+        while len(rows) < LANES:
+            rows.append([dummy] + [NOTERM] * 14 + [0])
+        for r in rows:
+            desc += struct.pack("<16H", *r)
+        red = 0x80 if (k == K_LIN and any(n.reduce for n in jobs)) else 0   # value reduction is level-wide (always valid, never needed less)
+        hdr.append((k | red, ntx, nty, len(jobs)))
+    out_kind = K_CHECK1 if p.out == "check1" else K_OUT12
+    blob = bytearray()
+    blob += struct.pack("<8I", 0x54414c42, len(p.levels), p.nslot + 1, len(p.consts), out_kind, 0, 0, 0)
+    blob += struct.pack("<12H", *[n.slot for n in p.out_nodes]) + b"\0" * 8
+    for h in hdr:
+        blob += struct.pack("<4B", *h)
+    while len(blob) % 16:
+        blob += b"\0"
+    for n in p.consts:
+        blob += struct.pack("<16i", *(mont_limbs(n.aux) + [n.slot]))
+    blob += desc
+    return bytes(blob)
+
+
+def stats(p):
+    from collections import Counter
+    c = Counter(k for k, _ in p.levels)
+    jobs = Counter()
+    for k, j in p.levels:
+        jobs[k] += len(j)
+    return "levels=%d (mul %d, lin %d, inv %d, load %d)  jobs: mul %d lin %d  slots=%d consts=%d" % (
+        len(p.levels), c[K_MUL], c[K_LIN], c[K_INV], c[K_LOAD], jobs[K_MUL], jobs[K_LIN], p.nslot, len(p.consts))
+
+
+def main():
+    import pathlib
+    here = pathlib.Path(__file__).resolve().parent
+    sys.setrecursionlimit(100000)
+    out = bytearray()
+    index = []
+    for name in ("verify2", "pairing1"):
+        p = schedule(build_program(name))
+        blob = encode(p)
+        index.append((name, len(out), len(blob)))
+        out += blob
+        while len(out) % 256:
+            out += b"\0"
+        print(name, stats(p), "bytes=%d" % len(blob))
+    (here / "lat_programs.bin").write_bytes(bytes(out))
+    with open(here / "lat_programs.h", "w") as f:
+        f.write("// Generated by gen_lat.py -- offsets of the latency-path programs inside lat_programs.bin\n#pragma once\n")
+        for name, off, ln in index:
+            f.write("#define LAT_%s_OFFSET %d\n#define LAT_%s_BYTES %d\n" % (name.upper(), off, name.upper(), ln))
+        f.write("#define LAT_TOTAL_BYTES %d\n" % len(out))
+
+
+if __name__ == "__main__":
+    main()

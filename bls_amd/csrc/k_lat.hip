@@ -1,0 +1,144 @@
+// k_lat.hip -- the LATENCY path: one pairing / one Verify per 64-lane wave (programs: gen_lat.py).
+//
+// The throughput kernels give each tuple one lane pair; a call then costs what one lane pair needs for the whole path
+// (~15 ms) however few tuples it carries, and the Go API is one tuple per call (g2pubs/bls.go:159-162).  Here a tuple owns
+// a WAVE: its field elements live in LDS slots (15 x 27-bit limbs + 1 pad word = 64 bytes, Montgomery R = 2^405, the
+// representation of fp.cuh) and the wave interprets a straight-line program of levels.  In a level every lane does the
+// same thing to its own job: gather two small signed combinations of slots (ds_read_b128), one Montgomery product (the
+// column-scanning core of fp.cuh), store the result slot -- or, in a LIN level, gather one longer combination and
+// normalise it.  The 54 Fq products of an Fq12 multiplication are one level; the doubling step of the NEXT Miller
+// iteration shares levels with the accumulator update of the current one.  MillerLoop + FinalExponentiation:
+// ~510 product levels + ~820 recombination levels instead of ~14 600 sequential multiplications.
+//
+// Replaces, for small calls: MillerLoop (pairing.go:16-75), FinalExponentiation (pairing.go:79-129), CompareTwoPairings
+// (pairing.go:140-147).  Results leave as the canonical value (verdict byte or the reference's in-memory FQ12), so they
+// are bit-identical to the throughput path's and the reference's.
+#include "tower.cuh"
+#include "device_io.cuh"
+
+namespace {
+constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5;
+constexpr int SLOT_WORDS = 16;
+
+struct LatHeader {                      // gen_lat.py: encode()
+    u32 magic, nlevels, nslot, nconst, out_kind, r0, r1, r2;
+    unsigned short out_slot[12];
+    u8 pad[8];
+};
+
+// x += c * S[slot] over the 15 limbs (the 16th word of a slot is padding); c in [-15, 15]
+BLSMI_DEV void gather_term(const i32* S, u32 term, i32 x[NL]) {
+    const i32 c = (i32)(term >> 11) - 16;
+    const int4* p = reinterpret_cast<const int4*>(S + (term & 0x7ffu) * SLOT_WORDS);
+    const int4 a = p[0], b = p[1], d = p[2], e = p[3];
+    const i32 v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int i = 0; i < NL; i++) x[i] += c * v[i];
+}
+BLSMI_DEV void gather(const i32* S, const u32* terms, int nt, i32 x[NL]) {
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        if (t >= nt) break;                                                // nt is uniform across the wave (level header)
+        gather_term(S, terms[t], x);
+    }
+}
+BLSMI_DEV void store_slot(i32* S, u32 slot, const i32 r[NL]) {
+    int4* p = reinterpret_cast<int4*>(S + slot * SLOT_WORDS);
+    p[0] = make_int4(r[0], r[1], r[2], r[3]); p[1] = make_int4(r[4], r[5], r[6], r[7]);
+    p[2] = make_int4(r[8], r[9], r[10], r[11]); p[3] = make_int4(r[12], r[13], r[14], 0);
+}
+}  // namespace
+
+// bufs: up to four input arrays of affine records (48-byte big-endian field elements), stride 0 = one broadcast record.
+// out_kind CHECK1: ok[t] = (result == 1) && !flags[t];  OUT12: out[t] = the 12 Fq of the result as Montgomery-384 words.
+__global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, size_t s0, const u8* b1, size_t s1, const u8* b2, size_t s2,
+                                                const u8* b3, size_t s3, const u8* flags, u8* ok, u64* out, size_t n) {
+    extern __shared__ int4 lds4[];
+    i32* S = reinterpret_cast<i32*>(lds4);
+    const size_t t = blockIdx.x;
+    if (t >= n) return;
+    const int lane = threadIdx.x;
+    const LatHeader* H = reinterpret_cast<const LatHeader*>(prog);
+    const u32 nlevels = H->nlevels, nconst = H->nconst;
+    const u32* lvl = reinterpret_cast<const u32*>(prog + sizeof(LatHeader));
+    const i32* consts = reinterpret_cast<const i32*>(prog + sizeof(LatHeader) + ((nlevels * 4 + 15) & ~15u));
+    const uint4* desc = reinterpret_cast<const uint4*>(consts + (size_t)nconst * 16);
+    for (u32 k = lane; k < nconst * 16; k += 64) {                           // constants into their slots (word 15 of a record = its slot)
+        const u32 rec = k >> 4, w = k & 15;
+        if (w < 15) S[(u32)consts[rec * 16 + 15] * SLOT_WORDS + w] = consts[k];
+    }
+    __syncthreads();
+    uint4 d0 = desc[(size_t)lane * 2], d1 = desc[(size_t)lane * 2 + 1];
+    for (u32 l = 0; l < nlevels; l++) {
+        const u32 h = lvl[l];
+        const int kind = h & 0x7f, ntx = (h >> 8) & 0xff, nty = (h >> 16) & 0xff, njobs = (int)(h >> 24);
+        const bool reduce = (h & 0x80) != 0;
+        const u32 f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};     // 16 x u16: dst, 7 x-terms, 7 y-terms, flags
+        u32 tx[7], ty[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const int jx = 1 + i, jy = 8 + i;
+            tx[i] = (f[jx >> 1] >> (16 * (jx & 1))) & 0xffffu;
+            ty[i] = (f[jy >> 1] >> (16 * (jy & 1))) & 0xffffu;
+        }
+        const u32 dst = f[0] & 0xffffu;
+        if (l + 1 < nlevels) {                                                 // next level's descriptors while this one computes
+            d0 = desc[((size_t)(l + 1) * 64 + lane) * 2]; d1 = desc[((size_t)(l + 1) * 64 + lane) * 2 + 1];
+        }
+        i32 r[NL];
+        if (kind == K_MUL) {
+            i32 x[NL], y[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) { x[i] = 0; y[i] = 0; }
+            gather(S, tx, ntx, x);
+            gather(S, ty, nty, y);
+            vlimbs vx, vy;
+#pragma unroll
+            for (int i = 0; i < NL; i++) { vx[i] = x[i]; vy[i] = y[i]; }
+            const vlimbs z = fp_mul_body(vx, vy);
+#pragma unroll
+            for (int i = 0; i < NL; i++) r[i] = z[i];
+        } else if (kind == K_LIN) {
+            Fp<LMAX, VMAX> x;
+#pragma unroll
+            for (int i = 0; i < NL; i++) x.v[i] = 0;
+            gather(S, tx, ntx, x.v);
+            gather(S, ty, nty, x.v);
+            if (reduce) { const Fp<1, 3> y = fp_reduce(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
+            else { const auto y = fp_norm(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
+        } else if (kind == K_INV) {
+            Fp<LMAX, VMAX> x;
+#pragma unroll
+            for (int i = 0; i < NL; i++) x.v[i] = 0;
+            gather(S, tx, ntx, x.v);
+            const FpS y = fp_inv(x);                                           // inverse(0) = 0
+#pragma unroll
+            for (int i = 0; i < NL; i++) r[i] = y.v[i];
+        } else {                                                               // K_LOAD: tx[0] = buffer | element << 4
+            const u32 bsel = tx[0] & 15u, el = (tx[0] >> 4) & 0xfffu;
+            const u8* base = bsel == 0 ? b0 + s0 * t : bsel == 1 ? b1 + s1 * t : bsel == 2 ? b2 + s2 * t : b3 + s3 * t;
+            FpS y = fp_zero();
+            if (lane < njobs) y = load_be48(base + 48 * el);
+#pragma unroll
+            for (int i = 0; i < NL; i++) r[i] = y.v[i];
+        }
+        __syncthreads();                                                       // one wave: free; keeps gathers ahead of stores for wider groups
+        store_slot(S, dst, r);
+        __syncthreads();
+    }
+    // results leave LDS
+    const int okind = (int)H->out_kind;
+    FpS v = fp_zero();
+    if (lane < 12) {
+        const i32* p = S + (u32)H->out_slot[lane] * SLOT_WORDS;
+#pragma unroll
+        for (int i = 0; i < NL; i++) v.v[i] = p[i];
+    }
+    if (okind == K_CHECK1) {
+        const bool good = lane >= 12 ? true : (lane == 0 ? fp_eq(v, C_ONE) : fp_is_zero(v));
+        const bool all = __all(good ? 1 : 0) != 0;
+        if (lane == 0) ok[t] = (all && !(flags && flags[t])) ? 1 : 0;
+    } else if (lane < 12) {
+        store_m384(out + 72 * t + 6 * lane, v);
+    }
+}

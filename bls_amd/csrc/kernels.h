@@ -27,6 +27,9 @@ __global__ void k_miller1_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_final_exp_pair(const i32* fbuf, u64* out, size_t n, int mode);
 __global__ void k_miller2_pair(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
 __global__ void k_final_exp_is_one_pair(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+// k_lat.hip
+__global__ void k_lat(const u8* prog, const u8* b0, size_t s0, const u8* b1, size_t s1, const u8* b2, size_t s2,
+                                                const u8* b3, size_t s3, const u8* flags, u8* ok, u64* out, size_t n);
 // k_hash.hip
 __global__ void k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n);

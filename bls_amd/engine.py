@@ -56,6 +56,11 @@ def shard_count():
     return int(_lib().blsmi_shard_count())
 
 
+def set_latency_threshold(max_tuples):
+    """Batches of at most max_tuples tuples take the latency path (one tuple per wave); 0 = always the lane-pair kernels."""
+    _check(_lib().blsmi_set_latency_threshold(C.c_size_t(int(max_tuples))), "blsmi_set_latency_threshold")
+
+
 def shutdown():
     _lib().blsmi_shutdown.restype = None
     _lib().blsmi_shutdown()

@@ -9,11 +9,15 @@ from gpu_common import P, RC, mont, rand_g1, rand_g2, unmont
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["latency-path", "throughput-path"])
+def eng(request):
+    """Every test of this module runs twice: small batches through the latency path (one tuple per wave, k_lat.hip: the
+    default for <= 4096 tuples) and through the throughput kernels (one tuple per lane pair)."""
     from bls_amd import engine
     engine.init(0)
-    return engine
+    engine.set_latency_threshold(4096 if request.param == "latency-path" else 0)
+    yield engine
+    engine.set_latency_threshold(4096)
 
 
 def test_pairing_generator_kat(eng, kats):

@@ -12,11 +12,15 @@ from gpu_common import P, RC, rand_g1, rand_g2, sk_bytes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["latency-path", "throughput-path"])
+def eng(request):
+    """Every test of this module runs twice: small batches through the latency path (one tuple per wave, k_lat.hip: the
+    default for <= 4096 tuples) and through the throughput kernels (one tuple per lane pair)."""
     from bls_amd import engine
     engine.init(0)
-    return engine
+    engine.set_latency_threshold(4096 if request.param == "latency-path" else 0)
+    yield engine
+    engine.set_latency_threshold(4096)
 
 
 MSGS = [b"", b"a", b"the message to be signed", b"Hello world! 16 characters 0", bytes(range(55)), bytes(range(56)), bytes(range(64)), bytes(200), b"x" * 1000]

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Compiler view of every kernel's resources (VGPRs, AGPRs, scratch, occupancy): hipcc -Rpass-analysis=kernel-resource-usage
+# over the kernel translation units.  usage: tools/resource_usage.sh profiles/rNN_kernel_resource_usage.txt
+OUT=${1:-/tmp/kernel_resource_usage.txt}
+cd "$(dirname "$0")/../bls_amd/csrc" || exit 1
+: > "$OUT.tmp"
+for u in k_pairing_pair k_pairing_single k_hash k_curve k_lat; do
+  [ -f $u.hip ] || continue
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden --cuda-device-only -c -o /dev/null -Rpass-analysis=kernel-resource-usage $u.hip 2>&1 \
+      | grep -E "remark:" | sed -E 's/^.*remark: [^ ]+ //; s/^ +//' > "$OUT.$u" ) &
+done
+wait
+for u in k_pairing_pair k_pairing_single k_hash k_curve k_lat; do
+  [ -f "$OUT.$u" ] || continue
+  echo "== $u.hip" >> "$OUT.tmp"; cat "$OUT.$u" >> "$OUT.tmp"; rm -f "$OUT.$u"
+done
+mv "$OUT.tmp" "$OUT"
+grep -c "Function Name" "$OUT"
