@@ -64,6 +64,10 @@ def build(force=False, verbose=False):
     genlat = os.path.join(CSRC, "gen_lat.py")
     if not os.path.exists(LAT_BIN) or os.path.getmtime(genlat) > os.path.getmtime(LAT_BIN):
         subprocess.check_call(["python3", genlat])
+    genmul = os.path.join(CSRC, "gen_lat_mul.py")
+    mulinc = os.path.join(CSRC, "lat_mul.inc")
+    if not os.path.exists(mulinc) or os.path.getmtime(genmul) > os.path.getmtime(mulinc):
+        subprocess.check_call(["python3", genmul])
     if not force and not _stale():
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -26,22 +26,44 @@ struct LatHeader {                      // gen_lat.py: encode()
     u8 pad[8];
 };
 
-// x += c * S[slot] over the 15 limbs (the 16th word of a slot is padding); c in [-15, 15]
-BLSMI_DEV void gather_term(const i32* S, u32 term, i32 x[NL]) {
-    const i32 c = (i32)(term >> 11) - 16;
+// x += c * S[slot] over the 15 limbs (the 16th word of a slot is padding); c in [-15, 15].  The accumulators are 64 bits
+// wide so that a term costs ONE v_mad_u64_u32 per limb (a 32-bit multiply-add does not exist on gfx950; v_mul_lo + v_add
+// would be two); only their low words are meaningful and used.
+struct Acc { u64 v[NL]; };
+BLSMI_DEV void gather_term(const i32* S, u32 term, Acc& x) {
+    const u32 c = (u32)((i32)(term >> 11) - 16);
     const int4* p = reinterpret_cast<const int4*>(S + (term & 0x7ffu) * SLOT_WORDS);
     const int4 a = p[0], b = p[1], d = p[2], e = p[3];
     const i32 v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w};
-#pragma unroll
-    for (int i = 0; i < NL; i++) x[i] += c * v[i];
+    // rotating carry-out pairs: see gen_lat_mul.py
+    asm volatile("v_mad_u64_u32 %0, s[36:37], %8, %9, %0\n\tv_mad_u64_u32 %1, s[38:39], %8, %10, %1\n\tv_mad_u64_u32 %2, s[40:41], %8, %11, %2\n\tv_mad_u64_u32 %3, s[42:43], %8, %12, %3\n\t"
+                 "v_mad_u64_u32 %4, s[44:45], %8, %13, %4\n\tv_mad_u64_u32 %5, s[46:47], %8, %14, %5\n\tv_mad_u64_u32 %6, s[48:49], %8, %15, %6\n\tv_mad_u64_u32 %7, s[50:51], %8, %16, %7"
+                 : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7])
+                 : "v"(c), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
+    asm volatile("v_mad_u64_u32 %0, s[36:37], %7, %8, %0\n\tv_mad_u64_u32 %1, s[38:39], %7, %9, %1\n\tv_mad_u64_u32 %2, s[40:41], %7, %10, %2\n\tv_mad_u64_u32 %3, s[42:43], %7, %11, %3\n\t"
+                 "v_mad_u64_u32 %4, s[44:45], %7, %12, %4\n\tv_mad_u64_u32 %5, s[46:47], %7, %13, %5\n\tv_mad_u64_u32 %6, s[48:49], %7, %14, %6"
+                 : "+v"(x.v[8]), "+v"(x.v[9]), "+v"(x.v[10]), "+v"(x.v[11]), "+v"(x.v[12]), "+v"(x.v[13]), "+v"(x.v[14])
+                 : "v"(c), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14])
+                 : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
 }
-BLSMI_DEV void gather(const i32* S, const u32* terms, int nt, i32 x[NL]) {
+BLSMI_DEV void gather(const i32* S, const u32* terms, int nt, Acc& x) {
 #pragma unroll
     for (int t = 0; t < 7; t++) {
         if (t >= nt) break;                                                // nt is uniform across the wave (level header)
         gather_term(S, terms[t], x);
     }
 }
+BLSMI_DEV void acc_zero(Acc& x) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) x.v[i] = 0;
+}
+BLSMI_DEV void acc_low(const Acc& x, i32 r[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] = (i32)(u32)x.v[i];
+}
+// Montgomery product for a wave that is ALONE on its SIMD: MAD chains with a rotating carry-out SGPR pair (gen_lat_mul.py).
+#include "lat_mul.inc"
 BLSMI_DEV void store_slot(i32* S, u32 slot, const i32 r[NL]) {
     int4* p = reinterpret_cast<int4*>(S + slot * SLOT_WORDS);
     p[0] = make_int4(r[0], r[1], r[2], r[3]); p[1] = make_int4(r[4], r[5], r[6], r[7]);
@@ -87,30 +109,28 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
         }
         i32 r[NL];
         if (kind == K_MUL) {
+            Acc ax, ay;
+            acc_zero(ax); acc_zero(ay);
+            gather(S, tx, ntx, ax);
+            gather(S, ty, nty, ay);
             i32 x[NL], y[NL];
-#pragma unroll
-            for (int i = 0; i < NL; i++) { x[i] = 0; y[i] = 0; }
-            gather(S, tx, ntx, x);
-            gather(S, ty, nty, y);
-            vlimbs vx, vy;
-#pragma unroll
-            for (int i = 0; i < NL; i++) { vx[i] = x[i]; vy[i] = y[i]; }
-            const vlimbs z = fp_mul_body(vx, vy);
-#pragma unroll
-            for (int i = 0; i < NL; i++) r[i] = z[i];
+            acc_low(ax, x); acc_low(ay, y);
+            lat_mul(x, y, r);
         } else if (kind == K_LIN) {
+            Acc ax;
+            acc_zero(ax);
+            gather(S, tx, ntx, ax);
+            gather(S, ty, nty, ax);
             Fp<LMAX, VMAX> x;
-#pragma unroll
-            for (int i = 0; i < NL; i++) x.v[i] = 0;
-            gather(S, tx, ntx, x.v);
-            gather(S, ty, nty, x.v);
+            acc_low(ax, x.v);
             if (reduce) { const Fp<1, 3> y = fp_reduce(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
             else { const auto y = fp_norm(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
         } else if (kind == K_INV) {
+            Acc ax;
+            acc_zero(ax);
+            gather(S, tx, ntx, ax);
             Fp<LMAX, VMAX> x;
-#pragma unroll
-            for (int i = 0; i < NL; i++) x.v[i] = 0;
-            gather(S, tx, ntx, x.v);
+            acc_low(ax, x.v);
             const FpS y = fp_inv(x);                                           // inverse(0) = 0
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] = y.v[i];
@@ -122,9 +142,12 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] = y.v[i];
         }
-        __syncthreads();                                                       // one wave: free; keeps gathers ahead of stores for wider groups
+        // One wave per workgroup: LDS operations of a wave execute in program order, so the gathers above precede these
+        // stores and the stores precede the next level's gathers without a barrier (a barrier would also wait for the
+        // descriptor prefetch).  The wave barrier only pins the compiler's ordering; it emits no instruction.
+        __builtin_amdgcn_wave_barrier();
         store_slot(S, dst, r);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     // results leave LDS
     const int okind = (int)H->out_kind;

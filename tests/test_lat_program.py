@@ -1,0 +1,71 @@
+"""CPU (no GPU): the level programs of the latency path (bls_amd/csrc/gen_lat.py) evaluated by the generator's exact
+big-integer simulator -- slot reuse as scheduled -- against the oracle's pairing: FinalExponentiation(MillerLoop) bit for
+bit for one pair, and the CompareTwoPairings verdict/value for two pairs (pairing.go:132-147).  Also the bound accounting
+the kernel's integer arithmetic relies on (fp.cuh: limb bound L, value bound V per gathered operand)."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("gen_lat", os.path.join(ROOT, "bls_amd", "csrc", "gen_lat.py"))
+G = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(G)
+from oracle import pyref as P  # noqa: E402
+
+sys.setrecursionlimit(100000)
+
+
+@pytest.fixture(scope="module")
+def progs():
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2")}
+
+
+def _pt(xs):
+    a, b = P.rand_fr(xs), P.rand_fr(xs)
+    return P.jac_to_affine(P.F1, P.affine_mul(P.F1, P.G1_GEN, a)), P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, b))
+
+
+def test_pairing_program_matches_oracle(progs, kats):
+    p = progs["pairing1"]
+    xs = P.XORShift(5)
+    for Pa, Qa in [(P.G1_GEN, P.G2_GEN), _pt(xs), _pt(xs)]:
+        out = G.simulate(p, {0: [Pa[0], Pa[1]], 1: [Qa[0][0], Qa[0][1], Qa[1][0], Qa[1][1]]})
+        assert out == P.fq12_flat(P.pairing(Pa, Qa))
+    out = G.simulate(p, {0: list(P.G1_GEN), 1: [P.G2_GEN[0][0], P.G2_GEN[0][1], P.G2_GEN[1][0], P.G2_GEN[1][1]]})
+    assert out == [int(v) for v in kats["pairing_g1gen_g2gen"]]               # the reference's own vector, pairing_test.go:9-58
+
+
+def test_verify_program_matches_compare_two_pairings(progs):
+    p = progs["verify2"]
+    xs = P.XORShift(6)
+    a = P.rand_fr(xs)
+    P0 = P.jac_to_affine(P.F1, P.affine_mul(P.F1, P.G1_GEN, a)); Q0 = P.G2_GEN
+    P1 = P.G1_GEN; Q1 = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, a))
+
+    def run(P0, Q0, P1, Q1):
+        return G.simulate(p, {0: [P0[0], P0[1]], 1: [Q0[0][0], Q0[0][1], Q0[1][0], Q0[1][1]], 2: [P1[0], P1[1]], 3: [Q1[0][0], Q1[0][1], Q1[1][0], Q1[1][1]]})
+    assert run(P0, Q0, P1, Q1) == [1] + [0] * 11 and P.compare_two_pairings(P0, Q0, P1, Q1)
+    Q1b = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, a + 1))
+    f = P.final_exponentiation(P.miller_loop([(P0, P.g2_prepare(Q0)), (P.affine_neg(P.F1, P1), P.g2_prepare(Q1b))]))
+    assert run(P0, Q0, P1, Q1b) == P.fq12_flat(f) != [1] + [0] * 11
+
+
+def test_program_bounds_and_shape(progs):
+    for name, p in progs.items():
+        assert p.nslot < 1024
+        for kind, jobs in p.levels:
+            assert len(jobs) <= (1 if kind == G.K_INV else G.LANES)
+            for n in jobs:
+                if n.kind == "mul":
+                    assert len(n.x) <= G.TMAX and len(n.y) <= G.TMAX
+                    assert n.x.L() * n.y.L() <= G.LPROD_MAX and n.x.V() * n.y.V() <= G.VPROD_MAX
+                    assert n.x.cmax() <= G.CMAX and n.y.cmax() <= G.CMAX
+                elif n.kind == "lin":
+                    assert len(n.x) <= G.TLIN and n.x.L() <= G.LMAX and n.x.cmax() <= G.CMAX
+                for lin in (n.x, n.y):
+                    if lin:
+                        assert all(d.level < n.level for d in lin)                  # operands come from earlier levels
+        blob = G.encode(p)
+        assert len(blob) % 16 == 0
