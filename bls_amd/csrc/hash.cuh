@@ -229,10 +229,7 @@ __device__ __noinline__ void iso11(G1Aff& out, const G1Aff& p) {
 // hash.go:306-321: add the two mapped points, apply the isogeny, clear the cofactor by (|x| + 1)
 // The sum stays in Jacobian coordinates through the isogeny and the cofactor multiplication: one inversion (the final
 // ToAffine) instead of three.  A sum at infinity (p2 = -p1) follows the reference's affine steps literally.
-__device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2) {
-    G1Aff p1, p2;
-    swu_g1_helper(p1, t1);
-    swu_g1_helper(p2, t2);
+__device__ __noinline__ void swu_finish_g1(G1Aff& out, const G1Aff& p1, const G1Aff& p2) {
     const G1Jac sj = jac_add_affine(to_jac(p1), p2);
     G1Jac ij; iso_jac(ij, sj, C_XNUM11, C_XDEN11, C_YNUM11, C_YDEN11);
     out = jac_to_affine(jac_add(jac_mul_u64_public(ij, BLSMI_X_ABS), ij));
@@ -243,12 +240,36 @@ __device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2
         out.x = fp_select(sj.inf, r.x, out.x); out.y = fp_select(sj.inf, r.y, out.y); out.inf = (sj.inf & r.inf) | (~sj.inf & out.inf);
     }
 }
+__device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2) {
+    G1Aff p1, p2;
+    swu_g1_helper(p1, t1);
+    swu_g1_helper(p2, t2);
+    swu_finish_g1(out, p1, p2);
+}
 // hash.go:326-331
 __device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len) {
     u32 d[8];
     sha256_msg(d, 1, 0x01, msg, len);
     const FpS t1 = hp_from_digest(d, 0), t2 = hp_from_digest(d, 1);
     swu_map_g1(out, t1, t2);
+}
+// ---- two lanes per message (small batches): lane `par` of a lane pair maps t_par -- the two SWU evaluations, each one
+// exponentiation long, run side by side instead of one after the other -- the points are exchanged (DPP quad_perm
+// [1,0,3,2]) and both lanes finish the same sum, isogeny and cofactor clearing.  Same output bytes as hash_g1 / hash_g2.
+BLSMI_DEV i32 lane_partner(i32 x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); }
+BLSMI_DEV FpS fp_from_partner(const FpS& a) { FpS r; for (int i = 0; i < NL; i++) r.v[i] = lane_partner(a.v[i]); return r; }
+__device__ __noinline__ void hash_g1_two_lanes(G1Aff& out, const u8* msg, size_t len, int par) {
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msg, len);
+    const FpS t = hp_from_digest(d, (u32)par);
+    G1Aff mine, other;
+    swu_g1_helper(mine, t);
+    other.x = fp_from_partner(mine.x); other.y = fp_from_partner(mine.y); other.inf = 0;
+    const i32 m = par ? -1 : 0;
+    G1Aff p1, p2;
+    p1.x = fp_select(m, other.x, mine.x); p1.y = fp_select(m, other.y, mine.y); p1.inf = 0;
+    p2.x = fp_select(m, mine.x, other.x); p2.y = fp_select(m, mine.y, other.y); p2.inf = 0;
+    swu_finish_g1(out, p1, p2);
 }
 
 // ---- G2 (g2.go:933-1031, hash.go:282-411) ---------------------------------------------------------------
@@ -391,14 +412,33 @@ __device__ __noinline__ void clear_h2_jac(G2Aff& out, const G2Jac& p) {
     work = jac_add(work, psi_jac(psi_jac(jac_double(p))));
     out = jac_to_affine(work);
 }
+__device__ __noinline__ void swu_finish_g2(G2Aff& out, G2Aff p1, const G2Aff& p2);
 // hash.go:391-411
 __device__ __noinline__ void hash_g2(G2Aff& out, const u8* msg, size_t len) {
     u32 d[8];
     sha256_msg(d, 1, 0x01, msg, len);
     const Fp2S t1 = hp2_from_digest(d, 0), t2 = hp2_from_digest(d, 1);
-    G2Aff p1, p2, s;
+    G2Aff p1, p2;
     swu_g2_helper(p1, t1);
     swu_g2_helper(p2, t2);
+    swu_finish_g2(out, p1, p2);
+}
+__device__ __noinline__ void hash_g2_two_lanes(G2Aff& out, const u8* msg, size_t len, int par) {
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msg, len);
+    const Fp2S t = hp2_from_digest(d, (u32)par);
+    G2Aff mine, other;
+    swu_g2_helper(mine, t);
+    other.x.c0 = fp_from_partner(mine.x.c0); other.x.c1 = fp_from_partner(mine.x.c1);
+    other.y.c0 = fp_from_partner(mine.y.c0); other.y.c1 = fp_from_partner(mine.y.c1); other.inf = 0;
+    const i32 m = par ? -1 : 0;
+    G2Aff p1, p2;
+    p1.x = fp2_select(m, other.x, mine.x); p1.y = fp2_select(m, other.y, mine.y); p1.inf = 0;
+    p2.x = fp2_select(m, mine.x, other.x); p2.y = fp2_select(m, mine.y, other.y); p2.inf = 0;
+    swu_finish_g2(out, p1, p2);
+}
+__device__ __noinline__ void swu_finish_g2(G2Aff& out, G2Aff p1, const G2Aff& p2) {
+    G2Aff s;
     const G2Jac sj = jac_add_affine(to_jac(p1), p2);                      // stays Jacobian through iso3 and clearH2
     G2Jac ij; iso_jac(ij, sj, C_XNUM3, C_XDEN3, C_YNUM3, C_YDEN3);
     clear_h2_jac(out, ij);
