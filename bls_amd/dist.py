@@ -63,9 +63,8 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     Screens, agreed on by all ranks before any of them can return (a one-byte status rides on the first
     all-gather): a shard whose key and message counts differ (g2pubs/bls.go:241-243), an empty message, a key or
     the signature at infinity (all-zero record; the reference panics in MillerLoop there) -> False everywhere.
-    Duplicate rejection compares SHA-256 digests of the messages across ranks, not the message bytes: equal
-    messages always collide, distinct ones never in practice (a collision would need a SHA-256 collision)."""
-    import hashlib
+    Duplicate rejection compares 33-byte keys across ranks (message_keys): messages of up to 32 bytes verbatim, longer
+    ones by SHA-256 digest -- equal messages always collide, distinct ones only with a SHA-256 collision."""
     if engine is None:
         from . import engine as _e
         engine = _e
@@ -78,15 +77,18 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         status |= 1
     if not any(bytes(sig)):
         status |= 4                                            # signature at infinity
-    digests = b"".join(hashlib.sha256(bytes(m)).digest() for m in shard_msgs)
-    gathered = all_gather_bytes(digests + bytes([status]))
-    alld = []
+    keys = message_keys(shard_msgs)
+    gathered = all_gather_bytes(keys + bytes([status]))
     any_status = 0
+    allk = []
     for g in gathered:
         any_status |= g[-1]
-        alld.extend(g[i:i + 32] for i in range(0, len(g) - 1, 32))
-    if any_status or len(set(alld)) != len(alld):             # duplicate (or empty) message, bad shard: reject on every rank
+        allk.append(np.frombuffer(g[:-1], dtype=np.uint8).reshape(-1, 33))
+    if any_status:                                             # empty message, bad shard, infinity: reject on every rank
         return False
+    allk = np.concatenate(allk) if allk else np.zeros((0, 33), np.uint8)
+    if allk.shape[0] and np.unique(allk.view([("k", np.void, 33)])).shape[0] != allk.shape[0]:
+        return False                                           # some message occurs twice (g2pubs/bls.go:245-261)
     part, bad = engine.aggregate_partial(group, shard_msgs, pk_raw)
     parts = all_gather_bytes(part.tobytes() + bytes([1 if bad else 0]))
     if any(p[-1] for p in parts):                              # a key at infinity on some rank
@@ -98,6 +100,23 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         lhs = engine.miller_loop_batch(engine_generator(engine, 1), sig, 1)[0]
     fe = engine.final_exponentiation_batch(np.stack([lhs, rhs]))
     return bool(np.array_equal(fe[0], fe[1]))
+
+
+def message_keys(msgs):
+    """33-byte duplicate-detection key per message: messages of at most 32 bytes travel verbatim (length byte + bytes,
+    zero padded: exact comparison), longer ones as 0xff + SHA-256 (equal messages always collide, distinct ones only with
+    a SHA-256 collision).  Uniform 32-byte messages (the Eth2-era shape, BASELINE configs[3]) need no hashing at all."""
+    import hashlib
+    n = len(msgs)
+    if n and all(len(m) == 32 for m in msgs):
+        k = np.full((n, 33), 32, dtype=np.uint8)
+        k[:, 1:] = np.frombuffer(b"".join(bytes(m) for m in msgs), dtype=np.uint8).reshape(n, 32)
+        return k.tobytes()
+    out = bytearray()
+    for m in msgs:
+        m = bytes(m)
+        out += (bytes([len(m)]) + m.ljust(32, b"\0")) if len(m) <= 32 else (b"\xff" + hashlib.sha256(m).digest())
+    return bytes(out)
 
 
 _G1_GEN = bytes.fromhex("17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"

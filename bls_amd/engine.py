@@ -70,7 +70,21 @@ def version():
     return _lib().blsmi_version().decode()
 
 
+class PackedMsgs:
+    """n messages already laid out as the C ABI wants them (concatenated bytes + n+1 offsets): lets a caller that issues
+    the same batch repeatedly -- or holds a million messages -- pay the Python-side packing once."""
+
+    def __init__(self, msgs):
+        self.buf, self.off = _msgs(msgs)
+        self.n = len(msgs)
+
+    def __len__(self):
+        return self.n
+
+
 def _msgs(msgs):
+    if isinstance(msgs, PackedMsgs):
+        return msgs.buf, msgs.off
     off = np.zeros(len(msgs) + 1, dtype=np.uint64)
     if len(msgs):
         off[1:] = np.cumsum([len(m) for m in msgs])

@@ -81,7 +81,11 @@ int blsmi_final_exponentiation_batch(const uint64_t *in_fq12, uint64_t *out_fq12
  * (its 96/192 bytes are then zero).  in_inf may be NULL (all finite). */
 int blsmi_g1_mul_batch(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
 int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
-/* k_i * generator (PrivToPub g2pubs/bls.go:138-140 uses G2, g1pubs/bls.go:144-146 uses G1) */
+/* k_i * generator (PrivToPub g2pubs/bls.go:138-140 uses G2, g1pubs/bls.go:144-146 uses G1).
+ * NOT side-channel hardened: the scalar-multiplication kernels index a per-lane table by scalar nibbles and take
+ * data-dependent paths in the group law (the reference's bit-serial Mul is not constant-time either).  They exist to
+ * generate and check test/bench inputs and for public scalars; secret keys belong on the upstream pure-Go module
+ * (Sign / PrivToPub stay there in the Go shim). */
 int blsmi_g1_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
 int blsmi_g2_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
 /* sum of n points (tree reduction on the device; equals the reference's sequential Jacobian sum

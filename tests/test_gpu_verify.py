@@ -383,7 +383,7 @@ def test_sharded_verify_aggregate_single_process(eng):
                 import hashlib
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
-                    dig = b"".join(hashlib.sha256(m).digest() for m in msgs[lo:hi]) + b"\x00"
+                    dig = bdist.message_keys(msgs[lo:hi]) + b"\x00"
                     part = eng.aggregate_partial(group, msgs[lo:hi], b"".join(pk_list[lo:hi]))[0].tobytes() + b"\x00"
                     contrib.append((dig, part))
                 outs = []
