@@ -142,7 +142,7 @@ int init_device(Device& d) {            // caller holds g_mu
 }
 // Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
 // (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
-size_t g_lat_max = 4096;                // BLSMI_LAT_MAX, blsmi_set_latency_threshold
+std::atomic<size_t> g_lat_max{4096};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely)
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -388,8 +388,7 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
 // last call) with blsmi_last_kernel_ms.
 // Batches of at most `max_tuples` tuples take the latency path (one tuple per wave, k_lat.hip); 0 switches it off.
 BLSMI_API int blsmi_set_latency_threshold(size_t max_tuples) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_lat_max = max_tuples;
+    g_lat_max.store(max_tuples);
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_set_profiling(int on) {
