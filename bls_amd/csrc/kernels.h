@@ -35,6 +35,7 @@ __global__ void k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g1_two_lanes(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2_two_lanes(const u8* msgs, const u64* off, u8* out, size_t n);
+__global__ void k_hash_g2_domain_two_lanes(const u8* msgs32, const u8* domain, u8* out, size_t n);
 __global__ void k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n);
 __global__ void k_write_generators(u8* g1, u8* g2);
 __global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);

@@ -18,9 +18,12 @@ namespace blsmi {
 
 #include "pairing_body.inc"
 
+}  // namespace blsmi
+
 // The same tower / Miller loop / final exponentiation over the lane-pair Fq2 layer
+#include "pair_field.cuh"
+namespace blsmi {
 namespace pairl {
-#include "fp2_pair.inc"
 #include "tower_body.inc"
 #include "pairing_body.inc"
 }  // namespace pairl

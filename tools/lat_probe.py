@@ -24,3 +24,7 @@ for n in (64, 1024, 4096):
     ms = [msg] * n
     print("g2pubs verify n=%5d: %8.3f ms" % (n, best(lambda: engine.g2pubs_verify_batch(ms, pk * n, sig * n), 3)))
 assert engine.g2pubs_verify_batch([msg], pk, sig)[0][0] and engine.g1pubs_verify_batch([msg], pk1, sig1)[0][0]
+dom = bytes([42, 0, 0, 0, 0, 0, 0, 0]); m32 = b"Some msg".ljust(32, b"\0")
+sgd = RC.g1pubs.sign_with_domain(m32, sk, dom)
+assert engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sgd)[0]
+print("g1pubs verify_with_domain n=1: %.3f ms  (hash_g2_with_domain alone: %.3f ms)" % (best(lambda: engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sgd)), best(lambda: engine.hash_g2_with_domain_batch([m32], dom))))
