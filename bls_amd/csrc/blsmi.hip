@@ -506,7 +506,10 @@ static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t*
     HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
     if (pts) { HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream)); }
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
+    if (PB == 192 && g_pair_layout)                                        // G2: lane-pair kernel, two waves per SIMD
+        hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((n + PT - 1) / PT)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
+    else
+        hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)PB * n, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipMemcpyAsync(out_inf, dinf.p, n, hipMemcpyDeviceToHost, g_stream));

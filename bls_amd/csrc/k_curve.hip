@@ -134,3 +134,45 @@ KERNEL2 k_g1_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<F
 KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp2S, 192>(src, out, out_inf); }
 
 #include "msm.inc"
+
+// ------------------------------------------------------------------------------------------------------------------
+// G2 scalar multiplication in the LANE-PAIR layout (pair_field.cuh): lanes 2k, 2k+1 share point k, one Fq2 coefficient
+// per lane -- 45 registers of point state per lane instead of 90, the per-lane window table halves, and the kernel runs
+// two waves per SIMD (the one-point-per-lane k_g2_mul needs the whole register file: one wave).  Same window method,
+// same group element, same affine bytes.
+// ------------------------------------------------------------------------------------------------------------------
+#include "pair_field.cuh"
+namespace P2 = blsmi::pairl;
+BLSMI_DEV P2::G2AffP pair_load_g2(const u8* p, int par) {                  // wire order x.c0 || x.c1 || y.c0 || y.c1
+    u32 any = 0;
+    P2::G2AffP a;
+    a.x = P2::wrap(load_be48(p + 48 * par, &any)); a.y = P2::wrap(load_be48(p + 96 + 48 * par, &any));
+    any |= (u32)__shfl_xor((int)any, 1);
+    a.inf = any ? 0 : -1;                                                  // the all-zero record is the point at infinity
+    return a;
+}
+BLSMI_DEV void pair_store_g2(u8* p, int par, const P2::G2AffP& a) {
+    if (a.inf) { u32* w = reinterpret_cast<u32*>(p + 48 * par); for (int i = 0; i < 12; i++) { w[i] = 0; w[24 + i] = 0; } return; }
+    store_be48(p + 48 * par, a.x.c); store_be48(p + 96 + 48 * par, a.y.c);
+}
+__global__ void __launch_bounds__(WG, 2) k_g2_mul_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const int par = threadIdx.x & 1;
+    const size_t t = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t tt = t < n ? t : n - 1;
+    const P2::G2AffP p = pair_load_g2(pts + pt_stride * tt, par);
+    const u32* s32 = reinterpret_cast<const u32*>(scalars + 32 * tt);
+    P2::G2JacP tab[16];
+    tab[0] = jac_zero<P2::Fp2S>();
+    tab[1] = to_jac(p);
+    for (int j = 2; j < 16; j++) tab[j] = jac_add_affine(tab[j - 1], p);
+    P2::G2JacP res = jac_zero<P2::Fp2S>();
+    for (int w = 0; w < 8; w++) {
+        const u32 kw = __builtin_bswap32(s32[w]);
+        for (int nib = 7; nib >= 0; nib--) {
+            if (w | (7 - nib)) { res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); }
+            res = jac_add(res, tab[(kw >> (4 * nib)) & 15]);
+        }
+    }
+    const P2::G2AffP a = jac_to_affine(res);
+    if (t < n) { pair_store_g2(out + (size_t)192 * t, par, a); if (!par) out_inf[t] = a.inf ? 1 : 0; }
+}
