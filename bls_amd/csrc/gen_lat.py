@@ -496,11 +496,33 @@ def flat12(f):
             f[1][0][0], f[1][0][1], f[1][1][0], f[1][1][1], f[1][2][0], f[1][2][1]]
 
 
+BUF_RAW3 = 8       # LOAD: element e of the raw device representation (15 int32 limbs, structure-of-arrays with n = 1) at buffer 3
+BUF_M384_0 = 9     # LOAD: element e of the Fq wire format (6 little-endian uint64, Montgomery 2^384) at buffer 0
+
+
+def unflat12(v):
+    return (((v[0], v[1]), (v[2], v[3]), (v[4], v[5])), ((v[6], v[7]), (v[8], v[9]), (v[10], v[11])))
+
+
 def build_program(kind):
     """kind: 'verify2' -- inputs P0 (buf 0, 2 Fq), Q0 (buf 1, 4 Fq), P1 (buf 2), Q1 (buf 3); verdict = FE(ML((P0,Q0),(-P1,Q1))) == 1
-             'pairing1' -- inputs P (buf 0), Q (buf 1); output FE(ML(P, Q)) as 12 Fq"""
+             'pairing1' -- inputs P (buf 0), Q (buf 1); output FE(ML(P, Q)) as 12 Fq
+             'aggtail'  -- the tail of VerifyAggregate: P (buf 0), Q (buf 1) and an Fq12 R in the device representation (buf 3);
+                           verdict = FE(ML(-P, Q) * R) == 1, i.e. e(P, Q) == FE(R) with ONE final exponentiation
+             'finalexp1' -- input an Fq12 in the wire format (buf 0); output FE(f) as 12 Fq (pairing.go:79-129)"""
     b = Builder()
     pr = Pairing(b)
+    if kind == "aggtail":
+        P = (b.inp(0, 0), -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        R = unflat12([b.inp(BUF_RAW3, e) for e in range(12)])
+        R = pr.T.lin12(R, True)                                          # raw limbs of a stored value: normalised, any representative
+        f = pr.final_exp(pr.T.mul12(pr.miller([(P, Qa)]), R))
+        b.out = ("check1", flat12(pr.T.lin12(f, True)))
+        return b
+    if kind == "finalexp1":
+        f = unflat12([b.inp(BUF_M384_0, e) for e in range(12)])
+        b.out = ("out12", flat12(pr.T.lin12(pr.final_exp(f), True)))
+        return b
     if kind == "verify2":
         P0 = (b.inp(0, 0), b.inp(0, 1)); Q0 = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         P1 = (b.inp(2, 0), -b.inp(2, 1)); Q1 = ((b.inp(3, 0), b.inp(3, 1)), (b.inp(3, 2), b.inp(3, 3)))
@@ -690,7 +712,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -136,9 +136,19 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             for (int i = 0; i < NL; i++) r[i] = y.v[i];
         } else {                                                               // K_LOAD: tx[0] = buffer | element << 4
             const u32 bsel = tx[0] & 15u, el = (tx[0] >> 4) & 0xfffu;
-            const u8* base = bsel == 0 ? b0 + s0 * t : bsel == 1 ? b1 + s1 * t : bsel == 2 ? b2 + s2 * t : b3 + s3 * t;
             FpS y = fp_zero();
-            if (lane < njobs) y = load_be48(base + 48 * el);
+            if (lane < njobs) {
+                if (bsel == 8) {                                                   // device representation: raw limbs, SoA with n = 1, at buffer 3
+                    const i32* raw = reinterpret_cast<const i32*>(b3 + s3 * t) + el * NL;
+#pragma unroll
+                    for (int i = 0; i < NL; i++) y.v[i] = raw[i];
+                } else if (bsel == 9) {                                            // Fq wire format (Montgomery 2^384 limbs) at buffer 0
+                    y = load_m384(reinterpret_cast<const u64*>(b0 + s0 * t) + 6 * el);
+                } else {
+                    const u8* base = bsel == 0 ? b0 + s0 * t : bsel == 1 ? b1 + s1 * t : bsel == 2 ? b2 + s2 * t : b3 + s3 * t;
+                    y = load_be48(base + 48 * el);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] = y.v[i];
         }

@@ -19,7 +19,7 @@ sys.setrecursionlimit(100000)
 
 @pytest.fixture(scope="module")
 def progs():
-    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2")}
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "finalexp1")}
 
 
 def _pt(xs):
@@ -50,6 +50,21 @@ def test_verify_program_matches_compare_two_pairings(progs):
     Q1b = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, a + 1))
     f = P.final_exponentiation(P.miller_loop([(P0, P.g2_prepare(Q0)), (P.affine_neg(P.F1, P1), P.g2_prepare(Q1b))]))
     assert run(P0, Q0, P1, Q1b) == P.fq12_flat(f) != [1] + [0] * 11
+
+
+def test_final_exponentiation_and_aggregate_tail_programs(progs):
+    xs = P.XORShift(9)
+    a = P.rand_fr(xs)
+    Pa = P.jac_to_affine(P.F1, P.affine_mul(P.F1, P.G1_GEN, a)); Qa = P.G2_GEN
+    ml = P.miller_loop([(Pa, P.g2_prepare(Qa))])
+    assert G.simulate(progs["finalexp1"], {G.BUF_M384_0: P.fq12_flat(ml)}) == P.fq12_flat(P.final_exponentiation(ml))     # pairing.go:79-129
+    # aggregate tail: e(P, Q) == FE(R) decided as FE(ML(-P, Q) * R) == 1, with R any Miller value of an equal / unequal pairing
+    qin = {0: [Pa[0], Pa[1]], 1: [Qa[0][0], Qa[0][1], Qa[1][0], Qa[1][1]]}
+    for da, want in ((0, True), (1, False)):
+        Q1 = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, a + da))
+        R = P.miller_loop([(P.G1_GEN, P.g2_prepare(Q1))])
+        out = G.simulate(progs["aggtail"], dict(qin, **{G.BUF_RAW3: P.fq12_flat(R)}))
+        assert (out == [1] + [0] * 11) is want
 
 
 def test_program_bounds_and_shape(progs):
