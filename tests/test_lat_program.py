@@ -63,7 +63,8 @@ def test_final_exponentiation_and_aggregate_tail_programs(progs):
     for da, want in ((0, True), (1, False)):
         Q1 = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, a + da))
         R = P.miller_loop([(P.G1_GEN, P.g2_prepare(Q1))])
-        out = G.simulate(progs["aggtail"], dict(qin, **{G.BUF_RAW3: P.fq12_flat(R)}))
+        inputs = dict(qin); inputs[G.BUF_RAW3] = P.fq12_flat(R)
+        out = G.simulate(progs["aggtail"], inputs)
         assert (out == [1] + [0] * 11) is want
 
 
