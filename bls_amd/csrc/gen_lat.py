@@ -37,7 +37,7 @@ NLIMB, LB = 15, 27
 RMONT = 1 << (NLIMB * LB)
 
 # job / level kinds (shared with k_lat.hip)
-K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1 = 0, 1, 2, 3, 4, 5
+K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12 = 0, 1, 2, 3, 4, 5, 6
 LANES = 64
 TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
 TLIN = 14             # terms of a LIN job (both operand fields)
@@ -509,7 +509,8 @@ def build_program(kind):
              'pairing1' -- inputs P (buf 0), Q (buf 1); output FE(ML(P, Q)) as 12 Fq
              'aggtail'  -- the tail of VerifyAggregate: P (buf 0), Q (buf 1) and an Fq12 R in the device representation (buf 3);
                            verdict = FE(ML(-P, Q) * R) == 1, i.e. e(P, Q) == FE(R) with ONE final exponentiation
-             'finalexp1' -- input an Fq12 in the wire format (buf 0); output FE(f) as 12 Fq (pairing.go:79-129)"""
+             'finalexp1' -- input an Fq12 in the wire format (buf 0); output FE(f) as 12 Fq (pairing.go:79-129)
+             'miller1raw' -- inputs P (buf 0), Q (buf 1); output a Miller value of (P, Q) in the device representation"""
     b = Builder()
     pr = Pairing(b)
     if kind == "aggtail":
@@ -518,6 +519,12 @@ def build_program(kind):
         R = pr.T.lin12(R, True)                                          # raw limbs of a stored value: normalised, any representative
         f = pr.final_exp(pr.T.mul12(pr.miller([(P, Qa)]), R))
         b.out = ("check1", flat12(pr.T.lin12(f, True)))
+        return b
+    if kind == "miller1raw":
+        # MillerLoop(P, Q) for the product tree of VerifyAggregate, left in the device representation.  Its value differs from
+        # the reference's Miller value by a factor in Fq2* (projective lines), which every final exponentiation downstream removes.
+        P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        b.out = ("outraw12", flat12(pr.T.lin12(pr.miller([(P, Qa)]), True)))
         return b
     if kind == "finalexp1":
         f = unflat12([b.inp(BUF_M384_0, e) for e in range(12)])
@@ -682,7 +689,7 @@ def encode(p):
             desc += struct.pack("<16H", *r)
         red = 0x80 if (k == K_LIN and any(n.reduce for n in jobs)) else 0   # value reduction is level-wide (always valid, never needed less)
         hdr.append((k | red, ntx, nty, len(jobs)))
-    out_kind = K_CHECK1 if p.out == "check1" else K_OUT12
+    out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12}[p.out]
     blob = bytearray()
     blob += struct.pack("<8I", 0x54414c42, len(p.levels), p.nslot + 1, len(p.consts), out_kind, 0, 0, 0)
     blob += struct.pack("<12H", *[n.slot for n in p.out_nodes]) + b"\0" * 8
@@ -712,7 +719,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

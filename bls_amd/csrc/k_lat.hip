@@ -17,7 +17,7 @@
 #include "device_io.cuh"
 
 namespace {
-constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5;
+constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6;
 constexpr int SLOT_WORDS = 16;
 
 struct LatHeader {                      // gen_lat.py: encode()
@@ -72,7 +72,8 @@ BLSMI_DEV void store_slot(i32* S, u32 slot, const i32 r[NL]) {
 }  // namespace
 
 // bufs: up to four input arrays of affine records (48-byte big-endian field elements), stride 0 = one broadcast record.
-// out_kind CHECK1: ok[t] = (result == 1) && !flags[t];  OUT12: out[t] = the 12 Fq of the result as Montgomery-384 words.
+// out_kind CHECK1: ok[t] = (result == 1) && !flags[t];  OUT12: out[t] = the 12 Fq of the result as Montgomery-384 words;
+// OUTRAW12: out = int32 structure-of-arrays buffer of the n results in the device representation.
 __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, size_t s0, const u8* b1, size_t s1, const u8* b2, size_t s2,
                                                 const u8* b3, size_t s3, const u8* flags, u8* ok, u64* out, size_t n) {
     extern __shared__ int4 lds4[];
@@ -171,6 +172,12 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
         const bool good = lane >= 12 ? true : (lane == 0 ? fp_eq(v, C_ONE) : fp_is_zero(v));
         const bool all = __all(good ? 1 : 0) != 0;
         if (lane == 0) ok[t] = (all && !(flags && flags[t])) ? 1 : 0;
+    } else if (okind == K_OUTRAW12) {                                          // device representation, SoA over the n tuples (the product tree's input)
+        if (lane < 12) {
+            i32* fbuf = reinterpret_cast<i32*>(out);
+#pragma unroll
+            for (int j = 0; j < NL; j++) fbuf[((size_t)lane * NL + j) * n + t] = v.v[j];
+        }
     } else if (lane < 12) {
         store_m384(out + 72 * t + 6 * lane, v);
     }
