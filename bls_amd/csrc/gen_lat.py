@@ -115,8 +115,23 @@ class Builder:
         return Lin({n: 1})
 
     # ---- materialisation ----------------------------------------------------------------------------------------
+    def flatten(self, x):
+        """inline terms that are themselves un-reduced LIN jobs when the result still fits one gather: a chain of two
+        recombination levels becomes one (the inner jobs die if nothing else reads them)"""
+        y = Lin()
+        changed = False
+        for k, c in x.items():
+            if k.kind == "lin" and not k.reduce and len(k.x) > 0:
+                y = y + k.x.scale(c); changed = True
+            else:
+                y = y + Lin({k: c})
+        if changed and len(y) <= TLIN and y.L() <= LMAX and y.cmax() <= CMAX:
+            return y
+        return x
+
     def lin(self, x, force_reduce=False):
         """S = normalise(x): a node again (L = 1)."""
+        x = self.flatten(x)
         if len(x) == 1 and not force_reduce:
             (k, c), = x.items()
             if c == 1:

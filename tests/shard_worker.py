@@ -63,6 +63,7 @@ def main():
         ck[grp + "_aggregate_small_oracle"] = va(ms[:5], b"".join(pk2[:5]), agg) == o.verify_aggregate(agg, pk2[:5], ms[:5])
         small = (RC.g1_sum if grp == "g2pubs" else RC.g2_sum)(b"".join(o.sign(m, sk) for m, sk in zip(ms[:5], sks[:5])), 5)
         ck[grp + "_aggregate_small_true"] = va(ms[:5], b"".join(pk2[:5]), small) is True and o.verify_aggregate(small, pk2[:5], ms[:5]) is True
+    out["dup_screen"] = "sort" if os.environ.get("BLSMI_DUP_FORCE_SORT") else "hash table"
     out["ok"] = all(ck.values())
     eng.shutdown()
     print("SHARD_WORKER_RESULT " + json.dumps(out), flush=True)

@@ -273,6 +273,13 @@ def _run_worker(env_extra, *args):
     return json.loads(lines[-1][len("SHARD_WORKER_RESULT "):])
 
 
+def test_duplicate_screening_fallback_sort_path():
+    """has_duplicates falls back to the reference's sort (g2pubs/bls.go:245-261) when a probe sequence of its keyed hash
+    table grows long (attacker-chosen messages); BLSMI_DUP_FORCE_SORT takes that path on every call: same verdicts."""
+    res = _run_worker({"BLSMI_SHARDS": "1", "BLSMI_DUP_FORCE_SORT": "1"})
+    assert res["dup_screen"] == "sort" and res["ok"] is True, res
+
+
 @pytest.mark.parametrize("shards,force_rccl", [(2, "0"), (3, "1")])
 def test_inlibrary_split_two_logical_shards_on_one_gpu(shards, force_rccl):
     """blsmi_init_devices(1) with BLSMI_SHARDS logical shards: verify batches (verdict bytes + bitmap through the
