@@ -190,7 +190,7 @@ def aggregate_bench(engine, dev, rank, world, dist, use_dist, n_total=1 << 20, r
             dist.barrier()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         if use_dist:
-            ok = bdist.sharded_verify_aggregate("g2pubs", msgs, allpk, agg, rank, world, gather)
+            ok = bdist.sharded_verify_aggregate("g2pubs", packed, allpk, agg, rank, world, gather)
             dist.barrier()
         else:
             ok = engine.g2pubs_verify_aggregate(packed, allpk, agg)

@@ -73,7 +73,8 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     status = 0
     if len(pk_raw) != pk_bytes * len(shard_msgs):
         status |= 2                                            # len(pubKeys) != len(msgs)
-    if any(len(m) == 0 for m in shard_msgs):
+    if (hasattr(shard_msgs, "off") and (np.diff(shard_msgs.off.astype(np.int64)) == 0).any()) or \
+            (not hasattr(shard_msgs, "off") and any(len(m) == 0 for m in shard_msgs)):
         status |= 1
     if not any(bytes(sig)):
         status |= 4                                            # signature at infinity
@@ -87,7 +88,7 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     if any_status:                                             # empty message, bad shard, infinity: reject on every rank
         return False
     allk = np.concatenate(allk) if allk else np.zeros((0, 33), np.uint8)
-    if allk.shape[0] and np.unique(allk.view([("k", np.void, 33)])).shape[0] != allk.shape[0]:
+    if has_duplicate_rows(allk):
         return False                                           # some message occurs twice (g2pubs/bls.go:245-261)
     part, bad = engine.aggregate_partial(group, shard_msgs, pk_raw)
     parts = all_gather_bytes(part.tobytes() + bytes([1 if bad else 0]))
@@ -102,12 +103,38 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     return bool(np.array_equal(fe[0], fe[1]))
 
 
+def has_duplicate_rows(keys):
+    """exact duplicate test over the rows of an (n, 33) uint8 array: a 64-bit fingerprint (xor of the four 8-byte words)
+    is sorted first -- equal rows share it -- and only rows whose fingerprints collide are compared in full."""
+    n = keys.shape[0]
+    if n < 2:
+        return False
+    w = np.ascontiguousarray(keys[:, 1:33]).view(np.uint64).reshape(n, 4)
+    fp = w[:, 0] ^ w[:, 1] ^ w[:, 2] ^ w[:, 3] ^ keys[:, 0].astype(np.uint64)
+    order = np.argsort(fp, kind="stable")
+    fps = fp[order]
+    hit = fps[1:] == fps[:-1]
+    if not hit.any():
+        return False
+    idx = np.nonzero(np.concatenate([[False], hit]) | np.concatenate([hit, [False]]))[0]     # every member of a collision group
+    rows = keys[order[idx]]
+    rows = rows[np.lexsort(rows.T[::-1])]
+    return bool((rows[1:] == rows[:-1]).all(axis=1).any())
+
+
 def message_keys(msgs):
     """33-byte duplicate-detection key per message: messages of at most 32 bytes travel verbatim (length byte + bytes,
     zero padded: exact comparison), longer ones as 0xff + SHA-256 (equal messages always collide, distinct ones only with
     a SHA-256 collision).  Uniform 32-byte messages (the Eth2-era shape, BASELINE configs[3]) need no hashing at all."""
     import hashlib
     n = len(msgs)
+    if hasattr(msgs, "buf") and hasattr(msgs, "off"):          # engine.PackedMsgs
+        ln = np.diff(msgs.off.astype(np.int64))
+        if n and (ln == 32).all():
+            k = np.full((n, 33), 32, dtype=np.uint8)
+            k[:, 1:] = msgs.buf[:32 * n].reshape(n, 32)
+            return k.tobytes()
+        msgs = [bytes(msgs.buf[int(msgs.off[i]):int(msgs.off[i + 1])]) for i in range(n)]
     if n and all(len(m) == 32 for m in msgs):
         k = np.full((n, 33), 32, dtype=np.uint8)
         k[:, 1:] = np.frombuffer(b"".join(bytes(m) for m in msgs), dtype=np.uint8).reshape(n, 32)
