@@ -263,6 +263,43 @@ def test_zero_record_is_infinity_at_the_c_abi(eng):
         assert list(ok) == [False, True, False, True, True, True]
 
 
+# ---- the two paths against each other, at the largest batch the latency path takes ---------------------------------------
+def test_latency_and_throughput_paths_agree_on_4096_tuples():
+    """4 096 distinct (P, Q) pairs and 4 096 g2pubs tuples with a corruption schedule: the latency path (one tuple per wave,
+    projective Miller loop, level programs) and the throughput kernels (one tuple per lane pair, the reference's Jacobian
+    steps) must return the same 576-byte Fq12 values and the same verdicts, bit for bit; samples are checked against the
+    oracle by the other tests of this module."""
+    from bls_amd import engine
+    engine.init(0)
+    n, base = 4096, 64
+    xs = P.XORShift(404)
+    k1 = b"".join(sk_bytes(xs) for _ in range(base)); k2 = b"".join(sk_bytes(xs) for _ in range(base))
+    g1b, _ = engine.g1_mul_batch(RC.g1_generator() * base, k1, base); g2b, _ = engine.g2_mul_batch(RC.g2_generator() * base, k2, base)
+    g1 = np.tile(g1b, (n // base, 1)); g2 = np.concatenate([np.roll(g2b, -r, axis=0) for r in range(n // base)])
+    try:
+        engine.set_latency_threshold(4096)
+        a = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
+        engine.set_latency_threshold(0)
+        b = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
+        assert np.array_equal(a, b)
+        assert np.array_equal(a[4095], RC.pairing_batch(g1[4095].tobytes(), g2[4095].tobytes(), 1)[0])
+        # verify: 64 signers x 64 messages, every 7th tuple carries the wrong key
+        sks = [k1[32 * i:32 * i + 32] for i in range(base)]
+        pks, _ = engine.g2_mul_generator_batch(k1, base)
+        msgs = [b"path agreement %d" % i for i in range(n)]
+        h = engine.hash_g1_batch(msgs)
+        sigs, _ = engine.g1_mul_batch(h.reshape(-1), b"".join(sks[i % base] for i in range(n)), n)
+        allpk = np.stack([pks[(i + (1 if i % 7 == 6 else 0)) % base] for i in range(n)])
+        expect = [i % 7 != 6 for i in range(n)]
+        engine.set_latency_threshold(4096)
+        ok_lat, _ = engine.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
+        engine.set_latency_threshold(0)
+        ok_thr, _ = engine.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
+        assert list(ok_lat) == expect and list(ok_thr) == expect
+    finally:
+        engine.set_latency_threshold(4096)
+
+
 # ---- in-library multi-device split -----------------------------------------------------------------------------------------
 def _run_worker(env_extra, *args):
     env = dict(os.environ); env.update(env_extra)
