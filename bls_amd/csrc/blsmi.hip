@@ -64,8 +64,20 @@ struct Ctx {
     hipStream_t stream = nullptr;
     Workspace ws;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // two side streams + fork/join events: independent kernels of one small call (the two decompressions and the hash of
+    // Deserialize + Verify) run side by side instead of one after the other
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     bool busy = false;
     Device* dev = nullptr;
+    hipError_t ensure_aux() {
+        if (aux[0]) return hipSuccess;
+        hipError_t e;
+        for (auto& a : aux) if ((e = hipStreamCreateWithFlags(&a, hipStreamNonBlocking)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return e;
+        for (auto& j : join) if ((e = hipEventCreateWithFlags(&j, hipEventDisableTiming)) != hipSuccess) return e;
+        return hipSuccess;
+    }
 };
 constexpr int MAX_CTX = 16;
 constexpr int MAX_DEV = 16;
@@ -340,6 +352,9 @@ BLSMI_API void blsmi_shutdown(void) {
             (void)hipStreamSynchronize(c.stream);
             c.ws.release();
             for (auto& e : c.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& a : c.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
+            if (c.fork) { (void)hipEventDestroy(c.fork); c.fork = nullptr; }
+            for (auto& j : c.join) if (j) { (void)hipEventDestroy(j); j = nullptr; }
             (void)hipStreamDestroy(c.stream);
             c.stream = nullptr;
         }

@@ -28,3 +28,10 @@ dom = bytes([42, 0, 0, 0, 0, 0, 0, 0]); m32 = b"Some msg".ljust(32, b"\0")
 sgd = RC.g1pubs.sign_with_domain(m32, sk, dom)
 assert engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sgd)[0]
 print("g1pubs verify_with_domain n=1: %.3f ms  (hash_g2_with_domain alone: %.3f ms)" % (best(lambda: engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sgd)), best(lambda: engine.hash_g2_with_domain_batch([m32], dom))))
+pkc = engine.g2_compress_batch(pk, 1); sgc = engine.g1_compress_batch(sig, 1)
+for chk in (True, False):
+    ok, ep, es = engine.verify_serialized_batch("g2pubs", [msg], pkc.reshape(-1), sgc.reshape(-1), chk)
+    assert ok[0]
+    print("g2pubs verify_serialized n=1 subgroup_check=%s: %.3f ms" % (chk, best(lambda: engine.verify_serialized_batch("g2pubs", [msg], pkc.reshape(-1), sgc.reshape(-1), chk))))
+print("g2_decompress n=1 (checked): %.3f ms ; g1_decompress n=1 (checked): %.3f ms" % (best(lambda: engine.g2_decompress_batch(pkc.reshape(-1), 1, True)), best(lambda: engine.g1_decompress_batch(sgc.reshape(-1), 1, True))))
+print("g1_sum n=128: %.3f ms ; g2_sum n=128: %.3f ms" % (best(lambda: engine.g1_sum(pk1 * 128, 128)), best(lambda: engine.g2_sum(pk * 128, 128))))
