@@ -1,0 +1,41 @@
+"""One-off soak (GPU box): random tuples through both paths, outputs compared with each other and sampled against the oracle."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from bls_amd import engine
+from oracle import refcpu as RC, pyref as P
+engine.init(0)
+rng = np.random.default_rng(2024)
+def scal(n):
+    raw = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); raw[:, 0] &= 0x3f; raw[:, 31] |= 1
+    return raw
+n = 16384
+g1, _ = engine.g1_mul_batch(RC.g1_generator() * n, scal(n).reshape(-1), n)
+g2, _ = engine.g2_mul_batch(RC.g2_generator() * n, scal(n).reshape(-1), n)
+outs = {}
+for thr in (0, 4096):
+    engine.set_latency_threshold(thr)
+    parts = [engine.pairing_batch(g1[i:i + 4096].reshape(-1), g2[i:i + 4096].reshape(-1), 4096) for i in range(0, n, 4096)]
+    outs[thr] = np.concatenate(parts)
+assert np.array_equal(outs[0], outs[4096]), "paths differ"
+idx = rng.integers(0, n, size=200)
+t0 = time.time()
+for i in idx:
+    assert np.array_equal(outs[0][i], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]), i
+print("pairing soak ok: %d tuples on both paths, %d oracle samples (%.1f s)" % (n, len(idx), time.time() - t0))
+# hashes, both packages, odd lengths, both the one-lane and the two-lane kernels
+msgs = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in rng.integers(0, 200, size=3000)]
+for name, fn, ref in (("g1", engine.hash_g1_batch, RC.hash_g1), ("g2", engine.hash_g2_batch, RC.hash_g2)):
+    engine.set_latency_threshold(4096); a = fn(msgs[:2000])
+    engine.set_latency_threshold(0); b = fn(msgs[:2000])
+    assert np.array_equal(a, b), name
+    for i in rng.integers(0, 2000, size=60):
+        assert a[i].tobytes() == ref(msgs[i]), (name, i)
+    engine.set_latency_threshold(4096)
+dom = bytes(rng.integers(0, 256, size=8, dtype=np.uint8))
+m32 = [bytes(rng.integers(0, 256, size=32, dtype=np.uint8)) for _ in range(600)]
+a = engine.hash_g2_with_domain_batch(m32, dom); engine.set_latency_threshold(0); b = engine.hash_g2_with_domain_batch(m32, dom); engine.set_latency_threshold(4096)
+assert np.array_equal(a, b)
+for i in rng.integers(0, 600, size=25):
+    assert a[i].tobytes() == RC.hash_g2_with_domain(m32[i], dom), i
+print("hash soak ok")
