@@ -155,6 +155,7 @@ int init_device(Device& d) {            // caller holds g_mu
 // Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
 // (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
 std::atomic<size_t> g_lat_max{4096};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely)
+bool g_lat_hash = true;                 // BLSMI_LAT_HASH=0: small-batch hashes finish in the two-lane kernels instead of a level program
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -172,6 +173,7 @@ int ensure_init_list(const int* devs, int ndev) {
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
     if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_LAT_HASH")) g_lat_hash = atoi(v) != 0;
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
     for (int i = 0; i < ndev; i++) {
         g_dev[i].id = devs[i]; g_dev[i].index = i;
@@ -264,7 +266,8 @@ int device_index_of_pointer(const void* p) {
 struct DBuf {
     void* p = nullptr;
     hipStream_t s = nullptr;
-    hipError_t alloc(size_t bytes) { s = g_stream; return hipMallocAsync(&p, bytes ? bytes : 1, s); }
+    // st: the stream whose work uses the buffer (allocation and release are ordered on it); default: the lease's stream
+    hipError_t alloc(size_t bytes, hipStream_t st = nullptr) { s = st ? st : g_stream; return hipMallocAsync(&p, bytes ? bytes : 1, s); }
     ~DBuf() { if (p) (void)hipFreeAsync(p, s); }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };

@@ -37,7 +37,7 @@ NLIMB, LB = 15, 27
 RMONT = 1 << (NLIMB * LB)
 
 # job / level kinds (shared with k_lat.hip)
-K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12 = 0, 1, 2, 3, 4, 5, 6
+K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF = 0, 1, 2, 3, 4, 5, 6, 7
 LANES = 64
 TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
 TLIN = 14             # terms of a LIN job (both operand fields)
@@ -506,6 +506,224 @@ class Pairing:
         return T.mul12(y1, y3)
 
 
+# ---- curve arithmetic for the hash-to-curve tails (hash.go:185-389, g2.go:104-138) --------------------------------------
+# Points are homogeneous projective (X : Y : Z) on y^2 = x^3 + b and every group operation uses the COMPLETE formulas of
+# Renes-Costello-Batina (a = 0): doubling, addition of equal / opposite points and the point at infinity (0 : 1 : 0) need no
+# case distinction, and both operations are two product levels deep (the Jacobian formulas of g1.go / g2.go are five).
+import importlib.util as _ilu
+import pathlib as _pl
+_spec = _ilu.spec_from_file_location("iso_data", _pl.Path(__file__).resolve().parent / "iso_data.py")
+ISO = _ilu.module_from_spec(_spec); _spec.loader.exec_module(ISO)
+
+
+def _fits(x, y):
+    return len(x) <= TMAX and len(y) <= TMAX and x.cmax() <= CMAX and y.cmax() <= CMAX and x.L() <= LMAX and y.L() <= LMAX and x.L() * y.L() <= LPROD_MAX
+
+
+class Fld1:
+    """Fq as Lin values"""
+    lazy_out = True                                                  # results of a group operation feed the next one as they are
+    def __init__(self, b):
+        self.b = b
+    def mul(self, a, c): return self.b.mul(a, c)
+    def sqr(self, a): return self.b.mul(a, a)
+    def add(self, a, c): return a + c
+    def sub(self, a, c): return a - c
+    def neg(self, a): return -a
+    def sc(self, a, k): return a.scale(k)
+    def lin(self, a, fr=False): return self.b.lin(a, fr)
+    def const(self, v): return self.b.const(v) if v % Q else Lin()
+    def one(self): return self.b.const(1)
+    def zero(self): return Lin()
+    def b3_mul(self, a, c): return self.b.mul(a.scale(4), c.scale(3))   # 3 b a c, b = 4 (g1.go: y^2 = x^3 + 4): the factor rides on the operands
+    def b3_sqr(self, a): return self.b3_mul(a, a)
+    def inv(self, a): return self.b.inv(a)
+    def norm(self, a): return a                                      # a value that is zero iff a is
+    def coords(self, a): return [a]
+    def conj(self, a): return a
+
+
+class Fld2:
+    """Fq2 as pairs of Lin values"""
+    lazy_out = False
+    def __init__(self, b, T):
+        self.b, self.T = b, T
+    def mul(self, a, c):
+        """Karatsuba (fq2.go:116-130) when the operand sums stay inside the gather bounds, schoolbook otherwise"""
+        if _fits(a[0] + a[1], c[0] + c[1]):
+            return self.T.mul2(a, c, kar=True)
+        return self.T.mul2(a, c, kar=False)
+    def sqr(self, a): return self.T.sqr2(a)
+    def add(self, a, c): return Tower.add2(a, c)
+    def sub(self, a, c): return Tower.sub2(a, c)
+    def neg(self, a): return Tower.neg2(a)
+    def sc(self, a, k): return Tower.sc2(a, k)
+    def lin(self, a, fr=False): return self.T.lin2(a, fr)
+    def const(self, v): return self.T.k2(v)
+    def one(self): return (self.b.const(1), Lin())
+    def zero(self): return (Lin(), Lin())
+    def b3_mul(self, a, c):
+        """3 b' a c with b' = 4 (1 + u) (g2.go): schoolbook on the operands 2a and 6c, then the factor 1 + u as a recombination"""
+        return Tower.nr2(self.T.mul2(Tower.sc2(a, 2), Tower.sc2(c, 6), kar=False))
+    def b3_sqr(self, a):
+        """3 b' a^2 = 12 (1 + u) a^2 from two products of scaled operands: 12 (a0+a1)(a0-a1) and 24 a0 a1"""
+        s, d = self.b.lin(a[0] + a[1]), self.b.lin(a[0] - a[1])
+        p12, r24 = self.b.mul(s.scale(4), d.scale(3)), self.b.mul(a[0].scale(4), a[1].scale(6))
+        return (p12 - r24, p12 + r24)
+    def inv(self, a): return self.T.inv2(a)
+    def norm(self, a):
+        a = self.T.lin2(a)
+        return self.b.mul(a[0], a[0]) + self.b.mul(a[1], a[1])
+    def coords(self, a): return [a[0], a[1]]
+    def conj(self, a): return Tower.conj2(a)
+
+
+class Curve:
+    def __init__(self, F):
+        self.F = F
+
+    def neg(self, P):
+        return (P[0], self.F.neg(P[1]), P[2])
+
+    def _out(self, X3, Y3, Z3):
+        F = self.F
+        if F.lazy_out:
+            return (X3, Y3, Z3)
+        return (F.lin(X3), F.lin(Y3), F.lin(Z3))
+
+    def dbl(self, P):
+        """RCB16 algorithm 9 (a = 0): with B = 3 b Z^2 and d = Y^2 - 3B,
+             X3 = 2 d XY,   Y3 = 8 B Y^2 + d (Y^2 + B),   Z3 = 8 Y^3 Z                      two product levels, one recombination"""
+        F = self.F
+        X, Y, Z = P
+        t0, t1, xy, B = F.sqr(Y), F.mul(Y, Z), F.mul(X, Y), F.b3_sqr(Z)
+        d = F.sub(t0, F.sc(B, 3))
+        t04 = F.sc(t0, 4)
+        X3 = F.sc(F.mul(d, xy), 2)
+        Y3 = F.add(F.mul(F.sc(B, 2), t04), F.mul(d, F.add(t0, B)))
+        Z3 = F.mul(F.sc(t1, 2), t04)
+        return self._out(X3, Y3, Z3)
+
+    def add(self, P, R):
+        """RCB16 algorithm 7 (a = 0): complete addition, 12 products in two levels"""
+        F = self.F
+        X1, Y1, Z1 = P
+        X2, Y2, Z2 = R
+        t0, t1, t2 = F.mul(X1, X2), F.mul(Y1, Y2), F.mul(Z1, Z2)
+        t3 = F.lin(F.sub(F.sub(F.mul(F.add(X1, Y1), F.add(X2, Y2)), t0), t1))   # X1 Y2 + X2 Y1
+        t4 = F.lin(F.sub(F.sub(F.mul(F.add(Y1, Z1), F.add(Y2, Z2)), t1), t2))   # Y1 Z2 + Y2 Z1
+        B2 = F.b3_mul(Z1, Z2)                                                    # 3 b Z1 Z2
+        B5 = F.lin(F.add(F.b3_mul(X1, Z2), F.b3_mul(X2, Z1)))                    # 3 b (X1 Z2 + X2 Z1)
+        e = F.lin(F.sub(t1, B2)); g = F.lin(F.add(t1, B2)); t03 = F.lin(F.sc(t0, 3))
+        X3 = F.sub(F.mul(t3, e), F.mul(t4, B5))
+        Y3 = F.add(F.mul(e, g), F.mul(B5, t03))
+        Z3 = F.add(F.mul(g, t4), F.mul(t03, t3))
+        return self._out(X3, Y3, Z3)
+
+    def mul_u64(self, P, k):
+        """[k] P, most significant bit first (g1.go / g2.go Mul, same group element)"""
+        R = P
+        for i in range(k.bit_length() - 2, -1, -1):
+            R = self.dbl(R)
+            if (k >> i) & 1:
+                R = self.add(R, P)
+        return R
+
+    def to_affine(self, P):
+        F = self.F
+        zi = F.lin(F.inv(P[2]))
+        return F.lin(F.mul(P[0], zi), True), F.lin(F.mul(P[1], zi), True)
+
+
+def _powers(F, x, n):
+    """x^0 .. x^n with logarithmic depth"""
+    pw = [F.one(), x]
+    while len(pw) <= n:
+        top = len(pw) - 1                                             # highest power so far: multiply the block 1..top by x^top
+        base = pw[top]
+        for j in range(1, top + 1):
+            if len(pw) > n:
+                break
+            pw.append(F.lin(F.mul(base, pw[j])))
+    return pw
+
+
+def _poly(F, coeffs, pw):
+    acc = F.const(coeffs[0])
+    for k in range(1, len(coeffs)):
+        c = coeffs[k]
+        one = (c == 1) or (c == (1, 0))
+        acc = F.add(acc, pw[k] if one else F.mul(F.const(c), pw[k]))
+    return F.lin(acc)
+
+
+def iso_map(F, pt, xn, xd, yn, yd):
+    """the isogeny (hash.go:185-206 / 282-303) on an affine point, image in projective coordinates:
+    (xn/xd, y yn/yd) = (xn yd : y yn xd : xd yd)"""
+    x, y = pt
+    pw = _powers(F, x, max(len(xn), len(xd), len(yn), len(yd)) - 1)
+    XN, XD, YN, YD = _poly(F, xn, pw), _poly(F, xd, pw), _poly(F, yn, pw), _poly(F, yd, pw)
+    return (F.lin(F.mul(XN, YD)), F.lin(F.mul(y, F.lin(F.mul(YN, XD)))), F.lin(F.mul(XD, YD)))
+
+
+def _psi_consts():
+    ciw = (ISO.iwsc[0], (-ISO.iwsc[1]) % Q)
+    cx = f2mul(f2mul((1, 1), ciw), (ISO.kQiX, 0))
+    cy = f2mul(f2mul(f2mul((1, 1), (1, 1)), ciw), (ISO.kQiY, 0))
+    return cx, cy
+
+
+def psi_proj(F, P):
+    """psi (hash.go:341-366) on projective coordinates: (Cx conj(X) : Cy conj(Y) : conj(Z))"""
+    cx, cy = _psi_consts()
+    return (F.lin(F.mul(F.const(cx), F.conj(P[0]))), F.lin(F.mul(F.const(cy), F.conj(P[1]))), F.conj(P[2]))
+
+
+def clear_h2_proj(C, P):
+    """clearH2 (hash.go:368-389) on a projective point, same chain"""
+    F = C.F
+    work = C.add(C.mul_u64(P, X_ABS), P)
+    mpsi = C.neg(psi_proj(F, P))
+    work = C.add(work, mpsi)
+    work = C.mul_u64(work, X_ABS)
+    work = C.add(work, mpsi)
+    work = C.add(work, C.neg(P))
+    return C.add(work, psi_proj(F, psi_proj(F, C.dbl(P))))
+
+
+def h2_gls_digits():
+    """ScaleByCofactor (g2.go:104-115, 130-138) through clearH2 -- see gen_consts.py: [h2] P = sum (-1)^i d_i psi^i(clearH2(P))"""
+    x = -X_ABS
+    r = x**4 - x**2 + 1
+    c = pow(3 * (x * x - 1), -1, r)
+    d = [(c // X_ABS**i) % X_ABS for i in range(4)]
+    assert sum(di * X_ABS**i for i, di in enumerate(d)) == c
+    return d
+
+
+def scale_by_cofactor_proj(C, P):
+    F = C.F
+    q0 = clear_h2_proj(C, P)
+    q1 = psi_proj(F, q0); q2 = psi_proj(F, q1); q3 = psi_proj(F, q2)
+    q = [q0, C.neg(q1), q2, C.neg(q3)]
+    # subset sums of the four points: at most one addition per ladder step
+    table = {0: None}
+    for m in range(1, 16):
+        low = m & -m
+        i = low.bit_length() - 1
+        rest = m ^ low
+        table[m] = q[i] if rest == 0 else C.add(table[rest], q[i])
+    d = h2_gls_digits()
+    res = None
+    for bit in range(63, -1, -1):
+        if res is not None:
+            res = C.dbl(res)
+        m = sum(((d[i] >> bit) & 1) << i for i in range(4))
+        if m:
+            res = table[m] if res is None else C.add(res, table[m])
+    return res
+
+
 def flat12(f):
     return [f[0][0][0], f[0][0][1], f[0][1][0], f[0][1][1], f[0][2][0], f[0][2][1],
             f[1][0][0], f[1][0][1], f[1][1][0], f[1][1][1], f[1][2][0], f[1][2][1]]
@@ -528,6 +746,8 @@ def build_program(kind):
              'miller1raw' -- inputs P (buf 0), Q (buf 1); output a Miller value of (P, Q) in the device representation"""
     b = Builder()
     pr = Pairing(b)
+    if kind in ("hashfin1", "hashfin2", "cofac2"):
+        return build_hash_program(b, pr.T, kind)
     if kind == "aggtail":
         P = (b.inp(0, 0), -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         R = unflat12([b.inp(BUF_RAW3, e) for e in range(12)])
@@ -556,6 +776,43 @@ def build_program(kind):
         f = pr.final_exp(pr.miller([(P, Qa)]))
         outs = flat12(pr.T.lin12(f, True))
         b.out = ("out12", outs)
+    return b
+
+
+def build_hash_program(b, T, kind):
+    """the curve-arithmetic tails of hash-to-curve; inputs: the affine outputs of the SWU maps (buffer 0), output: the affine
+    hash point as wire-format field elements plus values that are zero exactly when a step was exceptional (an isogeny
+    denominator vanished, the two mapped points have the same x, the result is the point at infinity) -- the caller then
+    takes the one-message-per-lane kernels, which follow the reference's steps literally.
+      'hashfin1' -- HashG1 after the two SWU maps (hash.go:311-321): iso11 of both points, sum, clearH = [|x| + 1]
+      'hashfin2' -- HashG2 after the two SWU maps (hash.go:391-402): iso3 of both points, sum, clearH2
+      'cofac2'   -- HashG2WithDomain after the try-and-increment search (g2.go:1078-1084): ScaleByCofactor of the affine point
+    The reference adds the two mapped points first and applies the isogeny to the sum; the isogeny is a group homomorphism,
+    so mapping each point and adding the images is the same point -- and lets both maps share their levels."""
+    if kind == "hashfin1":
+        F = Fld1(b); C = Curve(F)
+        pts = [(b.inp(0, 0), b.inp(0, 1)), (b.inp(0, 2), b.inp(0, 3))]
+        im = [iso_map(F, q, ISO.xNum11, ISO.xDen11, ISO.yNum11, ISO.yDen11) for q in pts]
+        s = C.add(im[0], im[1])
+        r = C.add(C.mul_u64(s, X_ABS), s)
+    elif kind == "hashfin2":
+        F = Fld2(b, T); C = Curve(F)
+        pts = [((b.inp(0, 0), b.inp(0, 1)), (b.inp(0, 2), b.inp(0, 3))), ((b.inp(0, 4), b.inp(0, 5)), (b.inp(0, 6), b.inp(0, 7)))]
+        im = [iso_map(F, q, ISO.xNum3, ISO.xDen3, ISO.yNum3, ISO.yDen3) for q in pts]
+        r = clear_h2_proj(C, C.add(im[0], im[1]))
+    else:
+        F = Fld2(b, T); C = Curve(F)
+        pt = ((b.inp(0, 0), b.inp(0, 1)), (b.inp(0, 2), b.inp(0, 3)))
+        im = []
+        r = scale_by_cofactor_proj(C, (pt[0], pt[1], F.one()))
+    x, y = C.to_affine(r)
+    checks = [b.lin(F.norm(r[2]), True)] + [b.lin(F.norm(q[2]), True) for q in im]
+    if im:
+        # equal or opposite mapped points: the reference's addition then doubles with the a = 0 formula on a curve whose a is
+        # not 0 (g1.go / g2.go AddMixed -> Double), or stops at infinity; neither is reproduced here, both are flagged
+        checks.append(b.lin(F.norm(F.sub(pts[0][0], pts[1][0])), True))
+    outs = F.coords(x) + F.coords(y)
+    b.out = ("outaff", outs + checks, len(outs))
     return b
 
 
@@ -637,6 +894,7 @@ def schedule(b):
                 n.slot = nslot; nslot += 1
     p = Program()
     p.levels, p.consts, p.nslot, p.out, p.out_nodes, p.nodes = levels, consts, nslot, b.out[0], out_nodes, nodes
+    p.nout = b.out[2] if len(b.out) > 2 else len(out_nodes)
     return p
 
 
@@ -704,10 +962,11 @@ def encode(p):
             desc += struct.pack("<16H", *r)
         red = 0x80 if (k == K_LIN and any(n.reduce for n in jobs)) else 0   # value reduction is level-wide (always valid, never needed less)
         hdr.append((k | red, ntx, nty, len(jobs)))
-    out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12}[p.out]
+    out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12, "outaff": K_OUTAFF}[p.out]
     blob = bytearray()
-    blob += struct.pack("<8I", 0x54414c42, len(p.levels), p.nslot + 1, len(p.consts), out_kind, 0, 0, 0)
-    blob += struct.pack("<12H", *[n.slot for n in p.out_nodes]) + b"\0" * 8
+    assert len(p.out_nodes) <= 12
+    blob += struct.pack("<8I", 0x54414c42, len(p.levels), p.nslot + 1, len(p.consts), out_kind, p.nout, len(p.out_nodes) - p.nout, 0)
+    blob += struct.pack("<12H", *([n.slot for n in p.out_nodes] + [0] * (12 - len(p.out_nodes)))) + b"\0" * 8
     for h in hdr:
         blob += struct.pack("<4B", *h)
     while len(blob) % 16:
@@ -734,7 +993,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "hashfin1", "hashfin2", "cofac2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -604,7 +604,8 @@ BLSMI_DEV G2AffP psi_aff(const G2AffP& g) {                               // psi
 }
 }  // namespace pairl
 BLSMI_DEV Fp2S fp2_from_partner(const Fp2S& a) { Fp2S r; r.c0 = fp_from_partner(a.c0); r.c1 = fp_from_partner(a.c1); return r; }
-__device__ __noinline__ void hash_g2_with_domain_pair(FpS& ox, FpS& oy, i32& oinf, const u8* msg32, const u8* domain8, int par) {
+// The search half: both lanes return the x the reference's loop stops at and the y it favours (g2.go:1049-1077).
+__device__ __noinline__ void tai_g2_pair(Fp2S& xo, Fp2S& yo, const u8* msg32, const u8* domain8, int par) {
     u32 w[16], dre[8], dim[8];
     for (int tag = 1; tag <= 2; tag++) {                                   // SHA-256 of the 41-byte string m || domain || tag
         for (int i = 0; i < 8; i++) w[i] = ((u32)msg32[4 * i] << 24) | ((u32)msg32[4 * i + 1] << 16) | ((u32)msg32[4 * i + 2] << 8) | msg32[4 * i + 3];
@@ -644,6 +645,12 @@ __device__ __noinline__ void hash_g2_with_domain_pair(FpS& ox, FpS& oy, i32& oin
     Fp2S y = fp2_sqrt_from_norm_root(gsel, ssel);                          // either root: the choice follows
     const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() (g2.go:1074-1077)
     y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
+    xo = xsel; yo = y;
+}
+__device__ __noinline__ void hash_g2_with_domain_pair(FpS& ox, FpS& oy, i32& oinf, const u8* msg32, const u8* domain8, int par) {
+    Fp2S xsel, y;
+    tai_g2_pair(xsel, y, msg32, domain8, par);
+    const i32 m = par ? -1 : 0;
     pairl::G2AffP pt;
     pt.x = pairl::wrap(fp_select(m, xsel.c1, xsel.c0)); pt.y = pairl::wrap(fp_select(m, y.c1, y.c0)); pt.inf = 0;
     // ScaleByCofactor = [c] clearH2(P) through the psi ladder (see hash_g2_with_domain above), lane-pair arithmetic

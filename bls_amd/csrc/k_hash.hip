@@ -59,6 +59,59 @@ KERNEL k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n) {
     hash_g2_with_domain(h, msgs32 + 32 * tt, domain);
     if (t < n) store_g2(out + 192 * t, h);
 }
+// ---- small batches, the hash split in two: these kernels do SHA-256 and the SWU maps (or the try-and-increment search) --
+// one Fq exponentiation chain per lane, which is what a lane is good at -- and leave the mapped points as wire-format field
+// elements; the curve arithmetic that follows (isogeny, sum, cofactor clearing: wide and shallow) runs as a level program
+// of the latency path (k_lat.hip: hashfin1 / hashfin2 / cofac2), one message per wave.  pts: 2 points per message.
+KERNEL2 k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
+    G1Aff p;
+    swu_g1_helper(p, hp_from_digest(d, (u32)(idx & 1)));
+    if (t < n) store_g1(pts + 96 * idx, p);
+}
+KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
+    G2Aff p;
+    swu_g2_helper(p, hp2_from_digest(d, (u32)(idx & 1)));
+    if (t < n) store_g2(pts + 192 * idx, p);
+}
+KERNEL k_tai_g2_two_lanes(const u8* msgs32, const u8* domain, u8* pts, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
+    G2Aff p; p.inf = 0;
+    tai_g2_pair(p.x, p.y, msgs32 + 32 * tt, domain, (int)(idx & 1));
+    if (t < n && !(idx & 1)) store_g2(pts + 192 * t, p);
+}
+// Messages whose level program met an exceptional step (good[t] == 0: equal / opposite mapped points, an isogeny pole, a
+// result at infinity) are hashed again by the one-lane routines, which follow the reference's steps literally.  A wave
+// without such a message -- every wave, in practice -- returns at once.
+KERNEL2 k_hash_g1_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x, tt = t < n ? t : n - 1;
+    const bool mine = t < n && !good[t];
+    if (!__any(mine)) return;
+    G1Aff h;
+    hash_g1(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
+    if (mine) store_g1(out + 96 * t, h);
+}
+KERNEL k_hash_g2_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x, tt = t < n ? t : n - 1;
+    const bool mine = t < n && !good[t];
+    if (!__any(mine)) return;
+    G2Aff h;
+    hash_g2(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
+    if (mine) store_g2(out + 192 * t, h);
+}
+KERNEL k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const u8* good, u8* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x, tt = t < n ? t : n - 1;
+    const bool mine = t < n && !good[t];
+    if (!__any(mine)) return;
+    G2Aff h;
+    hash_g2_with_domain(h, msgs32 + 32 * tt, domain);
+    if (mine) store_g2(out + 192 * t, h);
+}
 KERNEL k_write_generators(u8* g1, u8* g2) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     G1Aff a; a.x = C_G1X; a.y = C_G1Y; a.inf = 0;

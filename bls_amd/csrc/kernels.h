@@ -37,6 +37,12 @@ __global__ void k_hash_g1_two_lanes(const u8* msgs, const u64* off, u8* out, siz
 __global__ void k_hash_g2_two_lanes(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2_domain_two_lanes(const u8* msgs32, const u8* domain, u8* out, size_t n);
 __global__ void k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n);
+__global__ void k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_tai_g2_two_lanes(const u8* msgs32, const u8* domain, u8* pts, size_t n);
+__global__ void k_hash_g1_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);
+__global__ void k_hash_g2_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);
+__global__ void k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const u8* good, u8* out, size_t n);
 __global__ void k_write_generators(u8* g1, u8* g2);
 __global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
 __global__ void k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);

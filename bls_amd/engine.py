@@ -393,6 +393,31 @@ def debug_g2_prepare(g2_aff=None, mode=0):
     return out.reshape(68, 3, 12)
 
 
+def debug_hash_tail(kind, pts, n):
+    """the level program behind a small-batch hash: mapped points -> (hash points (n, 96|192) uint8, good (n,) uint8)"""
+    rec, hb = (384 if kind == 1 else 192), (96 if kind == 0 else 192)
+    p = _u8(pts, rec * n)
+    out = np.zeros((n, hb), dtype=np.uint8); good = np.zeros(n, dtype=np.uint8)
+    _check(_lib().blsmi_debug_hash_tail(C.c_int(kind), _p8(p), _p8(out.reshape(-1)), _p8(good), C.c_size_t(n)), "blsmi_debug_hash_tail")
+    return out, good
+
+
+def debug_hash_redo(kind, msgs, good, out, domain8=None):
+    """re-hash the messages whose good byte is 0 into `out` (n, 96|192) uint8; returns the updated array"""
+    n = len(msgs)
+    hb = 96 if kind == 0 else 192
+    o = np.ascontiguousarray(out, dtype=np.uint8).reshape(n, hb).copy()
+    g = _u8(good, n)
+    if kind == 2:
+        buf = _u8(b"".join(bytes(m) for m in msgs), 32 * n); off = _u8(domain8, 8)
+        offp = off.ctypes.data_as(_u64p)
+    else:
+        buf, off = _msgs(msgs)
+        offp = off.ctypes.data_as(_u64p)
+    _check(_lib().blsmi_debug_hash_redo(C.c_int(kind), _p8(buf), offp, _p8(g), _p8(o.reshape(-1)), C.c_size_t(n)), "blsmi_debug_hash_redo")
+    return o
+
+
 def debug_op(name, a, b=None, lane_pair=False, raw_flag=False):
     op = OPS[name]
     width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 else (3 if op in (64, 65, 68) else 6)

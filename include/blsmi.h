@@ -176,6 +176,18 @@ int blsmi_debug_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, 
  * steps; 2: the table of the G2 generator the library prepared at start-up for g2pubs.Verify (g2_aff ignored). */
 int blsmi_debug_g2_prepare(const uint8_t *g2_aff /* 192 */, int mode, uint64_t *out /* 68*3*12 */);
 
+/* The two halves of a small-batch hash-to-curve, for the parity tests.  kind 0 / 1 / 2 = HashG1 (hash.go:326-331) / HashG2
+ * (hash.go:405-411) / HashG2WithDomain (g2.go:1041-1085).
+ * blsmi_debug_hash_tail: the curve arithmetic after the SWU maps (isogeny, sum, cofactor clearing; kind 2: ScaleByCofactor)
+ * run as a level program of the latency path.  pts: per message the mapped affine points as big-endian 48-byte field
+ * elements -- kind 0: two points of the 11-isogenous curve (192 bytes), kind 1: two points of the 3-isogenous curve (384),
+ * kind 2: the point of E'(Fq2) the try-and-increment search found (192).  out: the hash point (96 / 192 / 192 bytes);
+ * good[i] = 0 when message i met an exceptional step (the library then re-hashes it with the kernel below).
+ * blsmi_debug_hash_redo: that kernel -- messages with good[i] == 0 are hashed by the one-message-per-lane routine into
+ * out[i]; the records of the others are left as they were.  n <= 4096 for the tail. */
+int blsmi_debug_hash_tail(int kind, const uint8_t *pts, uint8_t *out, uint8_t *good, size_t n);
+int blsmi_debug_hash_redo(int kind, const uint8_t *msgs, const uint64_t *off_or_domain, const uint8_t *good, uint8_t *out /* in/out */, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,6 +263,70 @@ def test_zero_record_is_infinity_at_the_c_abi(eng):
         assert list(ok) == [False, True, False, True, True, True]
 
 
+# ---- the two halves of the small-batch hashes (SWU kernels + level program of the latency path) ------------------------------
+def _be(v):
+    return int(v).to_bytes(48, "big")
+
+
+def test_hash_tail_programs_and_redo_kernels():
+    """blsmi_debug_hash_tail: the level programs hashfin1 / hashfin2 / cofac2 on the GPU against the oracle's
+    iso11 / iso3 / clearH / clearH2 / ScaleByCofactor; exceptional inputs (equal or opposite mapped points) are flagged;
+    blsmi_debug_hash_redo: flagged messages are re-hashed by the one-lane kernels, the others left alone."""
+    from bls_amd import engine
+    engine.init(0)
+    msgs = [b"", b"abc", bytes(range(70)), b"x" * 200, b"tail"]
+    n = len(msgs)
+    # HashG1 (hash.go:311-331)
+    recs, want = [], []
+    for m in msgs:
+        p1, p2 = P.swu_g1_helper(P.hp(b"\x01" + m, 0)), P.swu_g1_helper(P.hp(b"\x01" + m, 1))
+        recs.append(_be(p1[0]) + _be(p1[1]) + _be(p2[0]) + _be(p2[1]))
+        want.append(RC.hash_g1(m))
+    p1 = P.swu_g1_helper(P.hp(b"\x01q", 0))
+    recs.append(_be(p1[0]) + _be(p1[1]) + _be(p1[0]) + _be((-p1[1]) % P.Q))          # opposite points: flagged
+    recs.append(_be(p1[0]) + _be(p1[1]) + _be(p1[0]) + _be(p1[1]))                    # equal points: flagged
+    out, good = engine.debug_hash_tail(0, b"".join(recs), n + 2)
+    assert list(good) == [1] * n + [0, 0]
+    assert [bytes(out[i]) for i in range(n)] == want
+    # HashG2 (hash.go:391-411)
+    recs, want2 = [], []
+    f2 = lambda v: _be(v[0]) + _be(v[1])
+    for m in msgs:
+        q1, q2 = P.swu_g2_helper(P.hp2(b"\x01" + m, 0)), P.swu_g2_helper(P.hp2(b"\x01" + m, 1))
+        recs.append(f2(q1[0]) + f2(q1[1]) + f2(q2[0]) + f2(q2[1]))
+        want2.append(RC.hash_g2(m))
+    q1 = P.swu_g2_helper(P.hp2(b"\x01q", 0))
+    recs.append(f2(q1[0]) + f2(q1[1]) + f2(q1[0]) + f2(P.fq2_neg(q1[1])))
+    out, good = engine.debug_hash_tail(1, b"".join(recs), n + 1)
+    assert list(good) == [1] * n + [0]
+    assert [bytes(out[i]) for i in range(n)] == want2
+    # ScaleByCofactor of the try-and-increment point (g2.go:1078-1084)
+    dom = bytes(range(8))
+    m32 = [bytes([i]) * 32 for i in range(3)]
+    recs = []
+    for m in m32:
+        x0 = (int.from_bytes(P._sha(m + dom + b"\x01"), "big"), int.from_bytes(P._sha(m + dom + b"\x02"), "big"))
+        while True:
+            y0 = P.fq2_sqrt(P.fq2_add(P.fq2_mul(P.fq2_sqr(x0), x0), P.B_COEFF_FQ2))
+            if y0 is not None:
+                break
+            x0 = P.fq2_add(x0, P.FQ2_ONE)
+        if not P.fq2_parity(y0):
+            y0 = P.fq2_neg(y0)
+        recs.append(f2(x0) + f2(y0))
+    out, good = engine.debug_hash_tail(2, b"".join(recs), 3)
+    want3 = [RC.hash_g2_with_domain(m, dom) for m in m32]
+    assert list(good) == [1, 1, 1] and [bytes(out[i]) for i in range(3)] == want3
+    # the redo kernels
+    flags = np.array([1, 0, 1, 0, 0], dtype=np.uint8)
+    for kind, hb, wv in ((0, 96, want), (1, 192, want2)):
+        o = engine.debug_hash_redo(kind, msgs, flags, np.full((n, hb), 0xAA, dtype=np.uint8))
+        for i in range(n):
+            assert bytes(o[i]) == (wv[i] if flags[i] == 0 else b"\xaa" * hb)
+    o = engine.debug_hash_redo(2, m32, np.array([0, 1, 0], dtype=np.uint8), np.full((3, 192), 0xAA, dtype=np.uint8), domain8=dom)
+    assert bytes(o[0]) == want3[0] and bytes(o[1]) == b"\xaa" * 192 and bytes(o[2]) == want3[2]
+
+
 # ---- the two paths against each other, at the largest batch the latency path takes ---------------------------------------
 def test_latency_and_throughput_paths_agree_on_4096_tuples():
     """4 096 distinct (P, Q) pairs and 4 096 g2pubs tuples with a corruption schedule: the latency path (one tuple per wave,

@@ -19,7 +19,7 @@ sys.setrecursionlimit(100000)
 
 @pytest.fixture(scope="module")
 def progs():
-    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "finalexp1")}
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "finalexp1", "hashfin1", "hashfin2", "cofac2")}
 
 
 def _pt(xs):
@@ -66,6 +66,47 @@ def test_final_exponentiation_and_aggregate_tail_programs(progs):
         inputs = dict(qin); inputs[G.BUF_RAW3] = P.fq12_flat(R)
         out = G.simulate(progs["aggtail"], inputs)
         assert (out == [1] + [0] * 11) is want
+
+
+def _f2(v):
+    return [v[0], v[1]]
+
+
+def test_hash_tail_programs_match_oracle(progs):
+    """the curve-arithmetic tails of HashG1 / HashG2 / HashG2WithDomain: outputs are the affine hash point, the check values
+    are nonzero for ordinary inputs and the final one is zero when the result is the point at infinity"""
+    msgs = [b"", b"abc", bytes(range(70))]
+    for m in msgs:
+        t1, t2 = P.hp(b"\x01" + m, 0), P.hp(b"\x01" + m, 1)
+        p1, p2 = P.swu_g1_helper(t1), P.swu_g1_helper(t2)
+        out = G.simulate(progs["hashfin1"], {0: [p1[0], p1[1], p2[0], p2[1]]})
+        want = P.hash_g1(m)
+        assert out[:2] == [want[0], want[1]] and all(out[2:])                    # hash.go:326-331
+        u1, u2 = P.hp2(b"\x01" + m, 0), P.hp2(b"\x01" + m, 1)
+        q1, q2 = P.swu_g2_helper(u1), P.swu_g2_helper(u2)
+        out = G.simulate(progs["hashfin2"], {0: _f2(q1[0]) + _f2(q1[1]) + _f2(q2[0]) + _f2(q2[1])})
+        want = P.hash_g2(m)
+        assert out[:4] == _f2(want[0]) + _f2(want[1]) and all(out[4:])           # hash.go:405-411
+    # opposite mapped points: the sum is the point at infinity, flagged by a zero check value (the caller falls back)
+    p1 = P.swu_g1_helper(P.hp(b"\x01x", 0))
+    out = G.simulate(progs["hashfin1"], {0: [p1[0], p1[1], p1[0], (-p1[1]) % P.Q]})
+    assert out[2] == 0 and out[3] and out[4] and out[5] == 0
+    # equal mapped points: flagged as well (the reference doubles with the a = 0 formula on the isogenous curve)
+    out = G.simulate(progs["hashfin1"], {0: [p1[0], p1[1], p1[0], p1[1]]})
+    assert out[5] == 0 and out[2] and out[3] and out[4]
+    # ScaleByCofactor (g2.go:104-138) of the try-and-increment point
+    msg32, dom = bytes(range(32)), bytes(range(8))
+    x0 = (int.from_bytes(P._sha(msg32 + dom + b"\x01"), "big"), int.from_bytes(P._sha(msg32 + dom + b"\x02"), "big"))
+    while True:
+        y0 = P.fq2_sqrt(P.fq2_add(P.fq2_mul(P.fq2_sqr(x0), x0), P.B_COEFF_FQ2))
+        if y0 is not None:
+            break
+        x0 = P.fq2_add(x0, P.FQ2_ONE)
+    if not P.fq2_parity(y0):
+        y0 = P.fq2_neg(y0)
+    out = G.simulate(progs["cofac2"], {0: _f2(x0) + _f2(y0)})
+    want = P.jac_to_affine(P.F2, P.hash_g2_with_domain(msg32, dom))
+    assert out[:4] == _f2(want[0]) + _f2(want[1]) and out[4]
 
 
 def test_program_bounds_and_shape(progs):
