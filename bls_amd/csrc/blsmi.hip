@@ -382,6 +382,14 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
         HIPCHK(hipStreamSynchronize(s));
         return BLSMI_OK;
     }
+    if (mode == 1 && n <= g_lat_max) {                                     // small MillerLoop call: the reference's steps as a level program
+        hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(LAT_MILLER1X_OFFSET), s, (const u8*)g_gens.lat + LAT_MILLER1X_OFFSET,
+                           (const u8*)d_g1, (size_t)96, (const u8*)d_g2, (size_t)192, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                           (const u8*)nullptr, (u8*)nullptr, (u64*)d_out, n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return BLSMI_OK;
+    }
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
     const bool prof = g_profile.load();

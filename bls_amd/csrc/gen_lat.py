@@ -37,7 +37,7 @@ NLIMB, LB = 15, 27
 RMONT = 1 << (NLIMB * LB)
 
 # job / level kinds (shared with k_lat.hip)
-K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF = 0, 1, 2, 3, 4, 5, 6, 7
+K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF, K_ISZERO = 0, 1, 2, 3, 4, 5, 6, 7, 8
 LANES = 64
 TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
 TLIN = 14             # terms of a LIN job (both operand fields)
@@ -420,16 +420,60 @@ class Pairing:
         line = (T.lin2(T.sub2(T.mul2(th, xq), T.mul2(la, yq))), T.neg2(th), la)
         return (T.lin2(X3), T.lin2(Y3), T.lin2(Z3), self.b.lin(Z3[0] + Z3[1]), self.b.lin(Z3[0] - Z3[1])), line
 
+    def dbl_step_ref(self, R):
+        """doubling step with the reference's formulas (g2.go:655-708): the line coefficients are the reference's field
+        elements (G2Prepared), which the Miller VALUE -- not only the pairing -- depends on.  Three product levels."""
+        T = self.T
+        X, Y, Z = R[0], R[1], R[2]
+        tmp0, tmp1, zsq = T.lin2(T.sqr2(X)), T.lin2(T.sqr2(Y)), T.lin2(T.sqr2(Z))
+        nz = T.lin2(T.sub2(T.sub2(T.sqr2(T.add2(Z, Y)), tmp1), zsq))
+        tmp2 = T.lin2(T.sqr2(tmp1))
+        tmp3 = T.lin2(T.sc2(T.sub2(T.sub2(T.sqr2(T.add2(tmp1, X)), tmp0), tmp2), 2))
+        tmp4 = T.sc2(tmp0, 3)
+        tmp5 = T.lin2(T.sqr2(tmp4))
+        tmp6 = T.add2(X, tmp4)
+        nx = T.lin2(T.sub2(tmp5, T.sc2(tmp3, 2)))
+        ny = T.lin2(T.sub2(T.mul2(T.sub2(tmp3, nx), tmp4, kar=True), T.sc2(tmp2, 8)))
+        o1 = T.sc2(T.mul2(tmp4, zsq, kar=True), -2)
+        o2 = T.lin2(T.sub2(T.sub2(T.sub2(T.sqr2(tmp6), tmp0), tmp5), T.sc2(tmp1, 4)))
+        o0 = T.sc2(T.mul2(nz, zsq, kar=True), 2)
+        return (nx, ny, nz), (o2, o1, o0)
+
+    def add_step_ref(self, R, Qa, ysq):
+        """addition step with the reference's formulas (g2.go:710-772)"""
+        T = self.T
+        X, Y, Z = R[0], R[1], R[2]
+        qx, qy = Qa
+        zsq = T.lin2(T.sqr2(Z))
+        t0 = T.mul2(zsq, qx, kar=True)
+        t1 = T.lin2(T.mul2(T.lin2(T.sub2(T.sub2(T.sqr2(T.add2(qy, Z)), ysq), zsq)), zsq, kar=True))
+        t2 = T.lin2(T.sub2(t0, X))
+        t3 = T.lin2(T.sqr2(t2))
+        t4 = T.sc2(t3, 4)
+        t5 = T.lin2(T.mul2(t4, t2, kar=True))
+        t6 = T.lin2(T.sub2(t1, T.sc2(Y, 2)))
+        t9 = T.mul2(t6, qx, kar=True)
+        t7 = T.lin2(T.mul2(t4, X, kar=True))
+        nx = T.lin2(T.sub2(T.sub2(T.sqr2(t6), t5), T.sc2(t7, 2)))
+        nz = T.lin2(T.sub2(T.sub2(T.sqr2(T.add2(Z, t2)), zsq), t3))
+        t8 = T.mul2(T.sub2(t7, nx), t6, kar=True)
+        ny = T.lin2(T.sub2(t8, T.sc2(T.mul2(Y, t5, kar=True), 2)))
+        t10 = T.sub2(T.sub2(T.sqr2(T.add2(qy, nz)), ysq), T.sqr2(nz))
+        o2 = T.lin2(T.sub2(T.sc2(t9, 2), t10))
+        return (nx, ny, nz), (o2, T.sc2(t6, -2), T.sc2(nz, 2))
+
     def eval_line(self, line, P):
         """(c0, o1, o0) at P = (xP, yP): the 014 element (c0, o1 xP, o0 yP)"""
         T = self.T
         return (line[0], T.lin2(T.mul2_fq(line[1], P[0])), T.lin2(T.mul2_fq(line[2], P[1])))
 
-    def miller(self, pairs):
-        """prod_k MillerLoop(P_k, Q_k) for 1 or 2 pairs: g <- g^2 * lines, lines of a step multiplied together first"""
+    def miller(self, pairs, exact=False):
+        """prod_k MillerLoop(P_k, Q_k) for 1 or 2 pairs: g <- g^2 * lines, lines of a step multiplied together first.
+        exact: the reference's doubling / addition steps -- the result is the reference's Miller value itself (pairing.go:16-75)"""
         T = self.T
         one = self.b.const(1)
         Rs = [(q[0], q[1], (one, Lin()), one, one) for _, q in pairs]            # (X, Y, Z, z0 + z1, z0 - z1) with Z = 1
+        ysq = [T.lin2(T.sqr2(q[1])) for _, q in pairs] if exact else None
         g = None
         xr = X_ABS >> 1
 
@@ -461,7 +505,10 @@ class Pairing:
         for s in steps:
             lines = []
             for k, (P, Qa) in enumerate(pairs):
-                Rs[k], ln = (self.dbl_step(Rs[k]) if s == "dbl" else self.add_step(Rs[k], Qa))
+                if exact:
+                    Rs[k], ln = (self.dbl_step_ref(Rs[k]) if s == "dbl" else self.add_step_ref(Rs[k], Qa, ysq[k]))
+                else:
+                    Rs[k], ln = (self.dbl_step(Rs[k]) if s == "dbl" else self.add_step(Rs[k], Qa))
                 lines.append(self.eval_line(ln, P))
             g = absorb(g, lines, square=(s == "dbl"))
         return T.conj12(g)                                          # x < 0 (pairing.go:71-73)
@@ -743,11 +790,14 @@ def build_program(kind):
              'aggtail'  -- the tail of VerifyAggregate: P (buf 0), Q (buf 1) and an Fq12 R in the device representation (buf 3);
                            verdict = FE(ML(-P, Q) * R) == 1, i.e. e(P, Q) == FE(R) with ONE final exponentiation
              'finalexp1' -- input an Fq12 in the wire format (buf 0); output FE(f) as 12 Fq (pairing.go:79-129)
-             'miller1raw' -- inputs P (buf 0), Q (buf 1); output a Miller value of (P, Q) in the device representation"""
+             'miller1raw' -- inputs P (buf 0), Q (buf 1); output a Miller value of (P, Q) in the device representation
+             'miller1x' -- inputs P (buf 0), Q (buf 1); output MillerLoop(P, Q), the reference's value (pairing.go:16-75), as 12 Fq"""
     b = Builder()
     pr = Pairing(b)
     if kind in ("hashfin1", "hashfin2", "cofac2"):
         return build_hash_program(b, pr.T, kind)
+    if kind in ("subgrp1", "subgrp2"):
+        return build_subgroup_program(b, pr.T, kind)
     if kind == "aggtail":
         P = (b.inp(0, 0), -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         R = unflat12([b.inp(BUF_RAW3, e) for e in range(12)])
@@ -760,6 +810,11 @@ def build_program(kind):
         # the reference's Miller value by a factor in Fq2* (projective lines), which every final exponentiation downstream removes.
         P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         b.out = ("outraw12", flat12(pr.T.lin12(pr.miller([(P, Qa)]), True)))
+        return b
+    if kind == "miller1x":
+        # the reference's Miller value itself (MillerLoop is an exported function, pairing.go:16): reference steps, wire format
+        P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        b.out = ("out12", flat12(pr.T.lin12(pr.miller([(P, Qa)], exact=True), True)))
         return b
     if kind == "finalexp1":
         f = unflat12([b.inp(BUF_M384_0, e) for e in range(12)])
@@ -776,6 +831,57 @@ def build_program(kind):
         f = pr.final_exp(pr.miller([(P, Qa)]))
         outs = flat12(pr.T.lin12(f, True))
         b.out = ("out12", outs)
+    return b
+
+
+def g1_beta():
+    """the cube root of unity beta with phi(x, y) = (beta x, y) = [-x^2] (x, y) on G1 (see gen_consts.py: checked on the generator)"""
+    G1 = (3685416753713387016781088315183077757961620795782546409894578378688607592378376318836054947676345821548104185464507,
+          1339506544944476473020471379941921221584933875938349620426543736416511423956333506472724655353366534992391756441569)
+    def add(P1, P2):
+        if P1 is None: return P2
+        if P2 is None: return P1
+        (x1, y1), (x2, y2) = P1, P2
+        if x1 == x2:
+            if (y1 + y2) % Q == 0: return None
+            l = 3 * x1 * x1 * pow(2 * y1, -1, Q) % Q
+        else:
+            l = (y2 - y1) * pow(x2 - x1, -1, Q) % Q
+        x3 = (l * l - x1 - x2) % Q
+        return (x3, (l * (x1 - x3) - y1) % Q)
+    r = X_ABS**4 - X_ABS**2 + 1
+    lam = (-(X_ABS ** 2)) % r
+    R = None
+    for bit in bin(lam)[2:]:
+        R = add(R, R)
+        if bit == "1": R = add(R, G1)
+    for g in range(2, 20):
+        beta = pow(g, (Q - 1) // 3, Q)
+        if beta != 1 and (beta * G1[0] % Q, G1[1]) == R:
+            return beta
+    raise AssertionError("beta")
+
+
+def build_subgroup_program(b, T, kind):
+    """IsInCorrectSubgroupAssumingOnCurve (g1.go:137-141, g2.go:293-295) through the endomorphisms, as k_hash.hip does it per
+    lane: G1: [x^2] P + phi(P) is the point at infinity; G2: [|x|] P + psi(P) is.  Output: the Z coordinate of that sum (zero
+    exactly for points of the subgroup, the formulas being complete).  Input: an affine point ON the curve (buffer 0)."""
+    if kind == "subgrp1":
+        F = Fld1(b); C = Curve(F)
+        x, y = b.inp(0, 0), b.inp(0, 1)
+        one = F.one()
+        P = (x, y, one)
+        R = C.mul_u64(C.mul_u64(P, X_ABS), X_ABS)
+        S = C.add(R, (F.lin(F.mul(F.const(g1_beta()), x)), y, one))
+        outs = [b.lin(S[2], True)]
+    else:
+        F = Fld2(b, T); C = Curve(F)
+        pt = ((b.inp(0, 0), b.inp(0, 1)), (b.inp(0, 2), b.inp(0, 3)))
+        P = (pt[0], pt[1], F.one())
+        S = C.add(C.mul_u64(P, X_ABS), psi_proj(F, P))
+        z = F.lin(S[2], True)
+        outs = [z[0], z[1]]
+    b.out = ("iszero", outs, len(outs))
     return b
 
 
@@ -962,7 +1068,7 @@ def encode(p):
             desc += struct.pack("<16H", *r)
         red = 0x80 if (k == K_LIN and any(n.reduce for n in jobs)) else 0   # value reduction is level-wide (always valid, never needed less)
         hdr.append((k | red, ntx, nty, len(jobs)))
-    out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12, "outaff": K_OUTAFF}[p.out]
+    out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12, "outaff": K_OUTAFF, "iszero": K_ISZERO}[p.out]
     blob = bytearray()
     assert len(p.out_nodes) <= 12
     blob += struct.pack("<8I", 0x54414c42, len(p.levels), p.nslot + 1, len(p.consts), out_kind, p.nout, len(p.out_nodes) - p.nout, 0)
@@ -993,7 +1099,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "hashfin1", "hashfin2", "cofac2"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

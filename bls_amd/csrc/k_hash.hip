@@ -206,6 +206,16 @@ KERNEL k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, s
         out_inf[t] = inf; err[t] = e;
     }
 }
+// Small batches: the decompression kernels run without their subgroup test, the test runs as a level program of the latency
+// path (k_lat.hip: subgrp1 / subgrp2, one point per wave) and this kernel applies its verdict -- what the kernels above do
+// for e = 4: the record becomes the all-zero (infinity) record and the error code is set.
+KERNEL k_apply_subgroup(const u8* in_subgroup, u8* out, int rec_words, const u8* out_inf, u8* err, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n || err[t] || out_inf[t] || in_subgroup[t]) return;
+    err[t] = 4;
+    u32* w = reinterpret_cast<u32*>(out) + (size_t)rec_words * t;
+    for (int i = 0; i < rec_words; i++) w[i] = 0;
+}
 // tuple flags for the verify kernels from the two deserialisation results: bit 0 = unusable public key, bit 1 = unusable signature
 KERNEL k_merge_flags(const u8* inf_pk, const u8* err_pk, const u8* inf_sig, const u8* err_sig, u8* flags, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;

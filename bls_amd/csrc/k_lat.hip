@@ -17,7 +17,7 @@
 #include "device_io.cuh"
 
 namespace {
-constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7;
+constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8;
 constexpr int SLOT_WORDS = 16;
 
 struct LatHeader {                      // gen_lat.py: encode()
@@ -74,6 +74,7 @@ BLSMI_DEV void store_slot(i32* S, u32 slot, const i32 r[NL]) {
 // bufs: up to four input arrays of affine records (48-byte big-endian field elements), stride 0 = one broadcast record.
 // out_kind CHECK1: ok[t] = (result == 1) && !flags[t];  OUT12: out[t] = the 12 Fq of the result as Montgomery-384 words;
 // OUTRAW12: out = int32 structure-of-arrays buffer of the n results in the device representation.
+// ISZERO: ok[t] = the result elements are all zero.
 // OUTAFF: out = n records of nout big-endian 48-byte field elements (an affine point), ok[t] = 0 when a step was exceptional.
 __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, size_t s0, const u8* b1, size_t s1, const u8* b2, size_t s2,
                                                 const u8* b3, size_t s3, const u8* flags, u8* ok, u64* out, size_t n) {
@@ -164,7 +165,7 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
     // results leave LDS
     const int okind = (int)H->out_kind;
     FpS v = fp_zero();
-    const int nres = okind == K_OUTAFF ? (int)(H->nout + H->nchk) : 12;
+    const int nres = (okind == K_OUTAFF || okind == K_ISZERO) ? (int)(H->nout + H->nchk) : 12;
     if (lane < nres) {
         const i32* p = S + (u32)H->out_slot[lane] * SLOT_WORDS;
 #pragma unroll
@@ -174,6 +175,10 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
         const bool good = lane >= 12 ? true : (lane == 0 ? fp_eq(v, C_ONE) : fp_is_zero(v));
         const bool all = __all(good ? 1 : 0) != 0;
         if (lane == 0) ok[t] = (all && !(flags && flags[t])) ? 1 : 0;
+    } else if (okind == K_ISZERO) {                                            // ok[t] = every result element is zero
+        const bool nz = lane < nres && !fp_is_zero(v);
+        const bool any_nz = __any(nz ? 1 : 0) != 0;
+        if (lane == 0) ok[t] = any_nz ? 0 : 1;
     } else if (okind == K_OUTAFF) {                                            // affine coordinates in the wire format; ok[t] = no check value is zero
         const int nout = (int)H->nout;
         const bool bad = lane >= nout && lane < nres && fp_is_zero(v);

@@ -46,6 +46,7 @@ __global__ void k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const 
 __global__ void k_write_generators(u8* g1, u8* g2);
 __global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
 __global__ void k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
+__global__ void k_apply_subgroup(const u8* in_subgroup, u8* out, int rec_words, const u8* out_inf, u8* err, size_t n);
 __global__ void k_merge_flags(const u8* inf_pk, const u8* err_pk, const u8* inf_sig, const u8* err_sig, u8* flags, size_t n);
 __global__ void k_flag_zero_records(const u8* pks, int pk_words, const u8* sigs, int sig_words, const u8* in_flags, u8* flags, int* any, size_t n);
 __global__ void k_pack_bitmap(const u8* ok, u8* bitmap, size_t n);

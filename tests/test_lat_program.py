@@ -19,7 +19,7 @@ sys.setrecursionlimit(100000)
 
 @pytest.fixture(scope="module")
 def progs():
-    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "finalexp1", "hashfin1", "hashfin2", "cofac2")}
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
 
 
 def _pt(xs):
@@ -35,6 +35,14 @@ def test_pairing_program_matches_oracle(progs, kats):
         assert out == P.fq12_flat(P.pairing(Pa, Qa))
     out = G.simulate(p, {0: list(P.G1_GEN), 1: [P.G2_GEN[0][0], P.G2_GEN[0][1], P.G2_GEN[1][0], P.G2_GEN[1][1]]})
     assert out == [int(v) for v in kats["pairing_g1gen_g2gen"]]               # the reference's own vector, pairing_test.go:9-58
+
+
+def test_exact_miller_program_is_the_reference_miller_value(progs):
+    p = progs["miller1x"]
+    xs = P.XORShift(15)
+    for Pa, Qa in [(P.G1_GEN, P.G2_GEN), _pt(xs)]:
+        out = G.simulate(p, {0: [Pa[0], Pa[1]], 1: [Qa[0][0], Qa[0][1], Qa[1][0], Qa[1][1]]})
+        assert out == P.fq12_flat(P.miller_loop([(Pa, P.g2_prepare(Qa))]))              # pairing.go:16-75
 
 
 def test_verify_program_matches_compare_two_pairings(progs):
@@ -107,6 +115,30 @@ def test_hash_tail_programs_match_oracle(progs):
     out = G.simulate(progs["cofac2"], {0: _f2(x0) + _f2(y0)})
     want = P.jac_to_affine(P.F2, P.hash_g2_with_domain(msg32, dom))
     assert out[:4] == _f2(want[0]) + _f2(want[1]) and out[4]
+
+
+def test_subgroup_programs(progs):
+    """[x^2] P + phi(P) / [|x|] P + psi(P): zero Z exactly for points of the prime-order subgroups (g1.go:137-141, g2.go:293-295)"""
+    xs = P.XORShift(21)
+    Pa, Qa = _pt(xs)
+    assert G.simulate(progs["subgrp1"], {0: [Pa[0], Pa[1]]}) == [0]
+    assert G.simulate(progs["subgrp2"], {0: [Qa[0][0], Qa[0][1], Qa[1][0], Qa[1][1]]}) == [0, 0]
+    # curve points outside the subgroups (a random curve point is, with overwhelming probability)
+    x = 5
+    while True:
+        y = P.fq_sqrt((x * x * x + 4) % P.Q)
+        if y is not None:
+            break
+        x += 1
+    assert not P.g1_in_subgroup((x, y))
+    assert G.simulate(progs["subgrp1"], {0: [x, y]}) != [0]
+    x2 = (7, 1)
+    while True:
+        y2 = P.fq2_sqrt(P.fq2_add(P.fq2_mul(P.fq2_sqr(x2), x2), P.B_COEFF_FQ2))
+        if y2 is not None:
+            break
+        x2 = P.fq2_add(x2, P.FQ2_ONE)
+    assert G.simulate(progs["subgrp2"], {0: [x2[0], x2[1], y2[0], y2[1]]}) != [0, 0]
 
 
 def test_program_bounds_and_shape(progs):
