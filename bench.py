@@ -357,7 +357,7 @@ def main():
     if rank == 0:
         ml = float(np.mean([k[0] for k in kms])); fe = float(np.mean([k[1] for k in kms]))
         suffix = "" if os.environ.get("BLSMI_LAYOUT") == "single" else "_pair"
-        kname = {"ml": "k_miller1" + suffix, "fe": "k_final_exp" + suffix}
+        kname = {"ml": "k_miller1h" + suffix, "fe": "k_final_exp" + suffix}      # the kernels of blsmi_pairing_batch_dev (blsmi.hip: pairing_dev, mode 0)
         dom, dom_ms = (kname["fe"], fe) if fe >= ml else (kname["ml"], ml)
         achieved = BYTES_PER_PAIRING * n / (dom_ms * 1e-3) / 1e9
         value = world * n * args.steps / dt

@@ -396,8 +396,9 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     if (prof && !tl_ctx->ev[0]) for (auto& e : tl_ctx->ev) HIPCHK(hipEventCreate(&e));
     if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[0], s));
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
-    if (g_pair_layout) hipLaunchKernelGGL(k_miller1_pair, dim3(pblocks), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
-    else hipLaunchKernelGGL(k_miller1, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+    // mode 1 (MillerLoop): the reference's steps; mode 0 (Pairing): the homogeneous steps
+    if (g_pair_layout) hipLaunchKernelGGL(mode ? k_miller1_pair : k_miller1h_pair, dim3(pblocks), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+    else hipLaunchKernelGGL(mode ? k_miller1 : k_miller1h, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
     if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[1], s));
     if (g_pair_layout) hipLaunchKernelGGL(k_final_exp_pair, dim3(pblocks), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
     else hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);

@@ -8,7 +8,7 @@
 // kernels: pairing
 // ------------------------------------------------------------------------------------------------
 // Miller loop for one pair per tuple; f goes to the internal SoA buffer (or nowhere else).
-KERNEL k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
+template <bool EXACT> BLSMI_DEV void miller1_body(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
     __shared__ u32 lds[WG * 49];
     const size_t first = (size_t)blockIdx.x * WG;
     const size_t t = first + threadIdx.x;
@@ -20,9 +20,12 @@ KERNEL k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
     tile_load<48>(lds, g2, first, n);
     q[0] = lds_g2(lds + rec * 49);
     Fp12S f;
-    miller_loop<1>(f, p, q);
+    miller_loop<1, false, EXACT>(f, p, q);
     if (t < n) soa_store12(fbuf, n, t, f);
 }
+// k_miller1: the reference's Miller value; k_miller1h: the homogeneous steps (see pairing_body.inc)
+KERNEL k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n) { miller1_body<true>(g1, g2, fbuf, n); }
+KERNEL k_miller1h(const u8* g1, const u8* g2, i32* fbuf, size_t n) { miller1_body<false>(g1, g2, fbuf, n); }
 // mode 0: out = FE(f) as Montgomery-384 limbs; mode 1: out = f itself (no final exponentiation)
 KERNEL k_final_exp(const i32* fbuf, u64* out, size_t n, int mode) {
     __shared__ u32 lds[WG * 145];
@@ -68,8 +71,8 @@ KERNEL k_miller2(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p
     tile_load<48>(lds, q1, first, n); q[1] = lds_g2(lds + rec * 49);
     (void)tt; (void)sp1; (void)sq1;
     Fp12S f;
-    if (pre) miller_loop<2, true>(f, p, q, pre);
-    else miller_loop<2>(f, p, q);
+    if (pre) miller_loop<2, true, false>(f, p, q, pre);
+    else miller_loop<2, false, false>(f, p, q);
     if (t < n) soa_store12(fbuf, n, t, f);
 }
 // ok[t] = FinalExponentiation(f_t) == 1, and 0 for tuples flagged as containing a point at infinity

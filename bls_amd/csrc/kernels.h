@@ -7,6 +7,7 @@ using namespace blsmi;
 constexpr int PT = WG / 2;          // tuples per workgroup of the lane-pair kernels
 // k_pairing_single.hip
 __global__ void k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n);
+__global__ void k_miller1h(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_final_exp(const i32* fbuf, u64* out, size_t n, int mode);
 __global__ void k_fq12_from_m384(const u64* in, i32* fbuf, size_t n);
 __global__ void k_prepare_generator_lines(const u8* g2, i32* table);
@@ -24,6 +25,7 @@ __global__ void k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size
 __global__ void k_debug_prepare_pair(const u8* g2, i32* table);
 // pair_kernels.inc
 __global__ void k_miller1_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
+__global__ void k_miller1h_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_final_exp_pair(const i32* fbuf, u64* out, size_t n, int mode);
 __global__ void k_miller2_pair(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
 __global__ void k_final_exp_is_one_pair(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
