@@ -643,6 +643,23 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
         std::swap(src, dst);
         seg = half;
     }
+    // Horner over the windows (240 dependent doublings) and ToAffine: one wave as a level program of the latency path
+    // (k_lat.hip: msmfin1 / msmfin2, two product levels per doubling) instead of one lane (k.final: 3 / 8 ms)
+    static_assert(W == 3 || W == 6, "G1 / G2");
+    if (g_lat_hash && c == 16 && nwin == 16) {
+        const size_t prog = W == 3 ? LAT_MSMFIN1_OFFSET : LAT_MSMFIN2_OFFSET;
+        DBuf good; HIPCHK(good.alloc(1, s));
+        hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, (const u8*)nullptr, (size_t)0,
+                           (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)nwin,
+                           (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), (size_t)1);
+        HIPCHK(hipGetLastError());
+        u8 good_h = 0;
+        HIPCHK(hipMemcpyAsync(&good_h, good.p, 1, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemsetAsync(d_flag, good_h ? 0 : 1, sizeof(i32), s));    // nonzero = the sum is the point at infinity (record all zero)
+        HIPCHK(hipStreamSynchronize(s));
+        return BLSMI_OK;
+    }
     hipLaunchKernelGGL(k.final, dim3(1), dim3(WG), 0, s, (const i32*)src, nwin, c, d_out, d_flag);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));                                       // temporaries die with this scope

@@ -778,6 +778,12 @@ def flat12(f):
 
 BUF_RAW3 = 8       # LOAD: element e of the raw device representation (15 int32 limbs, structure-of-arrays with n = 1) at buffer 3
 BUF_M384_0 = 9     # LOAD: element e of the Fq wire format (6 little-endian uint64, Montgomery 2^384) at buffer 0
+BUF_SOA3 = 10      # LOAD: coordinate e of Jacobian record w of a structure-of-arrays buffer of `stride` records (buffer 3, stride = its
+                   # stride argument): element = e | w << 3 | (1 << 8 for 6-coordinate records); a record flagged infinite reads as (0, 1, 0)
+
+
+def soa_el(e, w, six):
+    return e | (w << 3) | ((1 << 8) if six else 0)
 
 
 def unflat12(v):
@@ -798,6 +804,8 @@ def build_program(kind):
         return build_hash_program(b, pr.T, kind)
     if kind in ("subgrp1", "subgrp2"):
         return build_subgroup_program(b, pr.T, kind)
+    if kind in ("msmfin1", "msmfin2"):
+        return build_msm_final_program(b, pr.T, kind)
     if kind == "aggtail":
         P = (b.inp(0, 0), -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         R = unflat12([b.inp(BUF_RAW3, e) for e in range(12)])
@@ -882,6 +890,34 @@ def build_subgroup_program(b, T, kind):
         z = F.lin(S[2], True)
         outs = [z[0], z[1]]
     b.out = ("iszero", outs, len(outs))
+    return b
+
+
+def build_msm_final_program(b, T, kind, nwin=16, c=16):
+    """the tail of the bucket-method MSM (msm.inc step 4): join the nwin window sums by Horner in 2^c -- c doublings and one
+    addition per window, 240 dependent doublings -- and convert to affine.  Inputs: the window sums as the kernels leave them
+    (Jacobian, raw limbs, structure of arrays); (X, Y, Z) Jacobian = (X Z : Y : Z^3) homogeneous.  Output: the affine sum and
+    its Z (zero for the point at infinity)."""
+    six = kind == "msmfin2"
+    F = Fld2(b, T) if six else Fld1(b)
+    C = Curve(F)
+    def coord(w, j):
+        if six:
+            return (b.lin(b.inp(BUF_SOA3, soa_el(2 * j, w, True)), True), b.lin(b.inp(BUF_SOA3, soa_el(2 * j + 1, w, True)), True))
+        return b.lin(b.inp(BUF_SOA3, soa_el(j, w, False)), True)
+    W = []
+    for w in range(nwin):
+        X, Y, Z = coord(w, 0), coord(w, 1), coord(w, 2)
+        z2 = F.lin(F.sqr(Z))
+        W.append((F.lin(F.mul(X, Z)), Y, F.lin(F.mul(z2, Z))))
+    R = W[nwin - 1]
+    for w in range(nwin - 2, -1, -1):
+        for _ in range(c):
+            R = C.dbl(R)
+        R = C.add(R, W[w])
+    x, y = C.to_affine(R)
+    outs = F.coords(x) + F.coords(y)
+    b.out = ("outaff", outs + [b.lin(F.norm(R[2]), True)], len(outs))
     return b
 
 
@@ -1099,7 +1135,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -145,6 +145,16 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
                     const i32* raw = reinterpret_cast<const i32*>(b3 + s3 * t) + el * NL;
 #pragma unroll
                     for (int i = 0; i < NL; i++) y.v[i] = raw[i];
+                } else if (bsel == 10) {                                           // coordinate of a Jacobian SoA record (msm.inc, curve.cuh jac_soa_store) at buffer 3
+                    const u32 e = el & 7u, w = (el >> 3) & 31u, ncoord = (el >> 8) & 1u ? 6u : 3u;
+                    const i32* raw = reinterpret_cast<const i32*>(b3);
+                    const size_t cnt = s3;                                         // records in the buffer = word stride
+#pragma unroll
+                    for (int i = 0; i < NL; i++) y.v[i] = raw[((size_t)e * NL + i) * cnt + w];
+                    if (raw[(size_t)ncoord * NL * cnt + w]) {                      // flagged infinite: (0, 1, 0) whatever the coordinates hold
+                        y = fp_zero();
+                        if (e == ncoord / 3) y = C_ONE;
+                    }
                 } else if (bsel == 9) {                                            // Fq wire format (Montgomery 2^384 limbs) at buffer 0
                     y = load_m384(reinterpret_cast<const u64*>(b0 + s0 * t) + 6 * el);
                 } else {

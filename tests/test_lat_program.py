@@ -141,6 +141,39 @@ def test_subgroup_programs(progs):
     assert G.simulate(progs["subgrp2"], {0: [x2[0], x2[1], y2[0], y2[1]]}) != [0, 0]
 
 
+def test_msm_final_programs():
+    """Horner over 16 window sums given in Jacobian coordinates: sum_w 2^(16 w) W_w, affine"""
+    xs = P.XORShift(31)
+    for kind, Fd, gen, six in (("msmfin1", P.F1, P.G1_GEN, False), ("msmfin2", P.F2, P.G2_GEN, True)):
+        p = G.schedule(G.build_program(kind))
+        ks = [P.rand_fr(xs) for _ in range(16)]
+        ks[3] = 0                                                              # an empty window: the point at infinity
+        inputs, total = {}, 0
+        for w, k in enumerate(ks):
+            total += k << (16 * w)
+            if k == 0:
+                coords = (0, 1, 0) if not six else ((0, 0), (1, 0), (0, 0))   # what the loader produces for a flagged record
+            else:
+                a = P.jac_to_affine(Fd, P.affine_mul(Fd, gen, k))
+                z = P.rand_int(xs, P.Q - 1) + 1                                # a random Jacobian representative (x z^2, y z^3, z)
+                if six:
+                    zz = (z, 0); z2 = P.fq2_sqr(zz); z3 = P.fq2_mul(z2, zz)
+                    coords = (P.fq2_mul(a[0], z2), P.fq2_mul(a[1], z3), zz)
+                else:
+                    coords = (a[0] * z * z % P.Q, a[1] * z * z * z % P.Q, z)
+            for j, cj in enumerate(coords):
+                if six:
+                    inputs[G.soa_el(2 * j, w, True)] = cj[0]; inputs[G.soa_el(2 * j + 1, w, True)] = cj[1]
+                else:
+                    inputs[G.soa_el(j, w, False)] = cj
+        out = G.simulate(p, {G.BUF_SOA3: inputs})
+        want = P.jac_to_affine(Fd, P.affine_mul(Fd, gen, total % P.R_ORDER))
+        if six:
+            assert out[:4] == [want[0][0], want[0][1], want[1][0], want[1][1]] and out[4]
+        else:
+            assert out[:2] == [want[0], want[1]] and out[2]
+
+
 def test_program_bounds_and_shape(progs):
     for name, p in progs.items():
         assert p.nslot < 1024
