@@ -603,7 +603,7 @@ BLSMI_API int blsmi_g2_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, 
 // two cross over) on: the bucket method of msm.inc, whose fixed tail (chunk reduction + 240 serial doublings) is ~6 ms.
 constexpr int BLSMI_E_SKEW = -1000;    // internal: bucket method declined (unbalanced digits)
 struct MsmKernels {
-    void (*bucket)(const u8*, const u32*, const u32*, const u32*, i32*, size_t, int, size_t);
+    void (*bucket)(const u8*, const u32*, const u32*, const u32*, const u32*, i32*, size_t, int, size_t);
     void (*chunk)(const i32*, i32*, int, int, size_t, size_t);
     void (*fold)(const i32*, i32*, size_t, size_t, int);
     void (*final)(const i32*, int, int, u8*, i32*);
@@ -633,7 +633,15 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     if (biggest > 2048) return BLSMI_E_SKEW;
     hipLaunchKernelGGL(k_msm_scan, dim3(nwin), dim3(256), 0, s, (const u32*)hist.as<u32>(), offs.as<u32>(), cursor.as<u32>(), c);
     hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, n, c, nwin, cursor.as<u32>(), idx.as<u32>());
-    hipLaunchKernelGGL(k.bucket, dim3(nblocks(nb)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), buckets.as<i32>(), n, c, nb);
+    // buckets ranked by population, so that the 64 lanes of a wave add about the same number of points (msm.inc)
+    DBuf cls, perm;
+    HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
+    HIPCHK(hipMemsetAsync(cls.p, 0, sizeof(u32) * 256, s));
+    const unsigned cb = (unsigned)((nb + 255) / 256);
+    hipLaunchKernelGGL(k_msm_class_hist, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, cls.as<u32>());
+    hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(256), 0, s, (const u32*)cls.as<u32>(), cls.as<u32>() + 256, cls.as<u32>() + 512);
+    hipLaunchKernelGGL(k_msm_class_scatter, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, (const u32*)(cls.as<u32>() + 256), cls.as<u32>() + 512, perm.as<u32>());
+    hipLaunchKernelGGL(k.bucket, dim3(nblocks(nb)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), n, c, nb);
     hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
     i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
     size_t seg = per_win;

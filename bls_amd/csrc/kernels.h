@@ -75,8 +75,11 @@ __global__ void k_msm_hist(const u8* scalars, size_t n, int c, int nwin, u32* hi
 __global__ void k_msm_scan(const u32* hist, u32* offs, u32* cursor, int c);
 __global__ void k_msm_max(const u32* hist, size_t nb, u32* out);
 __global__ void k_msm_scatter(const u8* scalars, size_t n, int c, int nwin, u32* cursor, u32* idx);
-__global__ void k_g1_msm_bucket(const u8* pts, const u32* idx, const u32* offs, const u32* hist, i32* buckets, size_t n, int c, size_t nb);
-__global__ void k_g2_msm_bucket(const u8* pts, const u32* idx, const u32* offs, const u32* hist, i32* buckets, size_t n, int c, size_t nb);
+__global__ void k_msm_class_hist(const u32* hist, size_t nb, u32* cls);
+__global__ void k_msm_class_scan(const u32* cls, u32* class_off, u32* cursor);
+__global__ void k_msm_class_scatter(const u32* hist, size_t nb, const u32* class_off, u32* cursor, u32* perm);
+__global__ void k_g1_msm_bucket(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb);
+__global__ void k_g2_msm_bucket(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb);
 __global__ void k_g1_msm_chunk(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nct);
 __global__ void k_g2_msm_chunk(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nct);
 __global__ void k_g1_msm_fold(const i32* src, i32* dst, size_t seg, size_t half, int nwin);
