@@ -542,7 +542,16 @@ static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t*
     HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
     if (pts) { HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream)); }
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    if (PB == 192 && g_pair_layout)                                        // G2: lane-pair kernel, two waves per SIMD
+    if (n <= g_lat_max && g_lat_hash) {                                    // small call: one multiplication per wave (k_lat.hip, SEL levels)
+        const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
+        const u8* base = pts ? dp.as<u8>() : d_gen;
+        const size_t stride = pts ? (size_t)PB : 0;
+        DBuf good; HIPCHK(good.alloc(n));
+        hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(prog), g_stream, (const u8*)g_gens.lat + prog, base, stride,
+                           (const u8*)ds.as<u8>(), (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                           (const u8*)nullptr, good.as<u8>(), dout.as<u64>(), n);
+        hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(n)), dim3(WG), 0, g_stream, (const u8*)good.as<u8>(), base, stride, PB / 4, dout.as<u8>(), dinf.as<u8>(), n);
+    } else if (PB == 192 && g_pair_layout)                                 // G2: lane-pair kernel, two waves per SIMD
         hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((n + PT - 1) / PT)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
     else
         hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);

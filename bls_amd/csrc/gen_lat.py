@@ -37,7 +37,7 @@ NLIMB, LB = 15, 27
 RMONT = 1 << (NLIMB * LB)
 
 # job / level kinds (shared with k_lat.hip)
-K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF, K_ISZERO = 0, 1, 2, 3, 4, 5, 6, 7, 8
+K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF, K_ISZERO, K_SEL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 LANES = 64
 TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
 TLIN = 14             # terms of a LIN job (both operand fields)
@@ -108,6 +108,36 @@ class Builder:
         if v not in self.consts:
             self.consts[v] = self._node("const", V=1, aux=v)
         return Lin({self.consts[v]: 1})
+
+    def table(self, entries):
+        """entries: equally long lists of Lin values.  Every value is copied (a LIN job) into a slot of a contiguous, permanently
+        reserved block -- entry d, coordinate j at block + d * ncoord + j -- so that a SEL job can index the block with a digit
+        of the run-time scalar.  Returns the table id."""
+        if not hasattr(self, "tables"):
+            self.tables = []
+        tid = len(self.tables)
+        ncoord = len(entries[0])
+        nodes = []
+        for d, coords in enumerate(entries):
+            assert len(coords) == ncoord
+            for j, v in enumerate(coords):
+                v = self.flatten(Lin(v))
+                assert len(v) <= TLIN and v.L() <= LMAX and v.cmax() <= CMAX
+                n = self._node("lin", x=Lin(v), V=max(1, v.V()))
+                n.pin = (tid, d * ncoord + j)
+                nodes.append(n)
+        self.tables.append((ncoord, nodes))
+        return tid
+
+    def select(self, tid, window):
+        """the ncoord values of table entry digit(window), digit = 4-bit window `window` of the scalar (window 0 = least significant)"""
+        ncoord, nodes = self.tables[tid]
+        out = []
+        for j in range(ncoord):
+            deps = Lin({nodes[d * ncoord + j]: 1 for d in range(len(nodes) // ncoord)})       # dependencies, not a sum
+            n = self._node("sel", x=deps, V=max(t.V for t in deps), aux=(tid, j, window))
+            out.append(Lin({n: 1}))
+        return out
 
     def inp(self, buf, elem, name=""):
         n = self._node("in", V=1, aux=(buf, elem))
@@ -806,6 +836,8 @@ def build_program(kind):
         return build_subgroup_program(b, pr.T, kind)
     if kind in ("msmfin1", "msmfin2"):
         return build_msm_final_program(b, pr.T, kind)
+    if kind in ("mul1", "mul2"):
+        return build_mul_program(b, pr.T, kind)
     if kind == "aggtail":
         P = (b.inp(0, 0), -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         R = unflat12([b.inp(BUF_RAW3, e) for e in range(12)])
@@ -921,6 +953,38 @@ def build_msm_final_program(b, T, kind, nwin=16, c=16):
     return b
 
 
+def build_mul_program(b, T, kind):
+    """[k] P for a run-time 256-bit scalar k (g1.go:80-90 / g2.go MulFR: same group element): fixed 4-bit windows, the table
+    0 P .. 15 P lives in a reserved slot block and a SEL level picks entry digit_w(k) per window -- the control flow does not
+    depend on the scalar.  Inputs: the affine point (buffer 0), the scalar as 32 big-endian bytes (buffer 1).
+    Output: the affine product and its Z (zero for the point at infinity)."""
+    six = kind == "mul2"
+    F = Fld2(b, T) if six else Fld1(b)
+    C = Curve(F)
+    if six:
+        pt = ((b.inp(0, 0), b.inp(0, 1)), (b.inp(0, 2), b.inp(0, 3)))
+    else:
+        pt = (b.inp(0, 0), b.inp(0, 1))
+    P = (pt[0], pt[1], F.one())
+    tab = [(F.zero(), F.one(), F.zero()), P]
+    for d in range(2, 16):
+        tab.append(C.dbl(tab[d // 2]) if d % 2 == 0 else C.add(tab[d - 1], P))
+    flat = (lambda q: [q[0][0], q[0][1], q[1][0], q[1][1], q[2][0], q[2][1]]) if six else (lambda q: [q[0], q[1], q[2]])
+    unflat = (lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))) if six else (lambda v: (v[0], v[1], v[2]))
+    tid = b.table([flat(q) for q in tab])
+    R = None
+    for w in range(63, -1, -1):
+        if R is not None:
+            for _ in range(4):
+                R = C.dbl(R)
+        Sw = unflat(b.select(tid, w))
+        R = Sw if R is None else C.add(R, Sw)
+    x, y = C.to_affine(R)
+    outs = F.coords(x) + F.coords(y)
+    b.out = ("outaff", outs + [b.lin(F.norm(R[2]), True)], len(outs))
+    return b
+
+
 def build_hash_program(b, T, kind):
     """the curve-arithmetic tails of hash-to-curve; inputs: the affine outputs of the SWU maps (buffer 0), output: the affine
     hash point as wire-format field elements plus values that are zero exactly when a step was exceptional (an isogeny
@@ -982,8 +1046,8 @@ def schedule(b):
                 stack.extend(lin.keys())
     nodes = [n for n in b.nodes if n.id in live]
     levels = []                          # [kind, [nodes]]
-    kind_of = {"mul": K_MUL, "lin": K_LIN, "inv": K_INV, "in": K_LOAD}
-    cap = {K_MUL: LANES, K_LIN: LANES, K_INV: 1, K_LOAD: LANES}
+    kind_of = {"mul": K_MUL, "lin": K_LIN, "inv": K_INV, "in": K_LOAD, "sel": K_SEL}
+    cap = {K_MUL: LANES, K_LIN: LANES, K_INV: 1, K_LOAD: LANES, K_SEL: LANES}
     consts = [n for n in nodes if n.kind == "const"]
     for n in consts:
         n.level = -1
@@ -1021,15 +1085,23 @@ def schedule(b):
     nslot = 0
     for n in consts:
         n.slot = nslot; nslot += 1
+    table_base = {}
+    for tid, (ncoord, tnodes) in enumerate(getattr(b, "tables", [])):     # tables: contiguous blocks, never recycled
+        table_base[tid] = nslot
+        for n in tnodes:
+            n.slot = nslot + n.pin[1]
+        nslot += len(tnodes)
     free = []
     expiring = {}
     for n in nodes:
-        if n.kind != "const":
+        if n.kind != "const" and not n.pin:
             expiring.setdefault(n.last, []).append(n)
     for li, (k, jobs) in enumerate(levels):
         for n in expiring.get(li - 1, []):  # values last read in an EARLIER level are dead (a multi-wave workgroup gathers and
             free.append(n.slot)             # stores of one level without a barrier in between: no reuse within the level)
         for n in jobs:
+            if n.pin:
+                continue
             if free:
                 n.slot = free.pop()
             else:
@@ -1037,6 +1109,8 @@ def schedule(b):
     p = Program()
     p.levels, p.consts, p.nslot, p.out, p.out_nodes, p.nodes = levels, consts, nslot, b.out[0], out_nodes, nodes
     p.nout = b.out[2] if len(b.out) > 2 else len(out_nodes)
+    p.table_base = table_base
+    p.table_ncoord = {tid: nc for tid, (nc, _) in enumerate(getattr(b, "tables", []))}
     return p
 
 
@@ -1060,6 +1134,10 @@ def simulate(p, inputs):
             elif n.kind == "inv":
                 v = ev(n.x)
                 res.append(pow(v, -1, Q) if v else 0)
+            elif n.kind == "sel":
+                tid, j, w = n.aux
+                digit = (inputs["scalar"] >> (4 * w)) & 15
+                res.append(S[p.table_base[tid] + digit * p.table_ncoord[tid] + j])
         for n, r in zip(jobs, res):
             S[n.slot] = r
     return [S[n.slot] for n in p.out_nodes]
@@ -1095,6 +1173,9 @@ def encode(p):
                 flags = 1 if n.reduce else 0
             elif k == K_LOAD:
                 xs = [n.aux[0] | (n.aux[1] << 4)]; ys = []
+            elif k == K_SEL:                                             # raw fields: slot of entry 0, window; stride
+                tid, j, w = n.aux
+                xs = [p.table_base[tid] + j, w]; ys = [p.table_ncoord[tid]]
             assert len(xs) <= 7 and len(ys) <= 7
             ntx, nty = max(ntx, len(xs)), max(nty, len(ys))
             rows.append([n.slot] + xs + [NOTERM] * (7 - len(xs)) + ys + [NOTERM] * (7 - len(ys)) + [flags])
@@ -1135,7 +1216,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

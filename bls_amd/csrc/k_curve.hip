@@ -74,6 +74,18 @@ __device__ void mul_batch_body(const u8* pts, size_t pt_stride, const u8* scalar
     const Aff<F> a = jac_to_affine(res);
     if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
 }
+// Small batches run the multiplication as a level program of the latency path (k_lat.hip: mul1 / mul2); this kernel turns its
+// verdict into the out_inf byte and applies the library's convention for a multiplicand given as the all-zero record.
+KERNEL k_mul_finish(const u8* good, const u8* pts, size_t pt_stride, int rec_words, u8* out, u8* out_inf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    const u32* in = reinterpret_cast<const u32*>(pts + pt_stride * t);
+    u32 any = 0;
+    for (int i = 0; i < rec_words; i++) any |= in[i];
+    const bool inf = !good[t] || any == 0;
+    out_inf[t] = inf ? 1 : 0;
+    if (inf) { u32* w = reinterpret_cast<u32*>(out) + (size_t)rec_words * t; for (int i = 0; i < rec_words; i++) w[i] = 0; }
+}
 KERNEL2 k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
 KERNEL k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
 

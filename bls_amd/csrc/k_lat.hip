@@ -17,7 +17,7 @@
 #include "device_io.cuh"
 
 namespace {
-constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8;
+constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8, K_SEL = 9;
 constexpr int SLOT_WORDS = 16;
 
 struct LatHeader {                      // gen_lat.py: encode()
@@ -137,6 +137,18 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             const FpS y = fp_inv(x);                                           // inverse(0) = 0
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] = y.v[i];
+        } else if (kind == K_SEL) {                                            // table entry picked by a 4-bit digit of the tuple's scalar (buffer 1, 32 big-endian bytes)
+            // raw fields: tx[0] = slot of entry 0, tx[1] = window (0 = least significant), ty[0] = slots per entry
+#pragma unroll
+            for (int i = 0; i < NL; i++) r[i] = 0;
+            if (lane < njobs) {
+                const u32 w = tx[1];
+                const u32 digit = ((u32)(b1 + s1 * t)[31 - (w >> 1)] >> ((w & 1u) * 4u)) & 15u;
+                const int4* p = reinterpret_cast<const int4*>(S + (tx[0] + digit * ty[0]) * SLOT_WORDS);
+                const int4 a = p[0], b = p[1], d = p[2], e = p[3];
+                r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+                r[8] = d.x; r[9] = d.y; r[10] = d.z; r[11] = d.w; r[12] = e.x; r[13] = e.y; r[14] = e.z;
+            }
         } else {                                                               // K_LOAD: tx[0] = buffer | element << 4
             const u32 bsel = tx[0] & 15u, el = (tx[0] >> 4) & 0xfffu;
             FpS y = fp_zero();

@@ -215,6 +215,11 @@ def test_scalar_mul_and_sums(eng):
     for i in range(n):
         e = RC.g2_mul(pts2[i], ks[i])
         assert (e is None) == bool(inf[i]) and (e is None or out[i].tobytes() == e), i
+    # the all-zero record is the point at infinity (the library's convention): k * infinity = infinity
+    out, inf = eng.g1_mul_batch(bytes(96) + pts1[5], ks[5] + ks[5], 2)
+    assert bool(inf[0]) and not bool(inf[1]) and out[0].tobytes() == bytes(96) and out[1].tobytes() == RC.g1_mul(pts1[5], ks[5])
+    out, inf = eng.g2_mul_batch(bytes(192) + pts2[5], ks[5] + ks[5], 2)
+    assert bool(inf[0]) and not bool(inf[1]) and out[0].tobytes() == bytes(192) and out[1].tobytes() == RC.g2_mul(pts2[5], ks[5])
     for m in (1, 2, 3, 64, 65, 67):
         assert eng.g1_sum(b"".join(pts1[:m]), m) == RC.g1_sum(b"".join(pts1[:m]), m)
         assert eng.g2_sum(b"".join(pts2[:m]), m) == RC.g2_sum(b"".join(pts2[:m]), m)

@@ -174,6 +174,24 @@ def test_msm_final_programs():
             assert out[:2] == [want[0], want[1]] and out[2]
 
 
+def test_scalar_multiplication_programs():
+    """[k] P with a run-time scalar: SEL levels index the table 0 P .. 15 P by the 4-bit digits of k (g1.go:80-90, g2.go MulFR)"""
+    xs = P.XORShift(41)
+    Pa, Qa = _pt(xs)
+    for kind, Fd, pt, six in (("mul1", P.F1, Pa, False), ("mul2", P.F2, Qa, True)):
+        p = G.schedule(G.build_program(kind))
+        inp = [pt[0][0], pt[0][1], pt[1][0], pt[1][1]] if six else [pt[0], pt[1]]
+        for k in (P.rand_fr(xs), 1, 0, P.R_ORDER - 1, (1 << 255) + 12345, P.R_ORDER):
+            out = G.simulate(p, {0: inp, "scalar": k})
+            want = P.jac_to_affine(Fd, P.affine_mul(Fd, pt, k)) if k % P.R_ORDER else None
+            if want is None:
+                assert out[-1] == 0                                             # the point at infinity: Z = 0
+            elif six:
+                assert out[:4] == [want[0][0], want[0][1], want[1][0], want[1][1]] and out[4]
+            else:
+                assert out[:2] == [want[0], want[1]] and out[2]
+
+
 def test_program_bounds_and_shape(progs):
     for name, p in progs.items():
         assert p.nslot < 1024
