@@ -84,7 +84,9 @@ int blsmi_g1_mul_batch(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* 
 int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
 /* k_i * generator (PrivToPub g2pubs/bls.go:138-140 uses G2, g1pubs/bls.go:144-146 uses G1).
  * NOT side-channel hardened: the scalar-multiplication kernels index a per-lane table by scalar nibbles and take
- * data-dependent paths in the group law (the reference's bit-serial Mul is not constant-time either).  They exist to
+ * data-dependent paths in the group law (the reference's bit-serial Mul is not constant-time either); the small-batch
+ * level program has a fixed instruction sequence and complete group formulas but still addresses an LDS table by the
+ * scalar's digits.  They exist to
  * generate and check test/bench inputs and for public scalars; secret keys belong on the upstream pure-Go module
  * (Sign / PrivToPub stay there in the Go shim). */
 int blsmi_g1_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
