@@ -650,7 +650,10 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     hipLaunchKernelGGL(k_msm_class_hist, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, cls.as<u32>());
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(256), 0, s, (const u32*)cls.as<u32>(), cls.as<u32>() + 256, cls.as<u32>() + 512);
     hipLaunchKernelGGL(k_msm_class_scatter, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, (const u32*)(cls.as<u32>() + 256), cls.as<u32>() + 512, perm.as<u32>());
-    hipLaunchKernelGGL(k.bucket, dim3(nblocks(nb)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), n, c, nb);
+    if (W == 6 && g_pair_layout)                                           // G2: a lane pair per bucket, two waves per SIMD
+        hipLaunchKernelGGL(k_g2_msm_bucket_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), n, c, nb);
+    else
+        hipLaunchKernelGGL(k.bucket, dim3(nblocks(nb)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), n, c, nb);
     hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
     i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
     size_t seg = per_win;

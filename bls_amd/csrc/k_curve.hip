@@ -167,6 +167,22 @@ BLSMI_DEV void pair_store_g2(u8* p, int par, const P2::G2AffP& a) {
     if (a.inf) { u32* w = reinterpret_cast<u32*>(p + 48 * par); for (int i = 0; i < 12; i++) { w[i] = 0; w[24 + i] = 0; } return; }
     store_be48(p + 48 * par, a.x.c); store_be48(p + 96 + 48 * par, a.y.c);
 }
+// G2 bucket accumulation of the MSM (msm.inc step 2) with a lane PAIR per bucket: half the point state per lane, two waves per
+// SIMD instead of one.  The record a pair leaves is the one-lane kernel's (jac_soa_store): coordinate c_par by lane par.
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_pair(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb) {
+    const int par = threadIdx.x & 1;
+    const size_t j = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t jj = j < nb ? j : nb - 1;
+    const size_t t = perm[jj];
+    const u32 cnt = j < nb ? hist[t] : 0;
+    const u32* slice = idx + (t >> c) * n + offs[t];
+    P2::G2JacP acc = jac_zero<P2::Fp2S>();
+    for (u32 k = 0; k < cnt; k++) acc = jac_add_affine(acc, pair_load_g2(pts + (size_t)192 * slice[k], par));
+    if (j < nb) {
+        soa_store(buckets, nb, t, 0 + par, acc.x.c); soa_store(buckets, nb, t, 2 + par, acc.y.c); soa_store(buckets, nb, t, 4 + par, acc.z.c);
+        if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
+    }
+}
 __global__ void __launch_bounds__(WG, 2) k_g2_mul_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
     const int par = threadIdx.x & 1;
     const size_t t = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
