@@ -1150,7 +1150,7 @@ def mont_limbs(v):
 
 
 def encode(p):
-    """header: magic, nlevels, nslot, nconst, out kind; per level: kind, ntx, nty, njobs; per (level, lane): 16 x u16
+    """header: magic, nlevels, nslot, nconst, out kind; per level: kind, ntx, nty, njobs (LIN: lanes per job); per (level, lane): 16 x u16
     [dst, 7 x-terms, 7 y-terms, flags]; term = slot | (coef + 16) << 11; constants: slot + 15 limbs."""
     assert p.nslot < 2048
     def term(d, c):
@@ -1163,10 +1163,21 @@ def encode(p):
     for k, jobs in p.levels:
         ntx = nty = 0
         rows = []
+        # A LIN level rarely has more than 16 jobs: its jobs are then spread over 4 (or 2) adjacent lanes each, every lane gathers
+        # a quarter of the terms and the partial sums are added across the lanes (DPP) before the normalisation.
+        split = (4 if len(jobs) <= 16 else 2 if len(jobs) <= 32 else 1) if k == K_LIN else 1
         for n in jobs:
             xs = [term(d, c) for d, c in n.x.items()] if n.x else []
             ys = [term(d, c) for d, c in n.y.items()] if n.y else []
             flags = 0
+            if k == K_LIN and split > 1:
+                assert len(xs) <= TLIN
+                flags = 1 if n.reduce else 0
+                for q in range(split):
+                    part = xs[q::split]
+                    ntx, nty = max(ntx, len(part[:7])), max(nty, len(part[7:]))
+                    rows.append([n.slot if q == 0 else dummy] + part[:7] + [NOTERM] * (7 - len(part[:7])) + part[7:] + [NOTERM] * (7 - len(part[7:])) + [flags])
+                continue
             if k == K_LIN:
                 assert len(xs) <= TLIN
                 xs, ys = xs[:7], xs[7:]
@@ -1184,7 +1195,7 @@ def encode(p):
         for r in rows:
             desc += struct.pack("<16H", *r)
         red = 0x80 if (k == K_LIN and any(n.reduce for n in jobs)) else 0   # value reduction is level-wide (always valid, never needed less)
-        hdr.append((k | red, ntx, nty, len(jobs)))
+        hdr.append((k | red, ntx, nty, split if k == K_LIN else len(jobs)))   # last byte: LIN: lanes per job; otherwise the job count
     out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12, "outaff": K_OUTAFF, "iszero": K_ISZERO}[p.out]
     blob = bytearray()
     assert len(p.out_nodes) <= 12

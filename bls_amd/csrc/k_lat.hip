@@ -5,8 +5,8 @@
 // a WAVE: its field elements live in LDS slots (15 x 27-bit limbs + 1 pad word = 64 bytes, Montgomery R = 2^405, the
 // representation of fp.cuh) and the wave interprets a straight-line program of levels.  In a level every lane does the
 // same thing to its own job: gather two small signed combinations of slots (ds_read_b128), one Montgomery product (the
-// column-scanning core of fp.cuh), store the result slot -- or, in a LIN level, gather one longer combination and
-// normalise it.  The 54 Fq products of an Fq12 multiplication are one level; the doubling step of the NEXT Miller
+// column-scanning core of fp.cuh), store the result slot -- or, in a LIN level, gather one longer combination (spread over up to four
+// lanes when the level has few jobs) and normalise it.  The 54 Fq products of an Fq12 multiplication are one level; the doubling step of the NEXT Miller
 // iteration shares levels with the accumulator update of the current one.  MillerLoop + FinalExponentiation:
 // ~510 product levels + ~820 recombination levels instead of ~14 600 sequential multiplications.
 //
@@ -126,6 +126,16 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             gather(S, ty, nty, ax);
             Fp<LMAX, VMAX> x;
             acc_low(ax, x.v);
+            // njobs of a LIN level = lanes per job (gen_lat.py encode): the job's terms are spread over 2 or 4 adjacent lanes,
+            // whose partial sums meet here (quad_perm [1,0,3,2], then [2,3,0,1]); every lane of the group ends with the total
+            if (njobs >= 2) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) x.v[i] += __builtin_amdgcn_update_dpp(0, x.v[i], 0xB1, 0xf, 0xf, true);
+            }
+            if (njobs == 4) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) x.v[i] += __builtin_amdgcn_update_dpp(0, x.v[i], 0x4E, 0xf, 0xf, true);
+            }
             if (reduce) { const Fp<1, 3> y = fp_reduce(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
             else { const auto y = fp_norm(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
         } else if (kind == K_INV) {
