@@ -30,12 +30,27 @@ struct LatHeader {                      // gen_lat.py: encode()
 // wide so that a term costs ONE v_mad_u64_u32 per limb (a 32-bit multiply-add does not exist on gfx950; v_mul_lo + v_add
 // would be two); only their low words are meaningful and used.
 struct Acc { u64 v[NL]; };
+// INIT: the first term of a gather -- the accumulators are written, not added to (saves clearing 15 register pairs)
+template <bool INIT>
 BLSMI_DEV void gather_term(const i32* S, u32 term, Acc& x) {
     const u32 c = (u32)((i32)(term >> 11) - 16);
     const int4* p = reinterpret_cast<const int4*>(S + (term & 0x7ffu) * SLOT_WORDS);
     const int4 a = p[0], b = p[1], d = p[2], e = p[3];
     const i32 v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w};
     // rotating carry-out pairs: see gen_lat_mul.py
+    if constexpr (INIT) {
+        asm volatile("v_mad_u64_u32 %0, s[36:37], %8, %9, 0\n\tv_mad_u64_u32 %1, s[38:39], %8, %10, 0\n\tv_mad_u64_u32 %2, s[40:41], %8, %11, 0\n\tv_mad_u64_u32 %3, s[42:43], %8, %12, 0\n\t"
+                     "v_mad_u64_u32 %4, s[44:45], %8, %13, 0\n\tv_mad_u64_u32 %5, s[46:47], %8, %14, 0\n\tv_mad_u64_u32 %6, s[48:49], %8, %15, 0\n\tv_mad_u64_u32 %7, s[50:51], %8, %16, 0"
+                     : "=&v"(x.v[0]), "=&v"(x.v[1]), "=&v"(x.v[2]), "=&v"(x.v[3]), "=&v"(x.v[4]), "=&v"(x.v[5]), "=&v"(x.v[6]), "=&v"(x.v[7])
+                     : "v"(c), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])
+                     : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
+        asm volatile("v_mad_u64_u32 %0, s[36:37], %7, %8, 0\n\tv_mad_u64_u32 %1, s[38:39], %7, %9, 0\n\tv_mad_u64_u32 %2, s[40:41], %7, %10, 0\n\tv_mad_u64_u32 %3, s[42:43], %7, %11, 0\n\t"
+                     "v_mad_u64_u32 %4, s[44:45], %7, %12, 0\n\tv_mad_u64_u32 %5, s[46:47], %7, %13, 0\n\tv_mad_u64_u32 %6, s[48:49], %7, %14, 0"
+                     : "=&v"(x.v[8]), "=&v"(x.v[9]), "=&v"(x.v[10]), "=&v"(x.v[11]), "=&v"(x.v[12]), "=&v"(x.v[13]), "=&v"(x.v[14])
+                     : "v"(c), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14])
+                     : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
+        return;
+    }
     asm volatile("v_mad_u64_u32 %0, s[36:37], %8, %9, %0\n\tv_mad_u64_u32 %1, s[38:39], %8, %10, %1\n\tv_mad_u64_u32 %2, s[40:41], %8, %11, %2\n\tv_mad_u64_u32 %3, s[42:43], %8, %12, %3\n\t"
                  "v_mad_u64_u32 %4, s[44:45], %8, %13, %4\n\tv_mad_u64_u32 %5, s[46:47], %8, %14, %5\n\tv_mad_u64_u32 %6, s[48:49], %8, %15, %6\n\tv_mad_u64_u32 %7, s[50:51], %8, %16, %7"
                  : "+v"(x.v[0]), "+v"(x.v[1]), "+v"(x.v[2]), "+v"(x.v[3]), "+v"(x.v[4]), "+v"(x.v[5]), "+v"(x.v[6]), "+v"(x.v[7])
@@ -47,11 +62,21 @@ BLSMI_DEV void gather_term(const i32* S, u32 term, Acc& x) {
                  : "v"(c), "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14])
                  : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49");
 }
+// FIRST: x is written (zero when there is no term), otherwise added to
+template <bool FIRST>
 BLSMI_DEV void gather(const i32* S, const u32* terms, int nt, Acc& x) {
+    if (FIRST) {
+        if (nt == 0) {
 #pragma unroll
-    for (int t = 0; t < 7; t++) {
+            for (int i = 0; i < NL; i++) x.v[i] = 0;
+            return;
+        }
+        gather_term<true>(S, terms[0], x);
+    }
+#pragma unroll
+    for (int t = FIRST ? 1 : 0; t < 7; t++) {
         if (t >= nt) break;                                                // nt is uniform across the wave (level header)
-        gather_term(S, terms[t], x);
+        gather_term<false>(S, terms[t], x);
     }
 }
 BLSMI_DEV void acc_zero(Acc& x) {
@@ -113,17 +138,15 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
         i32 r[NL];
         if (kind == K_MUL) {
             Acc ax, ay;
-            acc_zero(ax); acc_zero(ay);
-            gather(S, tx, ntx, ax);
-            gather(S, ty, nty, ay);
+            gather<true>(S, tx, ntx, ax);
+            gather<true>(S, ty, nty, ay);
             i32 x[NL], y[NL];
             acc_low(ax, x); acc_low(ay, y);
             lat_mul(x, y, r);
         } else if (kind == K_LIN) {
             Acc ax;
-            acc_zero(ax);
-            gather(S, tx, ntx, ax);
-            gather(S, ty, nty, ax);
+            gather<true>(S, tx, ntx, ax);
+            gather<false>(S, ty, nty, ax);
             Fp<LMAX, VMAX> x;
             acc_low(ax, x.v);
             // njobs of a LIN level = lanes per job (gen_lat.py encode): the job's terms are spread over 2 or 4 adjacent lanes,
@@ -140,8 +163,7 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             else { const auto y = fp_norm(x); for (int i = 0; i < NL; i++) r[i] = y.v[i]; }
         } else if (kind == K_INV) {
             Acc ax;
-            acc_zero(ax);
-            gather(S, tx, ntx, ax);
+            gather<true>(S, tx, ntx, ax);
             Fp<LMAX, VMAX> x;
             acc_low(ax, x.v);
             const FpS y = fp_inv(x);                                           // inverse(0) = 0
