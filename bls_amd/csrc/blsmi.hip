@@ -155,7 +155,6 @@ int init_device(Device& d) {            // caller holds g_mu
 // Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
 // (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
 std::atomic<size_t> g_lat_max{4096};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely)
-bool g_lat_hash = true;                 // BLSMI_LAT_HASH=0: small-batch hashes finish in the two-lane kernels instead of a level program
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -173,7 +172,6 @@ int ensure_init_list(const int* devs, int ndev) {
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
     if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
-    if (const char* v = getenv("BLSMI_LAT_HASH")) g_lat_hash = atoi(v) != 0;
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
     for (int i = 0; i < ndev; i++) {
         g_dev[i].id = devs[i]; g_dev[i].index = i;
@@ -542,7 +540,7 @@ static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t*
     HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
     if (pts) { HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream)); }
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    if (n <= g_lat_max && g_lat_hash) {                                    // small call: one multiplication per wave (k_lat.hip, SEL levels)
+    if (n <= g_lat_max) {                                                  // small call: one multiplication per wave (k_lat.hip, SEL levels)
         const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
         const u8* base = pts ? dp.as<u8>() : d_gen;
         const size_t stride = pts ? (size_t)PB : 0;
@@ -666,7 +664,7 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     // Horner over the windows (240 dependent doublings) and ToAffine: one wave as a level program of the latency path
     // (k_lat.hip: msmfin1 / msmfin2, two product levels per doubling) instead of one lane (k.final: 3 / 8 ms)
     static_assert(W == 3 || W == 6, "G1 / G2");
-    if (g_lat_hash && c == 16 && nwin == 16) {
+    if (g_lat_max > 0 && c == 16 && nwin == 16) {                          // (the latency path switched off: the one-lane kernel below)
         const size_t prog = W == 3 ? LAT_MSMFIN1_OFFSET : LAT_MSMFIN2_OFFSET;
         DBuf good; HIPCHK(good.alloc(1, s));
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, (const u8*)nullptr, (size_t)0,

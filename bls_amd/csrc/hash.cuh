@@ -253,24 +253,9 @@ __device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len) {
     const FpS t1 = hp_from_digest(d, 0), t2 = hp_from_digest(d, 1);
     swu_map_g1(out, t1, t2);
 }
-// ---- two lanes per message (small batches): lane `par` of a lane pair maps t_par -- the two SWU evaluations, each one
-// exponentiation long, run side by side instead of one after the other -- the points are exchanged (DPP quad_perm
-// [1,0,3,2]) and both lanes finish the same sum, isogeny and cofactor clearing.  Same output bytes as hash_g1 / hash_g2.
+// ---- lane-pair helpers of the small-batch kernels (k_hash.hip: one lane per SWU map / two search candidates per round) ----
 BLSMI_DEV i32 lane_partner(i32 x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); }
 BLSMI_DEV FpS fp_from_partner(const FpS& a) { FpS r; for (int i = 0; i < NL; i++) r.v[i] = lane_partner(a.v[i]); return r; }
-__device__ __noinline__ void hash_g1_two_lanes(G1Aff& out, const u8* msg, size_t len, int par) {
-    u32 d[8];
-    sha256_msg(d, 1, 0x01, msg, len);
-    const FpS t = hp_from_digest(d, (u32)par);
-    G1Aff mine, other;
-    swu_g1_helper(mine, t);
-    other.x = fp_from_partner(mine.x); other.y = fp_from_partner(mine.y); other.inf = 0;
-    const i32 m = par ? -1 : 0;
-    G1Aff p1, p2;
-    p1.x = fp_select(m, other.x, mine.x); p1.y = fp_select(m, other.y, mine.y); p1.inf = 0;
-    p2.x = fp_select(m, mine.x, other.x); p2.y = fp_select(m, mine.y, other.y); p2.inf = 0;
-    swu_finish_g1(out, p1, p2);
-}
 
 // ---- G2 (g2.go:933-1031, hash.go:282-411) ---------------------------------------------------------------
 // Reference-shaped version (inversion + norm root + root: three exponentiations); serves g(x0) = 0.
@@ -423,20 +408,6 @@ __device__ __noinline__ void hash_g2(G2Aff& out, const u8* msg, size_t len) {
     swu_g2_helper(p2, t2);
     swu_finish_g2(out, p1, p2);
 }
-__device__ __noinline__ void hash_g2_two_lanes(G2Aff& out, const u8* msg, size_t len, int par) {
-    u32 d[8];
-    sha256_msg(d, 1, 0x01, msg, len);
-    const Fp2S t = hp2_from_digest(d, (u32)par);
-    G2Aff mine, other;
-    swu_g2_helper(mine, t);
-    other.x.c0 = fp_from_partner(mine.x.c0); other.x.c1 = fp_from_partner(mine.x.c1);
-    other.y.c0 = fp_from_partner(mine.y.c0); other.y.c1 = fp_from_partner(mine.y.c1); other.inf = 0;
-    const i32 m = par ? -1 : 0;
-    G2Aff p1, p2;
-    p1.x = fp2_select(m, other.x, mine.x); p1.y = fp2_select(m, other.y, mine.y); p1.inf = 0;
-    p2.x = fp2_select(m, mine.x, other.x); p2.y = fp2_select(m, mine.y, other.y); p2.inf = 0;
-    swu_finish_g2(out, p1, p2);
-}
 __device__ __noinline__ void swu_finish_g2(G2Aff& out, G2Aff p1, const G2Aff& p2) {
     G2Aff s;
     const G2Jac sj = jac_add_affine(to_jac(p1), p2);                      // stays Jacobian through iso3 and clearH2
@@ -511,98 +482,6 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
     out = jac_to_affine(res);
 }
 
-}  // namespace blsmi
-
-// ------------------------------------------------------------------------------------------------------------------
-// The curve-arithmetic half of the G2 hash in the LANE-PAIR layout (pair_field.cuh): sum of the two mapped points, the
-// 3-isogeny on Jacobian coordinates, clearH2 -- Fq2 multiplications as one fused pass per lane, half the point state per
-// lane.  Used by the two-lane small-batch hash: after the two SWU maps (one per lane) the pair stops duplicating the
-// finish and shares it.  Same formulas, same point, same bytes as swu_finish_g2.
-// ------------------------------------------------------------------------------------------------------------------
-#include "pair_field.cuh"
-namespace blsmi {
-namespace pairl {
-BLSMI_DEV G2JacP psi_jac(const G2JacP& g) {                                // see psi_jac above
-    G2JacP r;
-    r.x = fp2_store(fp2_mul(BLSMI_FP2_K(C_PSI_CX), fp2_conj(g.x)));
-    r.y = fp2_store(fp2_mul(BLSMI_FP2_K(C_PSI_CY), fp2_conj(g.y)));
-    r.z = fp2_store(fp2_conj(g.z));
-    r.inf = g.inf;
-    return r;
-}
-__device__ __noinline__ void clear_h2_jac(G2AffP& out, const G2JacP& p) {   // hash.go:368-389, as clear_h2_jac above
-    G2JacP work = jac_mul_u64_public(p, BLSMI_X_ABS);
-    work = jac_add(work, p);
-    const G2JacP mpsi = jac_neg(psi_jac(p));
-    work = jac_add(work, mpsi);
-    work = jac_mul_u64_public(work, BLSMI_X_ABS);
-    work = jac_add(work, mpsi);
-    work = jac_add(work, jac_neg(p));
-    work = jac_add(work, psi_jac(psi_jac(jac_double(p))));
-    out = jac_to_affine(work);
-}
-// iso_jac for the 3-isogeny with the coefficient tables read per lane (hash.go:282-303 on a Jacobian point)
-__device__ __noinline__ void iso3_jac(G2JacP& out, const G2JacP& p) {
-    constexpr int D = 3;
-    Fp2S wp[D + 1];
-    wp[1] = fp2_store(fp2_sqr(p.z));
-    for (int i = 2; i <= D; i++) wp[i] = fp2_store(fp2_mul(wp[i - 1], wp[1]));
-    auto hom = [&](const blsmi::Fp2S* c, int d) {
-        Fp2S v = BLSMI_FP2_K(c[d]);
-        for (int i = d - 1; i >= 0; i--) v = fp2_store(fp2_add(fp2_mul(v, p.x), fp2_mul(BLSMI_FP2_K(c[i]), wp[d - i])));
-        return v;
-    };
-    const Fp2S XN = hom(C_XNUM3, 3), XD = hom(C_XDEN3, 2), YN = hom(C_YNUM3, 3), YD = hom(C_YDEN3, 3);
-    const Fp2S xdyd = fp2_store(fp2_mul(XD, YD));
-    const Fp2S yd2 = fp2_store(fp2_sqr(YD)), xd2 = fp2_store(fp2_sqr(XD));
-    out.z = fp2_store(fp2_mul(p.z, xdyd));
-    out.x = fp2_store(fp2_mul(fp2_mul(XN, XD), yd2));
-    out.y = fp2_store(fp2_mul(fp2_mul(fp2_mul(p.y, YN), fp2_mul(xd2, XD)), yd2));
-    out.inf = p.inf | (fp2_is_zero(out.z) ? -1 : 0);
-}
-}  // namespace pairl
-
-// Two lanes per message, cooperative finish.  Lane `par` maps t_par (one-element-per-lane Fq2 arithmetic: the SWU map is
-// Fq-exponentiation bound and the two maps are independent), then the pair holds coefficient `par` of every Fq2 of both
-// points and finishes together.  out_half: this lane's 96 bytes of the affine result (x.c_par || y.c_par).
-__device__ __noinline__ void hash_g2_pair_finish(FpS& ox, FpS& oy, i32& oinf, const u8* msg, size_t len, int par) {
-    u32 d[8];
-    sha256_msg(d, 1, 0x01, msg, len);
-    const Fp2S t = hp2_from_digest(d, (u32)par);
-    G2Aff mine, other;
-    swu_g2_helper(mine, t);
-    other.x.c0 = fp_from_partner(mine.x.c0); other.x.c1 = fp_from_partner(mine.x.c1);
-    other.y.c0 = fp_from_partner(mine.y.c0); other.y.c1 = fp_from_partner(mine.y.c1); other.inf = 0;
-    const i32 m = par ? -1 : 0;
-    G2Aff p1, p2;
-    p1.x = fp2_select(m, other.x, mine.x); p1.y = fp2_select(m, other.y, mine.y); p1.inf = 0;
-    p2.x = fp2_select(m, mine.x, other.x); p2.y = fp2_select(m, mine.y, other.y); p2.inf = 0;
-    pairl::G2AffP a1, a2;
-    a1.x = pairl::wrap(fp_select(m, p1.x.c1, p1.x.c0)); a1.y = pairl::wrap(fp_select(m, p1.y.c1, p1.y.c0)); a1.inf = 0;
-    a2.x = pairl::wrap(fp_select(m, p2.x.c1, p2.x.c0)); a2.y = pairl::wrap(fp_select(m, p2.y.c1, p2.y.c0)); a2.inf = 0;
-    const pairl::G2JacP sj = jac_add_affine(to_jac(a1), a2);
-    pairl::G2JacP ij; pairl::iso3_jac(ij, sj);
-    pairl::G2AffP r; pairl::clear_h2_jac(r, ij);
-    ox = r.x.c; oy = r.y.c; oinf = r.inf;
-    if (__any(sj.inf != 0)) {                                              // p2 = -p1: the reference's affine steps (one element per lane)
-        G2Aff s; swu_finish_g2(s, p1, p2);
-        ox = fp_select(sj.inf, fp_select(m, s.x.c1, s.x.c0), ox); oy = fp_select(sj.inf, fp_select(m, s.y.c1, s.y.c0), oy);
-        oinf = (sj.inf & s.inf) | (~sj.inf & oinf);
-    }
-}
-
-// HashG2WithDomain (g2.go:1041-1085) with two lanes per message: the pair tests the candidates x0 + 2k and x0 + 2k + 1 of
-// the try-and-increment search side by side (the smaller passing counter wins, as in the reference's loop), takes the
-// root once, and runs ScaleByCofactor -- clearH2, three psi images and the 64-step joint ladder -- in the lane-pair layout.
-namespace pairl {
-BLSMI_DEV G2AffP psi_aff(const G2AffP& g) {                               // psi(x, y) = (Cx conj(x), Cy conj(y)), hash.go:341-366
-    G2AffP r;
-    r.x = fp2_store(fp2_mul(BLSMI_FP2_K(C_PSI_CX), fp2_conj(g.x)));
-    r.y = fp2_store(fp2_mul(BLSMI_FP2_K(C_PSI_CY), fp2_conj(g.y)));
-    r.inf = g.inf;
-    return r;
-}
-}  // namespace pairl
 BLSMI_DEV Fp2S fp2_from_partner(const Fp2S& a) { Fp2S r; r.c0 = fp_from_partner(a.c0); r.c1 = fp_from_partner(a.c1); return r; }
 // The search half: both lanes return the x the reference's loop stops at and the y it favours (g2.go:1049-1077).
 __device__ __noinline__ void tai_g2_pair(Fp2S& xo, Fp2S& yo, const u8* msg32, const u8* domain8, int par) {
@@ -646,25 +525,5 @@ __device__ __noinline__ void tai_g2_pair(Fp2S& xo, Fp2S& yo, const u8* msg32, co
     const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() (g2.go:1074-1077)
     y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
     xo = xsel; yo = y;
-}
-__device__ __noinline__ void hash_g2_with_domain_pair(FpS& ox, FpS& oy, i32& oinf, const u8* msg32, const u8* domain8, int par) {
-    Fp2S xsel, y;
-    tai_g2_pair(xsel, y, msg32, domain8, par);
-    const i32 m = par ? -1 : 0;
-    pairl::G2AffP pt;
-    pt.x = pairl::wrap(fp_select(m, xsel.c1, xsel.c0)); pt.y = pairl::wrap(fp_select(m, y.c1, y.c0)); pt.inf = 0;
-    // ScaleByCofactor = [c] clearH2(P) through the psi ladder (see hash_g2_with_domain above), lane-pair arithmetic
-    pairl::G2AffP q[4];
-    pairl::clear_h2_jac(q[0], to_jac(pt));
-    q[1] = pairl::psi_aff(q[0]); q[2] = pairl::psi_aff(q[1]); q[3] = pairl::psi_aff(q[2]);
-    q[1] = aff_neg(q[1]); q[3] = aff_neg(q[3]);
-    pairl::G2JacP res = jac_zero<pairl::Fp2S>();
-    for (int bit = 63; bit >= 0; bit--) {
-        res = jac_double(res);
-        for (int i = 0; i < 4; i++)
-            if ((C_H2_GLS[i] >> bit) & 1) res = jac_add_affine(res, q[i]);
-    }
-    const pairl::G2AffP r = jac_to_affine(res);
-    ox = r.x.c; oy = r.y.c; oinf = r.inf;
 }
 }  // namespace blsmi

@@ -20,38 +20,6 @@ KERNEL k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n) {
     hash_g2(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
     if (t < n) store_g2(out + 192 * t, h);
 }
-// small batches: two lanes per message (hash_g{1,2}_two_lanes)
-KERNEL2 k_hash_g1_two_lanes(const u8* msgs, const u64* off, u8* out, size_t n) {
-    const size_t t = ((size_t)blockIdx.x * WG + threadIdx.x) >> 1;
-    const size_t tt = t < n ? t : n - 1;
-    G1Aff h;
-    hash_g1_two_lanes(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]), threadIdx.x & 1);
-    if (t < n && !(threadIdx.x & 1)) store_g1(out + 96 * t, h);
-}
-KERNEL k_hash_g2_two_lanes(const u8* msgs, const u64* off, u8* out, size_t n) {
-    const size_t t = ((size_t)blockIdx.x * WG + threadIdx.x) >> 1;
-    const size_t tt = t < n ? t : n - 1;
-    const int par = threadIdx.x & 1;
-    FpS x, y; i32 inf;
-    hash_g2_pair_finish(x, y, inf, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]), par);
-    if (t < n) {                                                           // this lane's halves: x.c_par at +48 par, y.c_par at +96 + 48 par
-        u8* o = out + 192 * t;
-        if (inf) { u32* w = reinterpret_cast<u32*>(o + 48 * par); for (int i = 0; i < 12; i++) { w[i] = 0; w[24 + i] = 0; } }
-        else { store_be48(o + 48 * par, x); store_be48(o + 96 + 48 * par, y); }
-    }
-}
-KERNEL k_hash_g2_domain_two_lanes(const u8* msgs32, const u8* domain, u8* out, size_t n) {
-    const size_t t = ((size_t)blockIdx.x * WG + threadIdx.x) >> 1;
-    const size_t tt = t < n ? t : n - 1;
-    const int par = threadIdx.x & 1;
-    FpS x, y; i32 inf;
-    hash_g2_with_domain_pair(x, y, inf, msgs32 + 32 * tt, domain, par);
-    if (t < n) {
-        u8* o = out + 192 * t;
-        if (inf) { u32* w = reinterpret_cast<u32*>(o + 48 * par); for (int i = 0; i < 12; i++) { w[i] = 0; w[24 + i] = 0; } }
-        else { store_be48(o + 48 * par, x); store_be48(o + 96 + 48 * par, y); }
-    }
-}
 KERNEL k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;

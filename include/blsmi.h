@@ -67,8 +67,7 @@ int blsmi_pairing_batch_dev(const void *d_g1_aff, const void *d_g2_aff, void *d_
 int blsmi_set_profiling(int on);
 /* Latency path: pairing / verify batches of at most `max_tuples` tuples run ONE TUPLE PER WAVE (the pairing spread over
  * 64 lanes, field elements staged in LDS) instead of one per lane pair: ~10x lower latency for the one-tuple-per-call
- * Go API (g2pubs/bls.go:159-162), same results.  Default 4096 (environment BLSMI_LAT_MAX); 0 switches it off.
- * BLSMI_LAT_HASH=0 (environment, diagnostic) keeps the hash tails and subgroup tests of small batches in the per-lane kernels. */
+ * Go API (g2pubs/bls.go:159-162), same results.  Default 4096 (environment BLSMI_LAT_MAX); 0 switches it off. */
 int blsmi_set_latency_threshold(size_t max_tuples);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
 /* Miller loop only (pairing.go:16-75 with one pair per tuple), same output format */
