@@ -112,6 +112,17 @@ def Verify(m, pub, sig):
     return VerifyBatch([m], [pub], [sig])[0]
 
 
+def Sign(message, key):
+    """Sign(message, key) (g2pubs/bls.go:132-135): key = the secret scalar as 32 big-endian bytes (SecretKey.Serialize()).  One call is
+    one hash-to-curve plus one windowed multiplication on the latency path; not side-channel hardened (include/blsmi.h)."""
+    return SignBatch([message], [key])[0]
+
+
+def PrivToPub(k):
+    """PrivToPub(k) (g2pubs/bls.go:138-140): k = the secret scalar as 32 big-endian bytes."""
+    return PrivToPubBatch([k])[0]
+
+
 def PrivToPubBatch(secret_scalars):
     """pk_i = sk_i * generator (PrivToPub, g2pubs/bls.go:138-140); scalars are 32-byte big-endian."""
     n = len(secret_scalars)

@@ -199,6 +199,11 @@ def test_sign_on_device_matches_oracle(eng):
     msgs = [b"Hello world! 16 characters %d" % i for i in range(3)]
     assert [s.s.raw for s in g2p.SignBatch(msgs, sks)] == [RC.g2pubs.sign(m, sk) for m, sk in zip(msgs, sks)]
     assert [s.s.raw for s in g1p.SignBatch(msgs, sks)] == [RC.g1pubs.sign(m, sk) for m, sk in zip(msgs, sks)]
+    # the one-tuple forms of the Go API (g2pubs/bls.go:132-140, g1pubs/bls.go:132-146): sign, derive the key, verify
+    for pkg, o in ((g2p, RC.g2pubs), (g1p, RC.g1pubs)):
+        sig = pkg.Sign(msgs[0], sks[0]); pk = pkg.PrivToPub(sks[0])
+        assert sig.s.raw == o.sign(msgs[0], sks[0]) and pk.p.raw == o.priv_to_pub(sks[0])
+        assert pkg.Verify(msgs[0], pk, sig) is True and pkg.Verify(msgs[1], pk, sig) is False
 
 
 def test_scalar_mul_and_sums(eng):
