@@ -27,6 +27,7 @@ __global__ void k_debug_prepare_pair(const u8* g2, i32* table);
 __global__ void k_miller1_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_miller1h_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_final_exp_pair(const i32* fbuf, u64* out, size_t n, int mode);
+__global__ void k_miller1x2_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n, size_t m);
 __global__ void k_miller2_pair(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
 __global__ void k_final_exp_is_one_pair(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
 // k_lat.hip

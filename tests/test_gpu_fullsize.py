@@ -101,6 +101,33 @@ def test_config4_verify_aggregate_1m(eng):
     assert eng.g2pubs_verify_aggregate(dup, all_pks.reshape(-1), agg) is False
 
 
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_verify_aggregate_odd_count_on_the_throughput_kernels(eng, group):
+    """n = 8193 (odd, above the latency threshold): two tuples share a Miller loop in the throughput kernels and the last
+    one runs alone; true aggregate -> 1, one swapped key -> 0, and the same verdicts with n = 8192."""
+    n = 8193
+    nk = 64
+    sk = scalars(nk, 9)
+    msgs = _distinct_msgs(n)
+    if group == "g2pubs":
+        pks, _ = eng.g2_mul_batch(RC.g2_generator() * nk, sk.reshape(-1), nk)
+        h = eng.hash_g1_batch(msgs); mul, summ, va = eng.g1_mul_batch, eng.g1_sum, eng.g2pubs_verify_aggregate
+    else:
+        pks, _ = eng.g1_mul_batch(RC.g1_generator() * nk, sk.reshape(-1), nk)
+        h = eng.hash_g2_batch(msgs); mul, summ, va = eng.g2_mul_batch, eng.g2_sum, eng.g1pubs_verify_aggregate
+    sks = np.tile(sk, (n // nk + 1, 1))[:n]
+    all_pks = np.tile(pks, (n // nk + 1, 1))[:n]
+    sig_pts, inf = mul(h.reshape(-1), sks.reshape(-1), n)
+    assert not inf.any()
+    for m in (n, n - 1):
+        agg = summ(sig_pts[:m].reshape(-1), m)
+        assert va(msgs[:m], all_pks[:m].reshape(-1), agg) is True
+        bad = all_pks[:m].copy(); bad[m - 1] = all_pks[m - 2]                # the last tuple: the one that runs alone when m is odd
+        assert va(msgs[:m], bad.reshape(-1), agg) is False
+        bad = all_pks[:m].copy(); bad[100] = all_pks[101]
+        assert va(msgs[:m], bad.reshape(-1), agg) is False
+
+
 def test_config5_g1pubs_256k(eng):
     n = 262144
     nk = 256
