@@ -327,6 +327,36 @@ def test_hash_tail_programs_and_redo_kernels():
     assert bytes(o[0]) == want3[0] and bytes(o[1]) == b"\xaa" * 192 and bytes(o[2]) == want3[2]
 
 
+# ---- the boundary from plain C: what cgo compiles from the shim, minus Go ------------------------------------------------------
+def test_c_abi_from_a_plain_c_client(tmp_path):
+    """tests/native/abi_client.c (C99, only include/blsmi.h and -lblsmi) verifies tuples one per call -- the Go API's shape,
+    g2pubs/bls.go:159-162 -- and as a batch, and computes one pairing; verdicts and bytes are compared with the oracle."""
+    import shutil
+    import struct
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "abi_client")
+    subprocess.check_call([gcc, "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "abi_client.c"),
+                           "-o", exe, "-L", os.path.join(ROOT, "bls_amd"), "-lblsmi", "-Wl,-rpath," + os.path.join(ROOT, "bls_amd")])
+    msgs, pks, sigs, expect = _g2pubs_tuples(12, 77, 4)
+    blob = struct.pack("<Q", len(msgs))
+    for m, pk, sg in zip(msgs, pks, sigs):
+        blob += struct.pack("<I", len(m)) + m + pk + sg
+    path = tmp_path / "tuples.bin"
+    path.write_bytes(blob)
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")   # one HIP runtime per box: torch's copy
+    out = subprocess.run([exe, str(path)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l.strip()}
+    want = ["1" if e else "0" for e in expect]
+    assert lines["single"] == want and lines["batch"] == want
+    e = RC.pairing_batch(sigs[0], pks[0], 1).reshape(-1)
+    assert [int(x, 16) for x in lines["pairing"]] == [int(v) for v in e]
+
+
 # ---- the two paths against each other, at the largest batch the latency path takes ---------------------------------------
 def test_latency_and_throughput_paths_agree_on_4096_tuples():
     """4 096 distinct (P, Q) pairs and 4 096 g2pubs tuples with a corruption schedule: the latency path (one tuple per wave,
