@@ -103,9 +103,9 @@ def test_config4_verify_aggregate_1m(eng):
 
 @pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
 def test_verify_aggregate_odd_count_on_the_throughput_kernels(eng, group):
-    """n = 8193 (odd, above the latency threshold): two tuples share a Miller loop in the throughput kernels and the last
-    one runs alone; true aggregate -> 1, one swapped key -> 0, and the same verdicts with n = 8192."""
-    n = 8193
+    """n = 8195 .. 8192 (above the latency threshold): two tuples share a Miller loop in the throughput kernels, the last one of
+    an odd count runs alone; true aggregate -> 1, one swapped key (the last tuple, one in the body) -> 0."""
+    n = 8195
     nk = 64
     sk = scalars(nk, 9)
     msgs = _distinct_msgs(n)
@@ -119,7 +119,7 @@ def test_verify_aggregate_odd_count_on_the_throughput_kernels(eng, group):
     all_pks = np.tile(pks, (n // nk + 1, 1))[:n]
     sig_pts, inf = mul(h.reshape(-1), sks.reshape(-1), n)
     assert not inf.any()
-    for m in (n, n - 1):
+    for m in (n, n - 1, n - 2, n - 3):
         agg = summ(sig_pts[:m].reshape(-1), m)
         assert va(msgs[:m], all_pks[:m].reshape(-1), agg) is True
         bad = all_pks[:m].copy(); bad[m - 1] = all_pks[m - 2]                # the last tuple: the one that runs alone when m is odd
