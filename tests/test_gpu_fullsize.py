@@ -69,6 +69,39 @@ def test_config3_msm_1m_points(eng):
         assert msm(pts.reshape(-1), k.reshape(-1), n) == total
 
 
+def test_msm_bucket_method_edge_cases(eng):
+    """the bucket method (n >= 2^17) with inputs that leave windows empty or make the sum vanish: short scalars (the upper 12 of the
+    16 windows hold the point at infinity), and a multiset {P_i, -P_i} with equal scalars (every window's sum is the point at
+    infinity; the result is flagged infinite)."""
+    n = 1 << 17
+    base = 1024
+    bk = scalars(base, 71)
+    for gen, mul, msm, ref_mul, pb in [(RC.g1_generator(), eng.g1_mul_batch, eng.g1_msm, RC.g1_mul, 96),
+                                       (RC.g2_generator(), eng.g2_mul_batch, eng.g2_msm, RC.g2_mul, 192)]:
+        bpts, _ = mul(gen * base, bk.reshape(-1), base)
+        pts = np.tile(bpts, (n // base, 1))
+        rng = np.random.default_rng(5)
+        k = np.zeros((n, 32), dtype=np.uint8)
+        k[:, 24:] = rng.integers(0, 256, size=(n, 8), dtype=np.uint8)            # 64-bit scalars
+        bints = [int.from_bytes(bk[j].tobytes(), "big") for j in range(base)]
+        acc = 0
+        kk = k.reshape(n // base, base, 32)
+        for j in range(base):
+            acc = (acc + bints[j] * to_int_sum(kk[:, j, :])) % R
+        assert msm(pts.reshape(-1), k.reshape(-1), n) == ref_mul(gen, acc.to_bytes(32, "big"))
+        # second half = negated first half, same scalars: the sum is the point at infinity
+        half = n // 2
+        neg = pts[:half].copy().reshape(half, pb // 48, 48)
+        ycols = range(pb // 96, pb // 48)                                        # the y coordinate's field elements
+        for c in ycols:
+            y = np.array([int.from_bytes(neg[i, c].tobytes(), "big") for i in range(base)], dtype=object)
+            for i in range(base):
+                neg[i::base, c] = np.frombuffer(((P.Q - y[i]) % P.Q).to_bytes(48, "big"), dtype=np.uint8)
+        both = np.concatenate([pts[:half], neg.reshape(half, pb)])
+        k2 = scalars(half, 72)
+        assert msm(both.reshape(-1), np.concatenate([k2, k2]).reshape(-1), n) is None
+
+
 def _distinct_msgs(n):
     idx = np.arange(n, dtype=np.uint64)
     return [hashlib.sha256(int(i).to_bytes(8, "little")).digest() for i in idx]
