@@ -39,3 +39,26 @@ assert np.array_equal(a, b)
 for i in rng.integers(0, 600, size=25):
     assert a[i].tobytes() == RC.hash_g2_with_domain(m32[i], dom), i
 print("hash soak ok")
+# scalar multiplication (level program with SEL levels against the windowed kernels), full-range and short scalars
+m = 3000
+k = scal(m); k[::7, :20] = 0; k[::11] = 0
+for name, mul, pts, ref in (("g1", engine.g1_mul_batch, g1[:m], RC.g1_mul), ("g2", engine.g2_mul_batch, g2[:m], RC.g2_mul)):
+    engine.set_latency_threshold(4096); a, ia = mul(pts.reshape(-1), k.reshape(-1), m)
+    engine.set_latency_threshold(0); b, ib = mul(pts.reshape(-1), k.reshape(-1), m)
+    engine.set_latency_threshold(4096)
+    assert np.array_equal(a, b) and np.array_equal(ia, ib), name
+    assert ia[::11].all() and not ia[1::11][:50].any()
+    for i in rng.integers(0, m, size=40):
+        e = ref(pts[i].tobytes(), k[i].tobytes())
+        assert (e is None and ia[i]) or a[i].tobytes() == e, (name, i)
+print("scalar multiplication soak ok")
+# compressed wire format: valid points through both decompression paths (subgroup test as a level program / in the kernel)
+for name, comp, dec, pts, cb in (("g1", engine.g1_compress_batch, engine.g1_decompress_batch, g1[:m], 48), ("g2", engine.g2_compress_batch, engine.g2_decompress_batch, g2[:m], 96)):
+    c = comp(pts.reshape(-1), m)
+    engine.set_latency_threshold(4096); ra = dec(np.asarray(c).reshape(-1), m, True)
+    engine.set_latency_threshold(0); rb = dec(np.asarray(c).reshape(-1), m, True)
+    engine.set_latency_threshold(4096)
+    for x, y in zip(ra, rb):
+        assert np.array_equal(np.asarray(x), np.asarray(y)), name
+    assert np.array_equal(np.asarray(ra[0]).reshape(m, -1), pts.reshape(m, -1)), name
+print("decompression soak ok")
