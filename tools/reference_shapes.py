@@ -91,6 +91,16 @@ def run(engine, batch=65536):
     assert engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sg1)[0]
     S["VerifyWithDomain"] = {"ref": "g1pubs/verify_benchmark_test.go:15-31", "cpu_ms_per_op": round(t_vwd * 1e3, 4),
                              "gpu_ms_single_call": round(_best(lambda: engine.g1pubs_verify_with_domain_batch([m32], dom, pk1, sg1), 5) * 1e3, 3)}
+    # the same shape as one call of 65 536 distinct 32-byte messages (signatures made on the device: sk * HashG2WithDomain(m))
+    m32s = [hashlib.sha256(i.to_bytes(4, "little")).digest() for i in range(nb)]
+    sk_all = b"".join(sk) * (nb // 256)
+    pk_b, _ = engine.g1_mul_generator_batch(sk_all, nb)
+    hd = engine.hash_g2_with_domain_batch(m32s, dom)
+    sg_b, _ = engine.g2_mul_batch(hd.reshape(-1), sk_all, nb)
+    assert sg_b[9].tobytes() == RC.g1pubs.sign_with_domain(m32s[9], sk[9], dom)
+    okb = engine.g1pubs_verify_with_domain_batch(m32s, dom, pk_b.reshape(-1), sg_b.reshape(-1))
+    assert bool(np.all(okb))
+    S["VerifyWithDomain"]["gpu_batch_ops_per_s"] = round(nb / _best(lambda: engine.g1pubs_verify_with_domain_batch(m32s, dom, pk_b.reshape(-1), sg_b.reshape(-1)), 2), 1)
     nsig = 128
     mc = b"Some message".ljust(32, b"\0")
     pk128 = [RC.g1pubs.priv_to_pub(s) for s in sk[:nsig]]
