@@ -533,31 +533,42 @@ BLSMI_API int blsmi_debug_g2_prepare(const uint8_t* g2_aff, int mode, uint64_t* 
 template <int PB, class K>
 static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
     if (n && ((!pts && !gen_group) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
-    LOCK_AND_INIT();
     if (n == 0) return BLSMI_OK;
-    const u8* d_gen = gen_group == 1 ? g_gens.g1 : g_gens.g2;            // the leased device's copy of the generator
-    DBuf dp, ds, dout, dinf;
-    HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
-    if (pts) { HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream)); }
-    HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    if (n <= g_lat_max) {                                                  // small call: one multiplication per wave (k_lat.hip, SEL levels)
-        const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
-        const u8* base = pts ? dp.as<u8>() : d_gen;
-        const size_t stride = pts ? (size_t)PB : 0;
-        DBuf good; HIPCHK(good.alloc(n));
-        hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(prog), g_stream, (const u8*)g_gens.lat + prog, base, stride,
-                           (const u8*)ds.as<u8>(), (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
-                           (const u8*)nullptr, good.as<u8>(), dout.as<u64>(), n);
-        hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(n)), dim3(WG), 0, g_stream, (const u8*)good.as<u8>(), base, stride, PB / 4, dout.as<u8>(), dinf.as<u8>(), n);
-    } else if (PB == 192 && g_pair_layout)                                 // G2: lane-pair kernel, two waves per SIMD
-        hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((n + PT - 1) / PT)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
-    else
-        hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), n);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, dout.p, (size_t)PB * n, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipMemcpyAsync(out_inf, dinf.p, n, hipMemcpyDeviceToHost, g_stream));
-    HIPCHK(hipStreamSynchronize(g_stream));
-    return BLSMI_OK;
+    { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc; }
+    // independent multiplications: large host-buffer batches are split by contiguous block like a verify batch (devices,
+    // logical shards): each block has its own host thread and stream, so one block's copies run beside another's kernel
+    return run_shards(plan_shards(n, 64), [&](int, size_t lo, size_t hi) -> int {
+        const size_t m = hi - lo;
+        const u8* d_gen = gen_group == 1 ? g_gens.g1 : g_gens.g2;        // the leased device's copy of the generator
+        DBuf dp, ds, dout, dinf;
+        HIPCHK(ds.alloc(32 * m)); HIPCHK(dout.alloc((size_t)PB * m)); HIPCHK(dinf.alloc(m));
+        if (pts) { HIPCHK(dp.alloc((size_t)PB * m)); HIPCHK(hipMemcpyAsync(dp.p, pts + (size_t)PB * lo, (size_t)PB * m, hipMemcpyHostToDevice, g_stream)); }
+        HIPCHK(hipMemcpyAsync(ds.p, scalars + 32 * lo, 32 * m, hipMemcpyHostToDevice, g_stream));
+        if (m <= g_lat_max) {                                              // small call: one multiplication per wave (k_lat.hip, SEL levels)
+            const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
+            const u8* base = pts ? dp.as<u8>() : d_gen;
+            const size_t stride = pts ? (size_t)PB : 0;
+            DBuf good; HIPCHK(good.alloc(m));
+            hipLaunchKernelGGL(k_lat, dim3((unsigned)m), dim3(64), lat_lds_bytes(prog), g_stream, (const u8*)g_gens.lat + prog, base, stride,
+                               (const u8*)ds.as<u8>(), (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                               (const u8*)nullptr, good.as<u8>(), dout.as<u64>(), m);
+            hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(m)), dim3(WG), 0, g_stream, (const u8*)good.as<u8>(), base, stride, PB / 4, dout.as<u8>(), dinf.as<u8>(), m);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(out + (size_t)PB * lo, dout.p, (size_t)PB * m, hipMemcpyDeviceToHost, g_stream));
+            HIPCHK(hipMemcpyAsync(out_inf + lo, dinf.p, m, hipMemcpyDeviceToHost, g_stream));
+            HIPCHK(hipStreamSynchronize(g_stream));                        // `good` dies with this scope
+            return BLSMI_OK;
+        }
+        if (PB == 192 && g_pair_layout)                                    // G2: lane-pair kernel, two waves per SIMD
+            hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((m + PT - 1) / PT)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), m);
+        else
+            hipLaunchKernelGGL(kernel, dim3(nblocks(m)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), m);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out + (size_t)PB * lo, dout.p, (size_t)PB * m, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipMemcpyAsync(out_inf + lo, dinf.p, m, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        return BLSMI_OK;
+    });
 }
 BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<96>(k_g1_mul, pts, 0, scalars, out, out_inf, n); }
 BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<192>(k_g2_mul, pts, 0, scalars, out, out_inf, n); }
