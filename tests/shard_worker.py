@@ -63,6 +63,12 @@ def main():
         ck[grp + "_aggregate_small_oracle"] = va(ms[:5], b"".join(pk2[:5]), agg) == o.verify_aggregate(agg, pk2[:5], ms[:5])
         small = (RC.g1_sum if grp == "g2pubs" else RC.g2_sum)(b"".join(o.sign(m, sk) for m, sk in zip(ms[:5], sks[:5])), 5)
         ck[grp + "_aggregate_small_true"] = va(ms[:5], b"".join(pk2[:5]), small) is True and o.verify_aggregate(small, pk2[:5], ms[:5]) is True
+    # --- scalar multiplication batches are split the same way
+    n3 = 300
+    pts = b"".join(rand_g1(xs) for _ in range(8)) * 38
+    ks = [sk_bytes(xs) for _ in range(n3)]
+    o3, i3 = eng.g1_mul_batch(pts[:96 * n3], b"".join(ks), n3)
+    ck["g1_mul_split"] = (not i3.any()) and all(o3[i].tobytes() == RC.g1_mul(pts[96 * i:96 * i + 96], ks[i]) for i in (0, 1, 99, 100, 199, 200, 299))
     out["dup_screen"] = "sort" if os.environ.get("BLSMI_DUP_FORCE_SORT") else "hash table"
     out["ok"] = all(ck.values())
     eng.shutdown()
