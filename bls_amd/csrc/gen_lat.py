@@ -37,7 +37,7 @@ NLIMB, LB = 15, 27
 RMONT = 1 << (NLIMB * LB)
 
 # job / level kinds (shared with k_lat.hip)
-K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF, K_ISZERO, K_SEL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF, K_ISZERO, K_SEL, K_SQR = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 LANES = 64
 TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
 TLIN = 14             # terms of a LIN job (both operand fields)
@@ -202,6 +202,18 @@ class Builder:
                 x = self.lin(x, force_reduce=True); y = self.lin(y, force_reduce=True)
         return Lin({self._node("mul", x=x, y=y, V=2): 1})
 
+    def sqr3(self, x):
+        """3 x^2 as a job of a SQR level: every lane of such a level runs the squaring core (120 + 240 multiply-adds instead of
+        225 + 240, one operand gather); the factor 3 rides on the doubled operand (cross terms against 6x, diagonal against 3x),
+        which bounds the operand to L <= 3.  Only worth using where a whole level consists of squarings (the cyclotomic
+        squaring chains of the final exponentiation)."""
+        if not x:
+            return Lin()
+        x = self.fit(x, TMAX)
+        while x.L() > 3 or 3 * x.V() * x.V() > VPROD_MAX:
+            x = self.lin(x, force_reduce=x.V() > 1600)
+        return Lin({self._node("sqr3", x=x, V=2): 1})
+
     def inv(self, x):
         x = self.lin(x, force_reduce=True) if (len(x) != 1 or x.L() != 1) else x
         return Lin({self._node("inv", x=x, V=2): 1})
@@ -331,21 +343,28 @@ class Tower:
         return self.frob12_k[p % 12]
 
     def cyc_sqr(self, f):
-        """Granger-Scott squaring on the cyclotomic subgroup (same element as fq12.go:180-195 there): for each Fq4 pair
-        (a, b): a^2 and b^2 by two products each, ab by four; every output is ONE linear job of <= 6 terms, L <= 14."""
+        """Granger-Scott squaring on the cyclotomic subgroup (same element as fq12.go:180-195 there), written with SQUARINGS only,
+        so that its product level runs the squaring core (SQR level).  For each Fq4 pair (a, b), with S(x) = 3 x^2:
+            3 (a^2 + xi b^2) = (S(a0) - S(a1) + 2 S(b0) - S(b0+b1),   S(a0+a1) - S(a0) - S(a1) + S(b0+b1) - 2 S(b1))
+            3 (2ab)          = (S(a0+b0) - S(a0) - S(b0) - S(a1+b1) + S(a1) + S(b1),   S(a0+b1) + S(a1+b0) - S(a0) - S(b1) - S(a1) - S(b0))
+        10 squarings of operands with L <= 2 per pair, 30 per squaring; every output is ONE linear job of <= 8 terms, L <= 10."""
+        S = self.b.sqr3
         z0, z4, z3 = f[0]; z2, z1, z5 = f[1]
         def fp4(a, b):
-            a2, b2 = self.sqr2(a), self.sqr2(b)
-            v3 = self.mul2(self.sc2(a, 3), b)                             # 3ab: the factor of the outputs rides on an operand
-            return self.add2(a2, self.nr2(b2)), v3                        # (a^2 + xi b^2, 3ab)
+            sa0, sa1, sb0, sb1 = S(a[0]), S(a[1]), S(b[0]), S(b[1])
+            sa, sb = S(a[0] + a[1]), S(b[0] + b[1])
+            s00, s11, s01, s10 = S(a[0] + b[0]), S(a[1] + b[1]), S(a[0] + b[1]), S(a[1] + b[0])
+            A = (sa0 - sa1 + sb0.scale(2) - sb, sa - sa0 - sa1 + sb - sb1.scale(2))
+            B = (s00 - sa0 - sb0 - s11 + sa1 + sb1, s01 + s10 - sa0 - sb1 - sa1 - sb0)
+            return A, B                                                    # 3 (a^2 + xi b^2), 3 (2ab)
         a0, a1 = fp4(z0, z1); b0, b1 = fp4(z2, z3); c0, c1 = fp4(z4, z5)
         L2 = lambda t: self.lin2(t, False)
-        r00 = L2(self.sub2(self.sc2(a0, 3), self.sc2(z0, 2)))
-        r11 = L2(self.add2(self.sc2(a1, 2), self.sc2(z1, 2)))             # 3 * 2ab + 2 z1
-        r01 = L2(self.sub2(self.sc2(b0, 3), self.sc2(z4, 2)))
-        r12 = L2(self.add2(self.sc2(b1, 2), self.sc2(z5, 2)))
-        r10 = L2(self.add2(self.sc2(self.nr2(c1), 2), self.sc2(z2, 2)))   # 3 xi (2ab) + 2 z2
-        r02 = L2(self.sub2(self.sc2(c0, 3), self.sc2(z3, 2)))
+        r00 = L2(self.sub2(a0, self.sc2(z0, 2)))
+        r11 = L2(self.add2(a1, self.sc2(z1, 2)))                          # 3 * 2ab + 2 z1
+        r01 = L2(self.sub2(b0, self.sc2(z4, 2)))
+        r12 = L2(self.add2(b1, self.sc2(z5, 2)))
+        r10 = L2(self.add2(self.nr2(c1), self.sc2(z2, 2)))                # 3 xi (2ab) + 2 z2
+        r02 = L2(self.sub2(c0, self.sc2(z3, 2)))
         return ((r00, r01, r02), (r10, r11, r12))
 
     def mul12_sparse5(self, f, l0, l1, l2, l4, l5):
@@ -1046,8 +1065,8 @@ def schedule(b):
                 stack.extend(lin.keys())
     nodes = [n for n in b.nodes if n.id in live]
     levels = []                          # [kind, [nodes]]
-    kind_of = {"mul": K_MUL, "lin": K_LIN, "inv": K_INV, "in": K_LOAD, "sel": K_SEL}
-    cap = {K_MUL: LANES, K_LIN: LANES, K_INV: 1, K_LOAD: LANES, K_SEL: LANES}
+    kind_of = {"mul": K_MUL, "lin": K_LIN, "inv": K_INV, "in": K_LOAD, "sel": K_SEL, "sqr3": K_SQR}
+    cap = {K_MUL: LANES, K_LIN: LANES, K_INV: 1, K_LOAD: LANES, K_SEL: LANES, K_SQR: LANES}
     consts = [n for n in nodes if n.kind == "const"]
     for n in consts:
         n.level = -1
@@ -1131,6 +1150,8 @@ def simulate(p, inputs):
                 res.append(ev(n.x) * ev(n.y) % Q)
             elif n.kind == "lin":
                 res.append(ev(n.x))
+            elif n.kind == "sqr3":
+                v = ev(n.x); res.append(3 * v * v % Q)
             elif n.kind == "inv":
                 v = ev(n.x)
                 res.append(pow(v, -1, Q) if v else 0)
@@ -1217,8 +1238,8 @@ def stats(p):
     jobs = Counter()
     for k, j in p.levels:
         jobs[k] += len(j)
-    return "levels=%d (mul %d, lin %d, inv %d, load %d)  jobs: mul %d lin %d  slots=%d consts=%d" % (
-        len(p.levels), c[K_MUL], c[K_LIN], c[K_INV], c[K_LOAD], jobs[K_MUL], jobs[K_LIN], p.nslot, len(p.consts))
+    return "levels=%d (mul %d, sqr %d, lin %d, inv %d, load %d)  jobs: mul %d lin %d  slots=%d consts=%d" % (
+        len(p.levels), c[K_MUL], c[K_SQR], c[K_LIN], c[K_INV], c[K_LOAD], jobs[K_MUL], jobs[K_LIN], p.nslot, len(p.consts))
 
 
 def main():

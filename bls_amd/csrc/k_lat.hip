@@ -17,7 +17,7 @@
 #include "device_io.cuh"
 
 namespace {
-constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8, K_SEL = 9;
+constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8, K_SEL = 9, K_SQR = 10;
 constexpr int SLOT_WORDS = 16;
 
 struct LatHeader {                      // gen_lat.py: encode()
@@ -143,6 +143,12 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             i32 x[NL], y[NL];
             acc_low(ax, x); acc_low(ay, y);
             lat_mul(x, y, r);
+        } else if (kind == K_SQR) {                                            // 3 x^2: the cyclotomic squarings (gen_lat.py cyc_sqr)
+            Acc ax;
+            gather<true>(S, tx, ntx, ax);
+            i32 x[NL];
+            acc_low(ax, x);
+            lat_sqr3(x, r);
         } else if (kind == K_LIN) {
             Acc ax;
             gather<true>(S, tx, ntx, ax);
