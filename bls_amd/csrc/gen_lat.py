@@ -9,7 +9,9 @@ the same code on its own job:
 
     MUL   S[dst] = montmul( sum_i cx_i S[sx_i] , sum_j cy_j S[sy_j] )        one Fq Montgomery product per lane
     LIN   S[dst] = normalise( sum_i c_i S[s_i] )  (value-reduced when asked)   recombination of products
+    SQR   S[dst] = 3 ( sum_i c_i S[s_i] )^2                                  the squaring core: levels that hold squarings only
     INV   S[dst] = 1 / S[s]                                                    (one lane; safegcd)
+    SEL   S[dst] = S[base + digit_w(scalar) * stride]                          table entry picked by a 4-bit digit of the tuple's scalar
     LOAD  S[dst] = input record element           OUT / CHECK: results leave LDS
 
 S = LDS slots of one Fq each (15 signed 27-bit limbs, Montgomery R = 2^405, the representation of fp.cuh).  This script
