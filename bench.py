@@ -201,7 +201,7 @@ def aggregate_bench(engine, dev, rank, world, dist, use_dist, n_total=1 << 20, r
         best = min(best, float(t.item()))
     assert ok is True, "the synthetic aggregate must verify"
     return {"signatures": n * world, "signatures_per_gpu": n, "ms": round(best * 1e3, 2), "signatures_per_s": round(n * world / best, 1),
-            "exchange": ("all-gather of 32-byte digests (global duplicate rejection) + all-gather of %d x 576-byte Fq12 partial products over RCCL" % world) if use_dist else "none (one GPU)",
+            "exchange": ("all-gather of 8-byte message fingerprints (global duplicate rejection: each rank screens 1/world of them, full keys only on suspicion) + all-gather of %d x 576-byte Fq12 partial products over RCCL" % world) if use_dist else "none (one GPU)",
             "note": "host buffers: PCIe included; min over %d repetitions; verdict True (false-verdict cases: tests/test_gpu_fullsize.py)" % reps}
 
 

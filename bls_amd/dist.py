@@ -78,19 +78,38 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         status |= 1
     if not any(bytes(sig)):
         status |= 4                                            # signature at infinity
-    keys = message_keys(shard_msgs)
-    gathered = all_gather_bytes(keys + bytes([status]))
-    any_status = 0
-    allk = []
-    for g in gathered:
-        any_status |= g[-1]
-        allk.append(np.frombuffer(g[:-1], dtype=np.uint8).reshape(-1, 33))
-    if any_status:                                             # empty message, bad shard, infinity: reject on every rank
-        return False
-    allk = np.concatenate(allk) if allk else np.zeros((0, 33), np.uint8)
-    if has_duplicate_rows(allk):
-        return False                                           # some message occurs twice (g2pubs/bls.go:245-261)
-    part, bad = engine.aggregate_partial(group, shard_msgs, pk_raw)
+    # The shard's Miller-loop product does not depend on the screening: it runs on the GPU (its own host thread; the C call
+    # releases the interpreter lock) while this thread exchanges the keys and looks for duplicates.
+    import concurrent.futures
+    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+    fut = pool.submit(engine.aggregate_partial, group, shard_msgs, pk_raw) if status == 0 else None
+    try:
+        # Duplicate rejection (g2pubs/bls.go:245-261) across ranks.  Equal messages have equal 33-byte keys, hence equal 64-bit
+        # fingerprints: the ranks exchange the FINGERPRINTS (8 bytes per message), rank r looks for a repeated value among those
+        # with fingerprint = r mod world -- 1/world of the sorting each -- and only when some rank finds one are the full keys
+        # exchanged and compared exactly (a true duplicate, or a 2^-64 accident).
+        keys = np.frombuffer(message_keys(shard_msgs), dtype=np.uint8).reshape(-1, 33)
+        fp = row_fingerprints(keys) if keys.shape[0] else np.zeros(0, np.uint64)
+        gathered = all_gather_bytes(fp.tobytes() + bytes([status]))
+        any_status = 0
+        for g in gathered:
+            any_status |= g[-1]
+        if any_status:                                         # empty message, bad shard, infinity: reject on every rank
+            return False
+        allfp = np.concatenate([np.frombuffer(g[:-1], dtype=np.uint64) for g in gathered]) if gathered else np.zeros(0, np.uint64)
+        mine = np.sort(allfp[allfp % np.uint64(world) == np.uint64(rank)])
+        suspect = bool(mine.size > 1 and (mine[1:] == mine[:-1]).any())
+        flags = all_gather_bytes(bytes([1 if suspect else 0]))
+        if any(f[0] for f in flags):
+            gk = all_gather_bytes(keys.tobytes())
+            allk = np.concatenate([np.frombuffer(g, dtype=np.uint8).reshape(-1, 33) for g in gk])
+            if has_duplicate_rows(allk):
+                return False                                   # some message occurs twice
+        part, bad = fut.result()
+    finally:
+        if fut is not None:
+            concurrent.futures.wait([fut])                     # never leave the shard's call running behind a return
+        pool.shutdown(wait=True)
     parts = all_gather_bytes(part.tobytes() + bytes([1 if bad else 0]))
     if any(p[-1] for p in parts):                              # a key at infinity on some rank
         return False
@@ -103,19 +122,26 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     return bool(np.array_equal(fe[0], fe[1]))
 
 
+def row_fingerprints(keys):
+    """64-bit fingerprint of every row of an (n, 33) uint8 key array: equal rows share it"""
+    n = keys.shape[0]
+    w = np.ascontiguousarray(keys[:, 1:33]).view(np.uint64).reshape(n, 4)
+    return w[:, 0] ^ w[:, 1] ^ w[:, 2] ^ w[:, 3] ^ keys[:, 0].astype(np.uint64)
+
+
 def has_duplicate_rows(keys):
     """exact duplicate test over the rows of an (n, 33) uint8 array: a 64-bit fingerprint (xor of the four 8-byte words)
     is sorted first -- equal rows share it -- and only rows whose fingerprints collide are compared in full."""
     n = keys.shape[0]
     if n < 2:
         return False
-    w = np.ascontiguousarray(keys[:, 1:33]).view(np.uint64).reshape(n, 4)
-    fp = w[:, 0] ^ w[:, 1] ^ w[:, 2] ^ w[:, 3] ^ keys[:, 0].astype(np.uint64)
+    fp = row_fingerprints(keys)
+    fs = np.sort(fp)                                            # the common case -- no two rows share a fingerprint -- needs no permutation
+    if not (fs[1:] == fs[:-1]).any():
+        return False
     order = np.argsort(fp, kind="stable")
     fps = fp[order]
     hit = fps[1:] == fps[:-1]
-    if not hit.any():
-        return False
     idx = np.nonzero(np.concatenate([[False], hit]) | np.concatenate([hit, [False]]))[0]     # every member of a collision group
     rows = keys[order[idx]]
     rows = rows[np.lexsort(rows.T[::-1])]

@@ -137,6 +137,16 @@ def _agg_worker(rank, world, port, q):
         infk = [bytes(192)] + pks[1:]                              # key 0 is the point at infinity (rank 0's shard only)
         ok_inf = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(infk[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
         ok_infsig = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(pks[lo:hi]), bytes(96), rank, world, gather, engine=_OracleEngine)
+        # two DISTINCT 32-byte messages with equal fingerprints (two 8-byte words swapped), one per shard: the fingerprint pass
+        # raises a suspicion, the exact comparison clears it, the aggregate verifies
+        a, b2 = bytes(range(8)), bytes(range(8, 16))
+        cm = [a + b2 + bytes(16), b2 + a + bytes(16)] + [bytes([7 + i]) * 32 for i in range(n - 2)]
+        cm = [cm[0]] + cm[2:] + [cm[1]]                            # the colliding pair sits in different shards
+        agg_c = RC.g1_sum(b"".join(RC.g2pubs.sign(m, sk) for m, sk in zip(cm, sks)), n)
+        ok_coll = bdist.sharded_verify_aggregate("g2pubs", cm[lo:hi], b"".join(pks[lo:hi]), agg_c, rank, world, gather, engine=_OracleEngine)
+        k = np.frombuffer(bdist.message_keys(cm), dtype=np.uint8).reshape(-1, 33)
+        fpc = bdist.row_fingerprints(k)
+        assert fpc[0] == fpc[n - 1] and ok_coll is True and RC.g2pubs.verify_aggregate(agg_c, pks, cm) is True
         q.put((rank, ok, ok_dup, ok_bad or ok_len or ok_inf or ok_infsig, RC.g2pubs.verify_aggregate(agg, pks, msgs)))
     finally:
         dist.destroy_process_group()

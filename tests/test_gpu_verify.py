@@ -393,13 +393,15 @@ def test_sharded_verify_aggregate_single_process(eng):
                 import hashlib
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
-                    dig = bdist.message_keys(msgs[lo:hi]) + b"\x00"
+                    keys = np.frombuffer(bdist.message_keys(msgs[lo:hi]), dtype=np.uint8).reshape(-1, 33)
+                    dig = bdist.row_fingerprints(keys).tobytes() + b"\x00"          # fingerprints + status byte
                     part = eng.aggregate_partial(group, msgs[lo:hi], b"".join(pk_list[lo:hi]))[0].tobytes() + b"\x00"
                     contrib.append((dig, part))
                 outs = []
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
-                    seq = iter([[c[0] for c in contrib], [c[1] for c in contrib]])
+                    # the three exchanges of a duplicate-free aggregate: fingerprints, suspicion flags, partial products
+                    seq = iter([[c[0] for c in contrib], [b"\x00"] * world, [c[1] for c in contrib]])
                     outs.append(bdist.sharded_verify_aggregate(group, msgs[lo:hi], b"".join(pk_list[lo:hi]), agg, r, world, lambda b: next(seq)))
                 assert len(set(outs)) == 1
                 return outs[0]
