@@ -53,18 +53,19 @@ def unpack_bitmap(bitmap, n):
 
 def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all_gather_bytes, engine=None):
     """One n-way VerifyAggregate (g2pubs/bls.go:240-270) whose (message, public key) pairs are block-sharded
-    over `world` ranks.  Per rank: duplicate screening on SHA-256 digests of its messages, the shard's
-    Miller-loop product on its GPU; then TWO small all-gathers -- 32-byte message digests (global duplicate
-    rejection) and the 576-byte Fq12 partials -- after which every rank multiplies the partials, runs the
-    signature-side Miller loop and one final exponentiation, and compares.  Returns the same boolean on
-    every rank.  `all_gather_bytes(b: bytes) -> list[bytes]` is the collective (RCCL via torch.distributed
-    in production, gloo in the CPU test); `engine` defaults to bls_amd.engine.
+    over `world` ranks.  Per rank: the shard's Miller-loop product on its GPU (started first, on its own host thread), and
+    beside it the duplicate screening -- an all-gather of 8-byte message fingerprints, of which rank r sorts the share with
+    value = r mod world; full 33-byte keys are exchanged and compared exactly only when some rank found a repeat.  Then one
+    all-gather of the 576-byte Fq12 partials, after which every rank multiplies the partials, runs the signature-side
+    Miller loop and one final exponentiation, and compares.  Returns the same boolean on every rank.
+    `all_gather_bytes(b: bytes) -> list[bytes]` is the collective (RCCL via torch.distributed in production, gloo in the
+    CPU test); `engine` defaults to bls_amd.engine.
 
     Screens, agreed on by all ranks before any of them can return (a one-byte status rides on the first
     all-gather): a shard whose key and message counts differ (g2pubs/bls.go:241-243), an empty message, a key or
     the signature at infinity (all-zero record; the reference panics in MillerLoop there) -> False everywhere.
-    Duplicate rejection compares 33-byte keys across ranks (message_keys): messages of up to 32 bytes verbatim, longer
-    ones by SHA-256 digest -- equal messages always collide, distinct ones only with a SHA-256 collision."""
+    Duplicate rejection is exact (message_keys: messages of up to 32 bytes verbatim, longer ones by SHA-256 digest --
+    equal messages always collide, distinct ones only with a SHA-256 collision)."""
     if engine is None:
         from . import engine as _e
         engine = _e
