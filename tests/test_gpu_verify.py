@@ -301,6 +301,46 @@ def test_concurrent_callers(eng):
     assert all(results.get(i) is True for i in range(len(threads))), results
 
 
+def test_concurrent_with_domain_callers_two_domains(eng):
+    """Concurrent small g1pubs VerifyWithDomain calls are combined per DOMAIN (g1pubs/bls.go:171-174): sixteen threads, two
+    domains, valid and corrupted tuples interleaved; every caller gets its own verdicts."""
+    import threading
+    xs = P.XORShift(77)
+    doms = [bytes([1, 0, 0, 0, 0, 0, 0, 0]), bytes([2, 9, 0, 0, 0, 0, 0, 7])]
+    jobs = []
+    for i in range(16):
+        dom = doms[i % 2]
+        sk = sk_bytes(xs)
+        m32 = bytes([i]) * 32
+        pk = RC.g1pubs.priv_to_pub(sk)
+        sig = RC.g1pubs.sign_with_domain(m32, sk, dom)
+        if i % 5 == 4:
+            m_use, want = bytes([i + 1]) * 32, False                      # wrong message
+        elif i % 7 == 6:
+            m_use, want = m32, None                                        # verified under the OTHER domain below -> False
+        else:
+            m_use, want = m32, True
+        jobs.append((m_use, dom if want is not None else doms[(i + 1) % 2], pk, sig, bool(want)))
+    results = {}
+
+    def run(idx):
+        try:
+            m, dom, pk, sig, want = jobs[idx]
+            for _ in range(4):
+                got = eng.g1pubs_verify_with_domain_batch([m], dom, pk, sig)
+                assert bool(got[0]) is want, (idx, got)
+            results[idx] = True
+        except Exception as e:  # noqa: BLE001
+            results[idx] = e
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(results.get(i) is True for i in range(len(jobs))), results
+    assert RC.g1pubs.verify_with_domain(jobs[0][0], jobs[0][2], jobs[0][3], jobs[0][1]) is True
+
+
 def test_wire_format(eng, kats):
     xs = P.XORShift(9)
     n = 10
