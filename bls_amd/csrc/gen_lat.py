@@ -833,6 +833,10 @@ BUF_SOA3 = 10      # LOAD: coordinate e of Jacobian record w of a structure-of-a
                    # stride argument): element = e | w << 3 | (1 << 8 for 6-coordinate records); a record flagged infinite reads as (0, 1, 0)
 
 
+BUF_SOA12 = 11     # LOAD: Fq element e of Fq12 record (tuple index + which * arg2) of a structure-of-arrays buffer of `stride` records (buffer 3,
+                   # stride = its stride argument, arg2 = buffer 2's stride argument): element = e | which << 4; a record past the end reads as 1
+
+
 def soa_el(e, w, six):
     return e | (w << 3) | ((1 << 8) if six else 0)
 
@@ -876,6 +880,13 @@ def build_program(kind):
         # the reference's Miller value itself (MillerLoop is an exported function, pairing.go:16): reference steps, wire format
         P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         b.out = ("out12", flat12(pr.T.lin12(pr.miller([(P, Qa)], exact=True), True)))
+        return b
+    if kind == "mul12raw":
+        # one node of the Fq12 product tree of VerifyAggregate: record t times record t + half of an SoA buffer (a missing partner
+        # reads as 1), both in the device representation, result in the device representation
+        a = unflat12([b.inp(BUF_SOA12, e) for e in range(12)])
+        c = unflat12([b.inp(BUF_SOA12, e | 16) for e in range(12)])
+        b.out = ("outraw12", flat12(pr.T.lin12(pr.T.mul12(pr.T.lin12(a, True), pr.T.lin12(c, True)), True)))
         return b
     if kind == "finalexp1":
         f = unflat12([b.inp(BUF_M384_0, e) for e in range(12)])
@@ -1250,7 +1261,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

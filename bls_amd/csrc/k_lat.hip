@@ -195,6 +195,14 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
                     const i32* raw = reinterpret_cast<const i32*>(b3 + s3 * t) + el * NL;
 #pragma unroll
                     for (int i = 0; i < NL; i++) y.v[i] = raw[i];
+                } else if (bsel == 11) {                                           // Fq12 product tree: element e of SoA record t + which * s2 of buffer 3 (s3 records); past the end: 1
+                    const u32 e = el & 15u, which = (el >> 4) & 1u;
+                    const size_t idx = t + (which ? s2 : 0), cnt = s3;
+                    if (idx < cnt) {
+                        const i32* raw = reinterpret_cast<const i32*>(b3);
+#pragma unroll
+                        for (int i = 0; i < NL; i++) y.v[i] = raw[((size_t)e * NL + i) * cnt + idx];
+                    } else if (e == 0) y = C_ONE;
                 } else if (bsel == 10) {                                           // coordinate of a Jacobian SoA record (msm.inc, curve.cuh jac_soa_store) at buffer 3
                     const u32 e = el & 7u, w = (el >> 3) & 31u, ncoord = (el >> 8) & 1u ? 6u : 3u;
                     const i32* raw = reinterpret_cast<const i32*>(b3);

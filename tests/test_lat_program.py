@@ -209,3 +209,15 @@ def test_program_bounds_and_shape(progs):
                         assert all(d.level < n.level for d in lin)                  # operands come from earlier levels
         blob = G.encode(p)
         assert len(blob) % 16 == 0
+
+
+def test_product_tree_node_program():
+    """mul12raw: two Fq12 values -> their product (fq12.go:198-213); a missing partner reads as 1"""
+    p = G.schedule(G.build_program("mul12raw"))
+    xs = P.XORShift(51)
+    a = [P.rand_int(xs, P.Q) for _ in range(12)]; c = [P.rand_int(xs, P.Q) for _ in range(12)]
+    inp = {e: a[e] for e in range(12)}; inp.update({e | 16: c[e] for e in range(12)})
+    assert G.simulate(p, {G.BUF_SOA12: inp}) == P.fq12_flat(P.fq12_mul(G.unflat12(a), G.unflat12(c)))
+    one = [1] + [0] * 11
+    inp.update({e | 16: one[e] for e in range(12)})
+    assert G.simulate(p, {G.BUF_SOA12: inp}) == a
