@@ -710,8 +710,18 @@ static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, cons
     if (rc == BLSMI_E_SKEW) {
         DBuf dm, dinf;
         HIPCHK(dm.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
-        hipLaunchKernelGGL(kmul, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), (size_t)PB, ds.as<u8>(), dm.as<u8>(), dinf.as<u8>(), n);
-        rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+        if (n <= g_lat_max) {                                              // few points: one multiplication per wave (k_lat.hip, mul1 / mul2)
+            const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
+            DBuf good; HIPCHK(good.alloc(n));
+            hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(prog), g_stream, (const u8*)g_gens.lat + prog, (const u8*)dp.as<u8>(), (size_t)PB,
+                               (const u8*)ds.as<u8>(), (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                               (const u8*)nullptr, good.as<u8>(), dm.as<u64>(), n);
+            hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(n)), dim3(WG), 0, g_stream, (const u8*)good.as<u8>(), (const u8*)dp.as<u8>(), (size_t)PB, PB / 4, dm.as<u8>(), dinf.as<u8>(), n);
+            rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);   // synchronises: `good` may go
+        } else {
+            hipLaunchKernelGGL(kmul, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), (size_t)PB, ds.as<u8>(), dm.as<u8>(), dinf.as<u8>(), n);
+            rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+        }
     }
     if (rc) return rc;
     i32 flag = 0;
