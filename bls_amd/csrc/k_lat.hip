@@ -1,18 +1,25 @@
-// k_lat.hip -- the LATENCY path: one pairing / one Verify per 64-lane wave (programs: gen_lat.py).
+// k_lat.hip -- the LATENCY path: one tuple (pairing, Verify, hash tail, scalar multiplication ...) per 64-lane wave
+// (programs: gen_lat.py).
 //
 // The throughput kernels give each tuple one lane pair; a call then costs what one lane pair needs for the whole path
 // (~15 ms) however few tuples it carries, and the Go API is one tuple per call (g2pubs/bls.go:159-162).  Here a tuple owns
 // a WAVE: its field elements live in LDS slots (15 x 27-bit limbs + 1 pad word = 64 bytes, Montgomery R = 2^405, the
 // representation of fp.cuh) and the wave interprets a straight-line program of levels.  In a level every lane does the
-// same thing to its own job: gather two small signed combinations of slots (ds_read_b128), one Montgomery product (the
-// column-scanning core of fp.cuh), store the result slot -- or, in a LIN level, gather one longer combination (spread over up to four
-// lanes when the level has few jobs) and normalise it.  The 54 Fq products of an Fq12 multiplication are one level; the doubling step of the NEXT Miller
-// iteration shares levels with the accumulator update of the current one.  MillerLoop + FinalExponentiation:
-// ~510 product levels + ~820 recombination levels instead of ~14 600 sequential multiplications.
+// same thing to its own job:
+//   MUL  gather two small signed combinations of slots (ds_read_b128), one Montgomery product (the column-scanning core of
+//        fp.cuh as MAD chains with rotating carry-out pairs), store the result slot;
+//   SQR  one gather, three times its square (the squaring core: the cyclotomic squarings of the final exponentiation);
+//   LIN  gather one longer combination -- spread over up to four lanes when the level has few jobs -- and normalise it;
+//   INV / SEL / LOAD  an inversion, a table entry picked by a digit of the tuple's scalar, an input element.
+// The 54 Fq products of an Fq12 multiplication are one level; the doubling step of the NEXT Miller iteration shares levels
+// with the accumulator update of the current one.  MillerLoop + FinalExponentiation: ~510 product / squaring levels +
+// ~810 recombination levels instead of ~14 600 sequential multiplications.
 //
 // Replaces, for small calls: MillerLoop (pairing.go:16-75), FinalExponentiation (pairing.go:79-129), CompareTwoPairings
-// (pairing.go:140-147).  Results leave as the canonical value (verdict byte or the reference's in-memory FQ12), so they
-// are bit-identical to the throughput path's and the reference's.
+// (pairing.go:140-147), the curve arithmetic of hash-to-curve (hash.go:185-389, g2.go:104-138), the subgroup tests
+// (g1.go:137-141, g2.go:293-295), MulFR (g1.go:80-90) and the tails of the MSM and of VerifyAggregate.  Results leave as
+// canonical values (verdict byte, the reference's in-memory FQ12, affine wire bytes), so they are bit-identical to the
+// throughput path's and the reference's.
 #include "tower.cuh"
 #include "device_io.cuh"
 
