@@ -582,6 +582,30 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
     size_t half = (n + 1) / 2;
     DBuf b0, b1;
     HIPCHK(b0.alloc(sizeof(i32) * words * half)); HIPCHK(b1.alloc(sizeof(i32) * words * ((half + 1) / 2)));
+    if (half <= g_lat_max) {
+        // few points: every addition of the tree as a level program, one per wave (k_lat.hip: sum0 / sum1 / sumfin; complete
+        // projective formulas, two product levels per addition) -- ~10 us a level instead of ~70-140
+        const size_t p0 = W == 3 ? LAT_SUM0_1_OFFSET : LAT_SUM0_2_OFFSET, p1 = W == 3 ? LAT_SUM1_1_OFFSET : LAT_SUM1_2_OFFSET, pf = W == 3 ? LAT_SUMFIN_1_OFFSET : LAT_SUMFIN_2_OFFSET;
+        const u8* L = (const u8*)g_gens.lat;
+        hipLaunchKernelGGL(k_lat, dim3((unsigned)half), dim3(64), lat_lds_bytes(p0), s, L + p0, d_pts, (size_t)PB, d_inf, (size_t)0, (const u8*)nullptr, half,
+                           (const u8*)nullptr, n, (const u8*)nullptr, (u8*)nullptr, b0.as<u64>(), half);
+        i32* src = b0.as<i32>(); i32* dst = b1.as<i32>();
+        size_t cur = half;
+        while (cur > 1) {
+            const size_t h = (cur + 1) / 2;
+            hipLaunchKernelGGL(k_lat, dim3((unsigned)h), dim3(64), lat_lds_bytes(p1), s, L + p1, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                               (const u8*)nullptr, h, reinterpret_cast<const u8*>(src), cur, (const u8*)nullptr, (u8*)nullptr, reinterpret_cast<u64*>(dst), h);
+            std::swap(src, dst);
+            cur = h;
+        }
+        DBuf good; HIPCHK(good.alloc(1, s));
+        hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(pf), s, L + pf, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                           (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)1, (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), (size_t)1);
+        hipLaunchKernelGGL(k_good_to_flag, dim3(1), dim3(WG), 0, s, (const u8*)good.as<u8>(), d_out_inf);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return BLSMI_OK;
+    }
     hipLaunchKernelGGL(k0, dim3(nblocks(half)), dim3(WG), 0, s, d_pts, d_inf, b0.as<i32>(), n, half);
     i32* src = b0.as<i32>(); i32* dst = b1.as<i32>();
     size_t cur = half;

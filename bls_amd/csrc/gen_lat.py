@@ -837,6 +837,13 @@ BUF_SOA12 = 11     # LOAD: Fq element e of Fq12 record (tuple index + which * ar
                    # stride = its stride argument, arg2 = buffer 2's stride argument): element = e | which << 4; a record past the end reads as 1
 
 
+BUF_AFFPT = 12     # LOAD: projective coordinate e of the AFFINE wire point (tuple index + which * arg2) of buffer 0 (stride = record bytes); in_inf
+                   # flags = buffer 1 (may be null); points = buffer 3's stride argument.  A flagged point, an all-zero record and a point
+                   # past the end read as (0 : 1 : 0); every other as (x : y : 1).  element = e | which << 4 | (1 << 5 for G2)
+BUF_SOAPT = 13     # LOAD: coordinate e of projective SoA record (tuple index + which * arg2) of buffer 3 (records = its stride argument); a record
+                   # past the end reads as (0 : 1 : 0).  element = e | which << 4 | (1 << 5 for G2)
+
+
 def soa_el(e, w, six):
     return e | (w << 3) | ((1 << 8) if six else 0)
 
@@ -863,6 +870,8 @@ def build_program(kind):
         return build_msm_final_program(b, pr.T, kind)
     if kind in ("mul1", "mul2"):
         return build_mul_program(b, pr.T, kind)
+    if kind in ("sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
+        return build_sum_program(b, pr.T, kind)
     if kind == "aggtail":
         P = (b.inp(0, 0), -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         R = unflat12([b.inp(BUF_RAW3, e) for e in range(12)])
@@ -1014,6 +1023,37 @@ def build_mul_program(b, T, kind):
     x, y = C.to_affine(R)
     outs = F.coords(x) + F.coords(y)
     b.out = ("outaff", outs + [b.lin(F.norm(R[2]), True)], len(outs))
+    return b
+
+
+def build_sum_program(b, T, kind):
+    """the tree sum of affine points (AggregateSignatures / AggregatePublicKeys g2pubs/bls.go:165-192, the tail of small MSMs) for
+    small counts, one addition per wave with the complete projective formulas (the point at infinity needs no flag):
+      'sum0_g' -- level 0: wire points t and t + half (flags / zero records / a missing partner = infinity) -> projective sum
+      'sum1_g' -- inner levels: projective records t and t + half -> their sum
+      'sumfin_g' -- the root: one projective record -> affine wire bytes and its Z (zero for the point at infinity)"""
+    six = kind.endswith("2")
+    F = Fld2(b, T) if six else Fld1(b)
+    C = Curve(F)
+    bit = 32 if six else 0
+    def point(buf, which):
+        def el(e):
+            return b.lin(b.inp(buf, e | (which << 4) | bit), True) if buf == BUF_SOAPT else b.inp(buf, e | (which << 4) | bit)
+        if six:
+            return ((el(0), el(1)), (el(2), el(3)), (el(4), el(5)))
+        return (el(0), el(1), el(2))
+    if kind.startswith("sumfin"):
+        R = point(BUF_SOAPT, 0)
+        x, y = C.to_affine(R)
+        outs = F.coords(x) + F.coords(y)
+        b.out = ("outaff", outs + [b.lin(F.norm(R[2]), True)], len(outs))
+        return b
+    buf = BUF_AFFPT if kind.startswith("sum0") else BUF_SOAPT
+    R = C.add(point(buf, 0), point(buf, 1))
+    outs = []
+    for c in R:
+        outs += [b.lin(v, True) for v in F.coords(c)]
+    b.out = ("outraw12", outs)
     return b
 
 
@@ -1261,7 +1301,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw"):
+    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

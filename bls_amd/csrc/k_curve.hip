@@ -74,6 +74,8 @@ __device__ void mul_batch_body(const u8* pts, size_t pt_stride, const u8* scalar
     const Aff<F> a = jac_to_affine(res);
     if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
 }
+// the verdict byte of a level program (1 = finite result) as the int32 infinity flag of the sum / MSM entry points
+KERNEL k_good_to_flag(const u8* good, i32* flag) { if (blockIdx.x == 0 && threadIdx.x == 0) *flag = good[0] ? 0 : 1; }
 // Small batches run the multiplication as a level program of the latency path (k_lat.hip: mul1 / mul2); this kernel turns its
 // verdict into the out_inf byte and applies the library's convention for a multiplicand given as the all-zero record.
 KERNEL k_mul_finish(const u8* good, const u8* pts, size_t pt_stride, int rec_words, u8* out, u8* out_inf, size_t n) {

@@ -202,6 +202,26 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
                     const i32* raw = reinterpret_cast<const i32*>(b3 + s3 * t) + el * NL;
 #pragma unroll
                     for (int i = 0; i < NL; i++) y.v[i] = raw[i];
+                } else if (bsel == 12 || bsel == 13) {                              // a coordinate of a projective point: 12 = from the affine wire format, 13 = SoA raw
+                    const u32 e = el & 15u, which = (el >> 4) & 1u, six = (el >> 5) & 1u;
+                    const u32 ycoord = six ? 2u : 1u, zcoord = six ? 4u : 2u;
+                    const size_t idx = t + (which ? s2 : 0), cnt = s3;
+                    bool inf = idx >= cnt;
+                    if (bsel == 12) {
+                        const u8* rec = b0 + s0 * (inf ? 0 : idx);
+                        if (!inf) {
+                            const u32* w32 = reinterpret_cast<const u32*>(rec);
+                            u32 any = 0;
+                            for (size_t i = 0; i < s0 / 4; i++) any |= w32[i];
+                            inf = any == 0 || (b1 && b1[idx]);                     // the all-zero record / the caller's flag: the point at infinity
+                        }
+                        if (!inf) { if (e < zcoord) y = load_be48(rec + 48 * e); else if (e == zcoord) y = C_ONE; }
+                    } else if (!inf) {
+                        const i32* raw = reinterpret_cast<const i32*>(b3);
+#pragma unroll
+                        for (int i = 0; i < NL; i++) y.v[i] = raw[((size_t)e * NL + i) * cnt + idx];
+                    }
+                    if (inf && e == ycoord) y = C_ONE;                             // (0 : 1 : 0)
                 } else if (bsel == 11) {                                           // Fq12 product tree: element e of SoA record t + which * s2 of buffer 3 (s3 records); past the end: 1
                     const u32 e = el & 15u, which = (el >> 4) & 1u;
                     const size_t idx = t + (which ? s2 : 0), cnt = s3;
@@ -240,7 +260,7 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
     // results leave LDS
     const int okind = (int)H->out_kind;
     FpS v = fp_zero();
-    const int nres = (okind == K_OUTAFF || okind == K_ISZERO) ? (int)(H->nout + H->nchk) : 12;
+    const int nres = (okind == K_OUTAFF || okind == K_ISZERO) ? (int)(H->nout + H->nchk) : okind == K_OUTRAW12 ? (int)H->nout : 12;
     if (lane < nres) {
         const i32* p = S + (u32)H->out_slot[lane] * SLOT_WORDS;
 #pragma unroll
@@ -261,7 +281,7 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
         if (lane < nout) store_be48(reinterpret_cast<u8*>(out) + 48 * ((size_t)nout * t + lane), v);
         if (lane == 0 && ok) ok[t] = any_bad ? 0 : 1;
     } else if (okind == K_OUTRAW12) {                                          // device representation, SoA over the n tuples (the product tree's input)
-        if (lane < 12) {
+        if (lane < nres) {                                                     // nout elements (12 for an Fq12, 3 / 6 for a projective point)
             i32* fbuf = reinterpret_cast<i32*>(out);
 #pragma unroll
             for (int j = 0; j < NL; j++) fbuf[((size_t)lane * NL + j) * n + t] = v.v[j];

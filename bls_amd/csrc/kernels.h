@@ -59,6 +59,7 @@ __global__ void k_debug_swu_g2(const u64* a, u64* out, size_t n);
 // k_curve.hip
 __global__ void k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n);
+__global__ void k_good_to_flag(const u8* good, i32* flag);
 __global__ void k_mul_finish(const u8* good, const u8* pts, size_t pt_stride, int rec_words, u8* out, u8* out_inf, size_t n);
 __global__ void k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);

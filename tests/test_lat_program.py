@@ -221,3 +221,45 @@ def test_product_tree_node_program():
     one = [1] + [0] * 11
     inp.update({e | 16: one[e] for e in range(12)})
     assert G.simulate(p, {G.BUF_SOA12: inp}) == a
+
+
+def test_sum_tree_programs():
+    """sum0 / sum1 / sumfin: one addition of the tree sum per program run (complete projective formulas; infinity as (0 : 1 : 0))"""
+    xs = P.XORShift(61)
+    Pa, Qa = _pt(xs); Pb, Qb = _pt(xs)
+    for g, Fd, A, B, six in (("1", P.F1, Pa, Pb, False), ("2", P.F2, Qa, Qb, True)):
+        bit = 32 if six else 0
+        def proj(pt):                                                          # affine -> the elements a loader produces
+            if pt is None:
+                return [0, 0, 1, 0, 0, 0] if six else [0, 1, 0]
+            return [pt[0][0], pt[0][1], pt[1][0], pt[1][1], 1, 0] if six else [pt[0], pt[1], 1]
+        def run(kind, buf, X, Y):
+            inp = {}
+            for e, v in enumerate(proj(X)): inp[e | bit] = v
+            for e, v in enumerate(proj(Y)): inp[e | 16 | bit] = v
+            return G.simulate(G.schedule(G.build_program(kind)), {buf: inp})
+        def aff(v):                                                            # projective elements -> affine tuple / None
+            if six:
+                z = (v[4], v[5])
+                if z == (0, 0): return None
+                zi = P.fq2_inv(z)
+                return (P.fq2_mul((v[0], v[1]), zi), P.fq2_mul((v[2], v[3]), zi))
+            if v[2] == 0: return None
+            zi = pow(v[2], -1, P.Q)
+            return (v[0] * zi % P.Q, v[1] * zi % P.Q)
+        want = P.jac_to_affine(Fd, P.jac_add_affine(Fd, P.to_jac(Fd, A), B))
+        s0 = run("sum0_" + g, G.BUF_AFFPT, A, B)
+        assert aff(s0) == want
+        assert aff(run("sum0_" + g, G.BUF_AFFPT, A, None)) == A and aff(run("sum0_" + g, G.BUF_AFFPT, None, None)) is None
+        neg = (A[0], P.fq2_neg(A[1])) if six else (A[0], (-A[1]) % P.Q)
+        assert aff(run("sum0_" + g, G.BUF_AFFPT, A, neg)) is None                   # P + (-P)
+        dbl = P.jac_to_affine(Fd, P.jac_double(Fd, P.to_jac(Fd, A)))
+        assert aff(run("sum0_" + g, G.BUF_AFFPT, A, A)) == dbl                      # P + P
+        # inner level on projective records (use the level-0 output and an infinity partner), then the root
+        inp = {e | bit: v for e, v in enumerate(s0)}
+        inp.update({e | 16 | bit: v for e, v in enumerate(proj(None))})
+        s1 = G.simulate(G.schedule(G.build_program("sum1_" + g)), {G.BUF_SOAPT: inp})
+        assert aff(s1) == want
+        fin = G.simulate(G.schedule(G.build_program("sumfin_" + g)), {G.BUF_SOAPT: {e | bit: v for e, v in enumerate(s1)}})
+        flat = [want[0][0], want[0][1], want[1][0], want[1][1]] if six else [want[0], want[1]]
+        assert fin[:len(flat)] == flat and fin[len(flat)]
