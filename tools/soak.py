@@ -62,3 +62,35 @@ for name, comp, dec, pts, cb in (("g1", engine.g1_compress_batch, engine.g1_deco
         assert np.array_equal(np.asarray(x), np.asarray(y)), name
     assert np.array_equal(np.asarray(ra[0]).reshape(m, -1), pts.reshape(m, -1)), name
 print("decompression soak ok")
+# differential fuzz: random sizes, every batch entry point on both paths (latency programs vs throughput kernels)
+import random
+rnd = random.Random(7)
+def both(fn):
+    engine.set_latency_threshold(4096); a = fn()
+    engine.set_latency_threshold(0); b = fn()
+    engine.set_latency_threshold(4096)
+    return a, b
+def same(a, b):
+    if isinstance(a, tuple):
+        return all(same(x, y) for x, y in zip(a, b))
+    if a is None or b is None or isinstance(a, (bytes, bool)):
+        return a == b
+    return np.array_equal(np.asarray(a), np.asarray(b))
+for it in range(40):
+    nn = rnd.choice([1, 2, 3, 5, 17, 63, 64, 65, 129, 300])
+    i0 = rnd.randrange(0, n - nn)
+    p1, p2 = g1[i0:i0 + nn], g2[i0:i0 + nn]
+    kk = scal(nn)
+    flags = np.array([rnd.random() < 0.1 for _ in range(nn)], dtype=np.uint8)
+    ops = {
+        "g1_sum": lambda: engine.g1_sum(p1.reshape(-1), nn, flags), "g2_sum": lambda: engine.g2_sum(p2.reshape(-1), nn, flags),
+        "g1_msm": lambda: engine.g1_msm(p1.reshape(-1), kk.reshape(-1), nn), "g2_msm": lambda: engine.g2_msm(p2.reshape(-1), kk.reshape(-1), nn),
+        "miller": lambda: engine.miller_loop_batch(p1.reshape(-1), p2.reshape(-1), nn),
+        "pairing": lambda: engine.pairing_batch(p1.reshape(-1), p2.reshape(-1), nn),
+        "fe": lambda: engine.final_exponentiation_batch(engine.miller_loop_batch(p1.reshape(-1), p2.reshape(-1), nn)),
+        "fq12_product": lambda: engine.fq12_product(engine.miller_loop_batch(p1.reshape(-1), p2.reshape(-1), nn)),
+    }
+    name = rnd.choice(list(ops))
+    a, b = both(ops[name])
+    assert same(a, b), (name, nn, it)
+print("differential fuzz ok")
