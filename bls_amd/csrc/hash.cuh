@@ -253,10 +253,6 @@ __device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len) {
     const FpS t1 = hp_from_digest(d, 0), t2 = hp_from_digest(d, 1);
     swu_map_g1(out, t1, t2);
 }
-// ---- lane-pair helpers of the small-batch kernels (k_hash.hip: one lane per SWU map / two search candidates per round) ----
-BLSMI_DEV i32 lane_partner(i32 x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true); }
-BLSMI_DEV FpS fp_from_partner(const FpS& a) { FpS r; for (int i = 0; i < NL; i++) r.v[i] = lane_partner(a.v[i]); return r; }
-
 // ---- G2 (g2.go:933-1031, hash.go:282-411) ---------------------------------------------------------------
 // Reference-shaped version (inversion + norm root + root: three exponentiations); serves g(x0) = 0.
 __device__ __noinline__ void swu_g2_helper_ref(G2Aff& out, const Fp2S& t) {
@@ -482,9 +478,12 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
     out = jac_to_affine(res);
 }
 
-BLSMI_DEV Fp2S fp2_from_partner(const Fp2S& a) { Fp2S r; r.c0 = fp_from_partner(a.c0); r.c1 = fp_from_partner(a.c1); return r; }
-// The search half: both lanes return the x the reference's loop stops at and the y it favours (g2.go:1049-1077).
-__device__ __noinline__ void tai_g2_pair(Fp2S& xo, Fp2S& yo, const u8* msg32, const u8* domain8, int par) {
+// The try-and-increment search of HashG2WithDomain (g2.go:1049-1077) with EIGHT lanes per message: lane g of an aligned group of eight tests the candidate x0 + 8 r + g in round r,
+// the group takes the smallest passing counter of the first round that has one (the x the reference's loop stops at) -- one round
+// almost always (a candidate passes with probability 1/2), where two lanes need 1.33 on average and a wave of 32 messages waits for
+// its unluckiest (~3.5 rounds).  Lane 0 of the group returns the point; the others return copies.
+BLSMI_DEV FpS fp_from_lane(const FpS& a, int src) { FpS r; for (int i = 0; i < NL; i++) r.v[i] = __shfl(a.v[i], src); return r; }
+__device__ __noinline__ void tai_g2_group8(Fp2S& xo, Fp2S& yo, const u8* msg32, const u8* domain8, int g) {
     u32 w[16], dre[8], dim[8];
     for (int tag = 1; tag <= 2; tag++) {                                   // SHA-256 of the 41-byte string m || domain || tag
         for (int i = 0; i < 8; i++) w[i] = ((u32)msg32[4 * i] << 24) | ((u32)msg32[4 * i + 1] << 16) | ((u32)msg32[4 * i + 2] << 8) | msg32[4 * i + 3];
@@ -500,26 +499,29 @@ __device__ __noinline__ void tai_g2_pair(Fp2S& xo, Fp2S& yo, const u8* msg32, co
     for (int j = 0; j < 8; j++) { wre[j] = dre[7 - j]; wim[j] = dim[7 - j]; }
     for (int j = 8; j < 12; j++) { wre[j] = 0; wim[j] = 0; }
     Fp2S xc; xc.c0 = fp_from_words(wre); xc.c1 = fp_from_words(wim);
-    const i32 m = par ? -1 : 0;
-    if (par) xc = fp2_store(fp2_add(xc, fp2_one()));                      // odd lane: x0 + 1
-    Fp2S two = fp2_store(fp2_add(fp2_one(), fp2_one()));
+    Fp2S one = fp2_one(), step = fp2_zero();
+    for (int k = 0; k < 8; k++) {                                          // x0 + g, and the stride 8 of a round
+        if (k < g) xc = fp2_store(fp2_add(xc, one));
+        step = fp2_store(fp2_add(step, one));
+    }
+    const int lane = (int)(threadIdx.x & 63), base = lane & ~7;
     Fp2S xsel = fp2_zero(), gsel = fp2_zero(); FpS ssel = fp_zero();
     i32 done = 0;
     while (true) {
         const Fp2S gx = fp2_store(fp2_add(fp2_mul(fp2_sqr(xc), xc), C_B2));
         bool ok; FpS nrm;
         const FpS s = fp2_norm_root(gx, nrm, ok);
-        const i32 mine_ok = ok ? -1 : 0, other_ok = lane_partner(mine_ok);
-        const i32 even_ok = (m & other_ok) | (~m & mine_ok), odd_ok = (m & mine_ok) | (~m & other_ok);
-        const i32 use_even = even_ok & ~done, use_odd = ~even_ok & odd_ok & ~done;
-        const i32 use_mine = (~m & use_even) | (m & use_odd), use_other = (m & use_even) | (~m & use_odd);
-        const Fp2S ox2 = fp2_from_partner(xc), og = fp2_from_partner(gx); const FpS os = fp_from_partner(s);
-        xsel = fp2_select(use_mine, xc, fp2_select(use_other, ox2, xsel));
-        gsel = fp2_select(use_mine, gx, fp2_select(use_other, og, gsel));
-        ssel = fp_select(use_mine, s, fp_select(use_other, os, ssel));
-        done |= use_even | use_odd;
+        const unsigned long long pass = __ballot(ok ? 1 : 0);
+        const u32 mine = (u32)(pass >> base) & 0xffu;                      // the eight verdicts of this message
+        const int win = base + (mine ? __builtin_ctz(mine) : 0);           // smallest passing counter
+        const i32 take = (mine != 0 && !done) ? -1 : 0;
+        Fp2S xw, gw; xw.c0 = fp_from_lane(xc.c0, win); xw.c1 = fp_from_lane(xc.c1, win);
+        gw.c0 = fp_from_lane(gx.c0, win); gw.c1 = fp_from_lane(gx.c1, win);
+        const FpS sw = fp_from_lane(s, win);
+        xsel = fp2_select(take, xw, xsel); gsel = fp2_select(take, gw, gsel); ssel = fp_select(take, sw, ssel);
+        done |= take;
         if (__all(done != 0)) break;
-        xc = fp2_store(fp2_add(xc, two));
+        xc = fp2_store(fp2_add(xc, step));
     }
     Fp2S y = fp2_sqrt_from_norm_root(gsel, ssel);                          // either root: the choice follows
     const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() (g2.go:1074-1077)

@@ -47,11 +47,12 @@ KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
     swu_g2_helper(p, hp2_from_digest(d, (u32)(idx & 1)));
     if (t < n) store_g2(pts + 192 * idx, p);
 }
-KERNEL k_tai_g2_two_lanes(const u8* msgs32, const u8* domain, u8* pts, size_t n) {
-    const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
+// the try-and-increment search of HashG2WithDomain with eight lanes per message (eight candidates per round)
+KERNEL k_tai_g2_lanes8(const u8* msgs32, const u8* domain, u8* pts, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 3, tt = t < n ? t : n - 1;
     G2Aff p; p.inf = 0;
-    tai_g2_pair(p.x, p.y, msgs32 + 32 * tt, domain, (int)(idx & 1));
-    if (t < n && !(idx & 1)) store_g2(pts + 192 * t, p);
+    tai_g2_group8(p.x, p.y, msgs32 + 32 * tt, domain, (int)(idx & 7));
+    if (t < n && !(idx & 7)) store_g2(pts + 192 * t, p);
 }
 // Messages whose level program met an exceptional step (good[t] == 0: equal / opposite mapped points, an isogeny pole, a
 // result at infinity) are hashed again by the one-lane routines, which follow the reference's steps literally.  A wave
