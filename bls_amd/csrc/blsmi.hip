@@ -4,6 +4,8 @@
 #include "../../include/blsmi.h"
 #include "kernels.h"
 #include "lat_programs.h"
+#include "util_dev.h"
+#include <functional>
 #include <mutex>
 #include <condition_variable>
 #include <chrono>
@@ -42,7 +44,7 @@ std::mutex g_mu;
 std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
-char g_version[200] = "blsmi 0.2 (uninitialised)";
+char g_version[200] = "blsmi 0.3 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
@@ -196,7 +198,7 @@ int ensure_init_list(const int* devs, int ndev) {
     HIPCHK(hipSetDevice(g_dev[0].id));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g_dev[0].id));
-    snprintf(g_version, sizeof g_version, "blsmi 0.2 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_have_comm ? " rccl" : "");
+    snprintf(g_version, sizeof g_version, "blsmi 0.3 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_have_comm ? " rccl" : "");
     g_ready = true;
     return BLSMI_OK;
 }
@@ -529,7 +531,30 @@ BLSMI_API int blsmi_debug_g2_prepare(const uint8_t* g2_aff, int mode, uint64_t* 
 }
 
 // ---- scalar multiplication / sums ----------------------------------------------------------------
-// pts == nullptr: every scalar multiplies the group generator (PrivToPub, g2pubs/bls.go:138-140, g1pubs/bls.go:144-146)
+// d_pts == nullptr: every scalar multiplies the group generator (PrivToPub, g2pubs/bls.go:138-140, g1pubs/bls.go:144-146).
+// Everything on the device of the leased context; enqueues on s, no synchronisation.
+template <int PB, class K>
+static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_scalars, u8* d_out, u8* d_inf, size_t m, hipStream_t s) {
+    const u8* d_gen = gen_group == 1 ? g_gens.g1 : g_gens.g2;            // the leased device's copy of the generator
+    const u8* base = d_pts ? d_pts : d_gen;
+    const size_t stride = d_pts ? (size_t)PB : 0;
+    if (m <= g_lat_max) {                                                  // small call: one multiplication per wave (k_lat.hip, SEL levels)
+        const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
+        DBuf good; HIPCHK(good.alloc(m, s));
+        hipLaunchKernelGGL(k_lat, dim3((unsigned)m), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, base, stride,
+                           d_scalars, (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                           (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), m);
+        hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(m)), dim3(WG), 0, s, (const u8*)good.as<u8>(), base, stride, PB / 4, d_out, d_inf, m);
+        HIPCHK(hipGetLastError());
+        return BLSMI_OK;                                                   // `good` is released in stream order
+    }
+    if (PB == 192 && g_pair_layout)                                        // G2: lane-pair kernel, two waves per SIMD
+        hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((m + PT - 1) / PT)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
+    else
+        hipLaunchKernelGGL(kernel, dim3(nblocks(m)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
+    HIPCHK(hipGetLastError());
+    return BLSMI_OK;
+}
 template <int PB, class K>
 static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
     if (n && ((!pts && !gen_group) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
@@ -539,31 +564,12 @@ static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t*
     // logical shards): each block has its own host thread and stream, so one block's copies run beside another's kernel
     return run_shards(plan_shards(n, 64), [&](int, size_t lo, size_t hi) -> int {
         const size_t m = hi - lo;
-        const u8* d_gen = gen_group == 1 ? g_gens.g1 : g_gens.g2;        // the leased device's copy of the generator
         DBuf dp, ds, dout, dinf;
         HIPCHK(ds.alloc(32 * m)); HIPCHK(dout.alloc((size_t)PB * m)); HIPCHK(dinf.alloc(m));
         if (pts) { HIPCHK(dp.alloc((size_t)PB * m)); HIPCHK(hipMemcpyAsync(dp.p, pts + (size_t)PB * lo, (size_t)PB * m, hipMemcpyHostToDevice, g_stream)); }
         HIPCHK(hipMemcpyAsync(ds.p, scalars + 32 * lo, 32 * m, hipMemcpyHostToDevice, g_stream));
-        if (m <= g_lat_max) {                                              // small call: one multiplication per wave (k_lat.hip, SEL levels)
-            const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
-            const u8* base = pts ? dp.as<u8>() : d_gen;
-            const size_t stride = pts ? (size_t)PB : 0;
-            DBuf good; HIPCHK(good.alloc(m));
-            hipLaunchKernelGGL(k_lat, dim3((unsigned)m), dim3(64), lat_lds_bytes(prog), g_stream, (const u8*)g_gens.lat + prog, base, stride,
-                               (const u8*)ds.as<u8>(), (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
-                               (const u8*)nullptr, good.as<u8>(), dout.as<u64>(), m);
-            hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(m)), dim3(WG), 0, g_stream, (const u8*)good.as<u8>(), base, stride, PB / 4, dout.as<u8>(), dinf.as<u8>(), m);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(out + (size_t)PB * lo, dout.p, (size_t)PB * m, hipMemcpyDeviceToHost, g_stream));
-            HIPCHK(hipMemcpyAsync(out_inf + lo, dinf.p, m, hipMemcpyDeviceToHost, g_stream));
-            HIPCHK(hipStreamSynchronize(g_stream));                        // `good` dies with this scope
-            return BLSMI_OK;
-        }
-        if (PB == 192 && g_pair_layout)                                    // G2: lane-pair kernel, two waves per SIMD
-            hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((m + PT - 1) / PT)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), m);
-        else
-            hipLaunchKernelGGL(kernel, dim3(nblocks(m)), dim3(WG), 0, g_stream, pts ? dp.as<u8>() : d_gen, (size_t)(pts ? PB : 0), ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), m);
-        HIPCHK(hipGetLastError());
+        int rc = mul_dev_core<PB>(kernel, pts ? dp.as<u8>() : nullptr, gen_group, ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), m, g_stream);
+        if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out + (size_t)PB * lo, dout.p, (size_t)PB * m, hipMemcpyDeviceToHost, g_stream));
         HIPCHK(hipMemcpyAsync(out_inf + lo, dinf.p, m, hipMemcpyDeviceToHost, g_stream));
         HIPCHK(hipStreamSynchronize(g_stream));
@@ -574,6 +580,20 @@ BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uin
 BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<192>(k_g2_mul, pts, 0, scalars, out, out_inf, n); }
 BLSMI_API int blsmi_g1_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, nullptr, 1, scalars, out, out_inf, n); }
 BLSMI_API int blsmi_g2_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, 2, scalars, out, out_inf, n); }
+// device-pointer forms: points (NULL = the group generator), scalars, results and infinity bytes resident on one device
+template <int PB, class K>
+static int mul_batch_dev(K kernel, int gen_group, const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream) {
+    if (n == 0) return BLSMI_OK;
+    if (!d_scalars || !d_out || !d_out_inf) return BLSMI_E_ARG;
+    LOCK_AND_INIT_AT(d_out);
+    UseStream us(stream);
+    int rc = mul_dev_core<PB>(kernel, (const u8*)d_pts, gen_group, (const u8*)d_scalars, (u8*)d_out, (u8*)d_out_inf, n, g_stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_g1_mul_batch_dev(const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream) { return mul_batch_dev<96>(k_g1_mul, 1, d_pts, d_scalars, d_out, d_out_inf, n, stream); }
+BLSMI_API int blsmi_g2_mul_batch_dev(const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream) { return mul_batch_dev<192>(k_g2_mul, 2, d_pts, d_scalars, d_out, d_out_inf, n, stream); }
 
 // tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
 template <int PB, int W, class K0, class K1, class K2>
@@ -639,6 +659,22 @@ static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* 
 }
 BLSMI_API int blsmi_g1_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[96], int* out_inf) { return sum_host<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, in_inf, n, out, out_inf); }
 BLSMI_API int blsmi_g2_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[192], int* out_inf) { return sum_host<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, in_inf, n, out, out_inf); }
+template <int PB, int W, class K0, class K1, class K2>
+static int sum_dev_api(K0 k0, K1 k1, K2 kfinal, const void* d_pts, const void* d_in_inf, size_t n, void* d_out, int* out_inf, void* stream) {
+    if (!d_out || !out_inf || (n && !d_pts)) return BLSMI_E_ARG;
+    LOCK_AND_INIT_AT(d_out);
+    UseStream us(stream);
+    if (n == 0) { HIPCHK(hipMemsetAsync(d_out, 0, PB, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); *out_inf = 1; return BLSMI_OK; }
+    DBuf dflag; HIPCHK(dflag.alloc(sizeof(i32)));
+    int rc = sum_dev<PB, W>(k0, k1, kfinal, (const u8*)d_pts, (const u8*)d_in_inf, n, (u8*)d_out, dflag.as<i32>(), g_stream);
+    if (rc) return rc;
+    i32 flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream));
+    *out_inf = flag;
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_g1_sum_dev(const void* d_pts, const void* d_in_inf, size_t n, void* d_out, int* out_inf, void* stream) { return sum_dev_api<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, d_pts, d_in_inf, n, d_out, out_inf, stream); }
+BLSMI_API int blsmi_g2_sum_dev(const void* d_pts, const void* d_in_inf, size_t n, void* d_out, int* out_inf, void* stream) { return sum_dev_api<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, d_pts, d_in_inf, n, d_out, out_inf, stream); }
 
 // multi-scalar multiplication sum_i k_i * P_i.  Small batches: per-point windowed multiples feed the tree sum on the
 // device (one launch of latency, ~6 ms up to 64k points).  From BLSMI_MSM_BUCKET_MIN points (default 2^17, where the
@@ -718,35 +754,30 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     HIPCHK(hipStreamSynchronize(s));                                       // temporaries die with this scope
     return BLSMI_OK;
 }
+// sum_i k_i P_i with everything resident on the leased device: bucket method from bucket_min points on (unless the digits
+// are skewed), per-point multiples + tree sum below.  Result: affine bytes at d_out, infinity flag (i32) at d_flag.  Synchronises s.
+template <int PB, int W, class KM, class K0, class K1, class K2>
+static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s) {
+    static const size_t bucket_min = []{ const char* v = getenv("BLSMI_MSM_BUCKET_MIN"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1 << 17; }();
+    int rc = BLSMI_E_SKEW;
+    if (n >= bucket_min) rc = msm_bucket_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s);
+    if (rc != BLSMI_E_SKEW) return rc;
+    DBuf dm, dinf;
+    HIPCHK(dm.alloc((size_t)PB * n, s)); HIPCHK(dinf.alloc(n, s));
+    rc = mul_dev_core<PB>(kmul, d_pts, 0, d_scalars, dm.as<u8>(), dinf.as<u8>(), n, s);
+    if (rc) return rc;
+    return sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, d_out, d_flag, s);   // synchronises: the temporaries may go
+}
 template <int PB, int W, class KM, class K0, class K1, class K2>
 static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int* out_inf) {
     if (!out || !out_inf || (n && (!pts || !scalars))) return BLSMI_E_ARG;
     if (n == 0) { memset(out, 0, PB); *out_inf = 1; return BLSMI_OK; }
     LOCK_AND_INIT();
-    static const size_t bucket_min = []{ const char* v = getenv("BLSMI_MSM_BUCKET_MIN"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1 << 17; }();
     DBuf dp, ds, dout, dflag;
     HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
     HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    int rc;
-    rc = BLSMI_E_SKEW;
-    if (n >= bucket_min) rc = msm_bucket_dev<PB, W>(mk, dp.as<u8>(), ds.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
-    if (rc == BLSMI_E_SKEW) {
-        DBuf dm, dinf;
-        HIPCHK(dm.alloc((size_t)PB * n)); HIPCHK(dinf.alloc(n));
-        if (n <= g_lat_max) {                                              // few points: one multiplication per wave (k_lat.hip, mul1 / mul2)
-            const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
-            DBuf good; HIPCHK(good.alloc(n));
-            hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(prog), g_stream, (const u8*)g_gens.lat + prog, (const u8*)dp.as<u8>(), (size_t)PB,
-                               (const u8*)ds.as<u8>(), (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
-                               (const u8*)nullptr, good.as<u8>(), dm.as<u64>(), n);
-            hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(n)), dim3(WG), 0, g_stream, (const u8*)good.as<u8>(), (const u8*)dp.as<u8>(), (size_t)PB, PB / 4, dm.as<u8>(), dinf.as<u8>(), n);
-            rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);   // synchronises: `good` may go
-        } else {
-            hipLaunchKernelGGL(kmul, dim3(nblocks(n)), dim3(WG), 0, g_stream, dp.as<u8>(), (size_t)PB, ds.as<u8>(), dm.as<u8>(), dinf.as<u8>(), n);
-            rc = sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
-        }
-    }
+    int rc = msm_dev_core<PB, W>(mk, kmul, k0, k1, kfinal, dp.as<u8>(), ds.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
     if (rc) return rc;
     i32 flag = 0;
     HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream));
@@ -755,13 +786,33 @@ static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, cons
     *out_inf = flag;
     return BLSMI_OK;
 }
+template <int PB, int W, class KM, class K0, class K1, class K2>
+static int msm_dev_api(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream) {
+    if (!d_out || !out_inf || (n && (!d_pts || !d_scalars))) return BLSMI_E_ARG;
+    LOCK_AND_INIT_AT(d_out);
+    UseStream us(stream);
+    if (n == 0) { HIPCHK(hipMemsetAsync(d_out, 0, PB, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); *out_inf = 1; return BLSMI_OK; }
+    DBuf dflag; HIPCHK(dflag.alloc(sizeof(i32)));
+    int rc = msm_dev_core<PB, W>(mk, kmul, k0, k1, kfinal, (const u8*)d_pts, (const u8*)d_scalars, n, (u8*)d_out, dflag.as<i32>(), g_stream);
+    if (rc) return rc;
+    i32 flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream));
+    *out_inf = flag;
+    return BLSMI_OK;
+}
+static const MsmKernels g_mk1{k_g1_msm_bucket, k_g1_msm_chunk, k_g1_msm_fold, k_g1_msm_final};
+static const MsmKernels g_mk2{k_g2_msm_bucket, k_g2_msm_chunk, k_g2_msm_fold, k_g2_msm_final};
 BLSMI_API int blsmi_g1_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[96], int* out_inf) {
-    static const MsmKernels mk{k_g1_msm_bucket, k_g1_msm_chunk, k_g1_msm_fold, k_g1_msm_final};
-    return msm_host<96, 3>(mk, k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, scalars, n, out, out_inf);
+    return msm_host<96, 3>(g_mk1, k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, scalars, n, out, out_inf);
 }
 BLSMI_API int blsmi_g2_msm(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[192], int* out_inf) {
-    static const MsmKernels mk{k_g2_msm_bucket, k_g2_msm_chunk, k_g2_msm_fold, k_g2_msm_final};
-    return msm_host<192, 6>(mk, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, scalars, n, out, out_inf);
+    return msm_host<192, 6>(g_mk2, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, scalars, n, out, out_inf);
+}
+BLSMI_API int blsmi_g1_msm_dev(const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream) {
+    return msm_dev_api<96, 3>(g_mk1, k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, d_pts, d_scalars, n, d_out, out_inf, stream);
+}
+BLSMI_API int blsmi_g2_msm_dev(const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream) {
+    return msm_dev_api<192, 6>(g_mk2, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, d_pts, d_scalars, n, d_out, out_inf, stream);
 }
 
 #include "verify_host.inc"

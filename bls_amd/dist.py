@@ -81,16 +81,19 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         status |= 4                                            # signature at infinity
     # The shard's Miller-loop product does not depend on the screening: it runs on the GPU (its own host thread; the C call
     # releases the interpreter lock) while this thread exchanges the keys and looks for duplicates.
-    import concurrent.futures
-    pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
-    fut = pool.submit(engine.aggregate_partial, group, shard_msgs, pk_raw) if status == 0 else None
+    fut = _executor().submit(engine.aggregate_partial, group, shard_msgs, pk_raw) if status == 0 else None
+    failure = None
+    part, bad = np.zeros(72, dtype=np.uint64), False
     try:
         # Duplicate rejection (g2pubs/bls.go:245-261) across ranks.  Equal messages have equal 33-byte keys, hence equal 64-bit
         # fingerprints: the ranks exchange the FINGERPRINTS (8 bytes per message), rank r looks for a repeated value among those
         # with fingerprint = r mod world -- 1/world of the sorting each -- and only when some rank finds one are the full keys
-        # exchanged and compared exactly (a true duplicate, or a 2^-64 accident).
+        # exchanged and compared exactly (a true duplicate, or a 2^-64 accident).  The fingerprint is KEYED with a nonce the
+        # ranks agreed on (messages are attacker-supplied: an unkeyed one could be driven into collisions at will, which
+        # costs the full-key exchange on every call -- never a wrong verdict).
+        fkey = _fingerprint_key(all_gather_bytes, world)
         keys = np.frombuffer(message_keys(shard_msgs), dtype=np.uint8).reshape(-1, 33)
-        fp = row_fingerprints(keys) if keys.shape[0] else np.zeros(0, np.uint64)
+        fp = row_fingerprints(keys, fkey) if keys.shape[0] else np.zeros(0, np.uint64)
         gathered = all_gather_bytes(fp.tobytes() + bytes([status]))
         any_status = 0
         for g in gathered:
@@ -106,13 +109,20 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
             allk = np.concatenate([np.frombuffer(g, dtype=np.uint8).reshape(-1, 33) for g in gk])
             if has_duplicate_rows(allk):
                 return False                                   # some message occurs twice
-        part, bad = fut.result()
+        try:
+            part, bad = fut.result()
+        except Exception as e:  # noqa: BLE001 -- a HIP error / out of memory on THIS rank: the peers are about to enter the
+            failure = e         # all-gather of the partials and would wait there forever; tell them through it, then raise
     finally:
         if fut is not None:
+            import concurrent.futures
             concurrent.futures.wait([fut])                     # never leave the shard's call running behind a return
-        pool.shutdown(wait=True)
-    parts = all_gather_bytes(part.tobytes() + bytes([1 if bad else 0]))
-    if any(p[-1] for p in parts):                              # a key at infinity on some rank
+    parts = all_gather_bytes(np.asarray(part, dtype=np.uint64).tobytes() + bytes([(1 if bad else 0) | (2 if failure is not None else 0)]))
+    if failure is not None:
+        raise failure
+    if any(p[-1] & 2 for p in parts):
+        raise RuntimeError("sharded_verify_aggregate: the shard of rank(s) %s failed on its device" % [i for i, p in enumerate(parts) if p[-1] & 2])
+    if any(p[-1] & 1 for p in parts):                              # a key at infinity on some rank
         return False
     rhs = engine.fq12_product(np.frombuffer(b"".join(p[:-1] for p in parts), dtype=np.uint64))
     if group == "g2pubs":
@@ -123,11 +133,54 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
     return bool(np.array_equal(fe[0], fe[1]))
 
 
-def row_fingerprints(keys):
-    """64-bit fingerprint of every row of an (n, 33) uint8 key array: equal rows share it"""
+_EXEC = None
+
+
+def _executor():
+    """one worker thread per process for the shard's device call (not one pool per VerifyAggregate)"""
+    global _EXEC
+    if _EXEC is None:
+        import concurrent.futures
+        _EXEC = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="blsmi-shard")
+    return _EXEC
+
+
+_FP_KEYS = {}
+_FP_TEST_MASK = None      # test hook: AND every fingerprint with this mask (forces collisions between distinct messages)
+
+
+def _fingerprint_key(all_gather_bytes, world):
+    """(k0, k1) of the keyed message fingerprint, the same on every rank and unknown to whoever supplies the messages: on the
+    first call every rank contributes 16 random bytes through one all-gather and the XOR of the contributions is kept for
+    the life of the process (every rank makes that first call together: the function is a collective)."""
+    key = _FP_KEYS.get(world)
+    if key is None:
+        import os
+        parts = all_gather_bytes(os.urandom(16))
+        acc = np.zeros(2, dtype=np.uint64)
+        for p in parts:
+            acc ^= np.frombuffer(p[:16], dtype=np.uint64)
+        key = (np.uint64(acc[0]), np.uint64(acc[1]) | np.uint64(1))
+        _FP_KEYS[world] = key
+    return key
+
+
+def row_fingerprints(keys, fkey=(np.uint64(0x9e3779b97f4a7c15), np.uint64(0xff51afd7ed558ccd))):
+    """64-bit fingerprint of every row of an (n, 33) uint8 key array: equal rows share it.  Multiply-xorshift over the
+    length byte and the four 8-byte words, keyed by fkey = (k0, odd k1)."""
     n = keys.shape[0]
     w = np.ascontiguousarray(keys[:, 1:33]).view(np.uint64).reshape(n, 4)
-    return w[:, 0] ^ w[:, 1] ^ w[:, 2] ^ w[:, 3] ^ keys[:, 0].astype(np.uint64)
+    k0, k1 = np.uint64(fkey[0]), np.uint64(fkey[1])
+    with np.errstate(over="ignore"):
+        h = (keys[:, 0].astype(np.uint64) + k0) * k1
+        for j in range(4):
+            h = (h ^ w[:, j]) * k1
+            h ^= h >> np.uint64(29)
+            h *= np.uint64(0xc4ceb9fe1a85ec53)
+            h ^= h >> np.uint64(32)
+    if _FP_TEST_MASK is not None:
+        h = h & np.uint64(_FP_TEST_MASK)
+    return h
 
 
 def has_duplicate_rows(keys):

@@ -125,6 +125,44 @@ def verify_batch_dev(group, d_msgs, d_off, d_pks, d_sigs, d_inf, d_ok, n, stream
     _check(fn(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_pks), C.c_void_p(d_sigs), C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_batch_dev")
 
 
+def mul_batch_dev(group, d_pts, d_scalars, d_out, d_out_inf, n, stream=0):
+    """k_i * P_i with everything resident on the device (ints = device pointers; d_pts = 0: the group generator)."""
+    fn = _lib().blsmi_g1_mul_batch_dev if group == "g1" else _lib().blsmi_g2_mul_batch_dev
+    _check(fn(C.c_void_p(d_pts or 0), C.c_void_p(d_scalars), C.c_void_p(d_out), C.c_void_p(d_out_inf), C.c_size_t(n), C.c_void_p(stream)), "mul_batch_dev")
+
+
+def sum_dev(group, d_pts, d_in_inf, n, d_out, stream=0):
+    """sum of n resident points -> affine bytes at d_out (device); returns True when the sum is the point at infinity."""
+    fn = _lib().blsmi_g1_sum_dev if group == "g1" else _lib().blsmi_g2_sum_dev
+    oinf = C.c_int(0)
+    _check(fn(C.c_void_p(d_pts), C.c_void_p(d_in_inf or 0), C.c_size_t(n), C.c_void_p(d_out), C.byref(oinf), C.c_void_p(stream)), "sum_dev")
+    return bool(oinf.value)
+
+
+def msm_dev(group, d_pts, d_scalars, n, d_out, stream=0):
+    """sum_i k_i P_i over resident points and scalars -> affine bytes at d_out (device); True when it is the point at infinity."""
+    fn = _lib().blsmi_g1_msm_dev if group == "g1" else _lib().blsmi_g2_msm_dev
+    oinf = C.c_int(0)
+    _check(fn(C.c_void_p(d_pts), C.c_void_p(d_scalars), C.c_size_t(n), C.c_void_p(d_out), C.byref(oinf), C.c_void_p(stream)), "msm_dev")
+    return bool(oinf.value)
+
+
+def verify_aggregate_dev(group, d_msgs, d_off, d_pks, sig, n, stream=0):
+    """VerifyAggregate with messages / offsets / keys resident on the device; sig = host bytes of the aggregate signature."""
+    fn, sgb = (_lib().blsmi_g2pubs_verify_aggregate_dev, 96) if group == "g2pubs" else (_lib().blsmi_g1pubs_verify_aggregate_dev, 192)
+    s = _u8(sig, sgb)
+    ok = C.c_int(0)
+    _check(fn(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_pks), _p8(s), C.c_size_t(n), C.byref(ok), C.c_void_p(stream)), "verify_aggregate_dev")
+    return bool(ok.value)
+
+
+def verify_aggregate_with_domain_dev(d_msgs32, d_domain, d_pks, sig, n, stream=0):
+    s = _u8(sig, 192)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g1pubs_verify_aggregate_with_domain_dev(C.c_void_p(d_msgs32), C.c_void_p(d_domain), C.c_void_p(d_pks), _p8(s), C.c_size_t(n), C.byref(ok), C.c_void_p(stream)), "verify_aggregate_with_domain_dev")
+    return bool(ok.value)
+
+
 # ---- groups ----------------------------------------------------------------------------------------
 def _mul(fn, pb, pts, scalars, n):
     p, s = _u8(pts, pb * n), _u8(scalars, 32 * n)

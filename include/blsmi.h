@@ -53,7 +53,9 @@ int blsmi_init_devices(int ndev);
 int blsmi_device_count(void);   /* devices in use (0 before initialisation) */
 int blsmi_shard_count(void);
 void blsmi_shutdown(void);
-/* "gfx950", CU count, and the library version string */
+/* "blsmi <ABI version> gfx950 CUs=.. devices=.. shards=..".  ABI history: 0.2 gave blsmi_g{1,2}pubs_aggregate_partial its trailing
+ * `int *bad` argument (a caller built against the 5-argument prototype of 0.1 must be rebuilt); 0.3 adds the *_dev forms of
+ * mul / sum / msm / verify_aggregate and changes no existing prototype.  Check the prefix before binding by hand. */
 const char *blsmi_version(void);
 
 /* ---- pairing (replaces bls.Pairing, pairing.go:132-136; BASELINE config 2) -------------------
@@ -99,6 +101,17 @@ int blsmi_g2_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t ou
  * from there on the bucket method (16-bit windows), with a fallback to the former for degenerate scalar sets. */
 int blsmi_g1_msm(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[96], int *out_inf);
 int blsmi_g2_msm(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[192], int *out_inf);
+/* Device-pointer forms of the above (BASELINE config 3 with inputs resident in HBM): every d_* buffer lives on ONE of the
+ * library's devices (the call runs on the device that owns d_out), layouts as in the host forms; d_pts == NULL multiplies
+ * the group generator; d_out_inf is n bytes, d_in_inf may be NULL.  The single-point results of sum / msm stay on the
+ * device (96 / 192 bytes at d_out), their infinity flag comes back through the host int.  `stream` as in
+ * blsmi_pairing_batch_dev.  (Added in blsmi 0.3.) */
+int blsmi_g1_mul_batch_dev(const void *d_pts, const void *d_scalars, void *d_out, void *d_out_inf, size_t n, void *stream);
+int blsmi_g2_mul_batch_dev(const void *d_pts, const void *d_scalars, void *d_out, void *d_out_inf, size_t n, void *stream);
+int blsmi_g1_sum_dev(const void *d_pts, const void *d_in_inf, size_t n, void *d_out, int *out_inf, void *stream);
+int blsmi_g2_sum_dev(const void *d_pts, const void *d_in_inf, size_t n, void *d_out, int *out_inf, void *stream);
+int blsmi_g1_msm_dev(const void *d_pts, const void *d_scalars, size_t n, void *d_out, int *out_inf, void *stream);
+int blsmi_g2_msm_dev(const void *d_pts, const void *d_scalars, size_t n, void *d_out, int *out_inf, void *stream);
 
 /* ---- hash to curve (HashG1 hash.go:326-331, HashG2 hash.go:405-411, HashG2WithDomain
  * g2.go:1041-1085) -- messages are concatenated in `msgs`, message i = msgs[off[i] .. off[i+1]) -- */
@@ -139,6 +152,14 @@ int blsmi_fq12_product(const uint64_t *in_fq12 /* n*72 */, size_t n, uint64_t *o
 /* device-pointer forms of the verify batches (inputs resident in HBM; ok is n bytes on the device) */
 int blsmi_g2pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
 int blsmi_g1pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
+
+/* device-pointer forms of VerifyAggregate (g2pubs/bls.go:240-270, g1pubs/bls.go:252-282, :300-311): messages, offsets (or the
+ * 8-byte domain) and keys resident on one of the library's devices, the aggregate signature in HOST memory (one point).  The
+ * duplicate-message rejection runs on the device as well (keyed fingerprints, radix sort, exact comparison inside runs).
+ * The call runs on the device that owns d_pks and is not split over devices.  (Added in blsmi 0.3.) */
+int blsmi_g2pubs_verify_aggregate_dev(const void *d_msgs, const void *d_off, const void *d_pks, const uint8_t sig[96], size_t n, int *ok, void *stream);
+int blsmi_g1pubs_verify_aggregate_dev(const void *d_msgs, const void *d_off, const void *d_pks, const uint8_t sig[192], size_t n, int *ok, void *stream);
+int blsmi_g1pubs_verify_aggregate_with_domain_dev(const void *d_msgs32, const void *d_domain, const void *d_pks, const uint8_t sig[192], size_t n, int *ok, void *stream);
 
 /* ---- Deserialize + Verify in one pass: keys and signatures in the compressed wire format (what
  * PublicKey.Serialize / Signature.Serialize produce, g2pubs/bls.go:18-20, 67-69): g2pubs pk 96 B + sig 48 B,

@@ -137,16 +137,40 @@ def _agg_worker(rank, world, port, q):
         infk = [bytes(192)] + pks[1:]                              # key 0 is the point at infinity (rank 0's shard only)
         ok_inf = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(infk[lo:hi]), agg, rank, world, gather, engine=_OracleEngine)
         ok_infsig = bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(pks[lo:hi]), bytes(96), rank, world, gather, engine=_OracleEngine)
-        # two DISTINCT 32-byte messages with equal fingerprints (two 8-byte words swapped), one per shard: the fingerprint pass
-        # raises a suspicion, the exact comparison clears it, the aggregate verifies
-        a, b2 = bytes(range(8)), bytes(range(8, 16))
-        cm = [a + b2 + bytes(16), b2 + a + bytes(16)] + [bytes([7 + i]) * 32 for i in range(n - 2)]
-        cm = [cm[0]] + cm[2:] + [cm[1]]                            # the colliding pair sits in different shards
+        # DISTINCT messages with equal fingerprints, in different shards: the fingerprint pass raises a suspicion, the exact
+        # comparison clears it, the aggregate verifies.  The fingerprint is keyed (nobody can craft such a pair without the
+        # ranks' nonce), so the collision is forced through the module's test hook: two fingerprint bits survive.
+        cm = [bytes([7 + i]) * 32 for i in range(n)]
         agg_c = RC.g1_sum(b"".join(RC.g2pubs.sign(m, sk) for m, sk in zip(cm, sks)), n)
-        ok_coll = bdist.sharded_verify_aggregate("g2pubs", cm[lo:hi], b"".join(pks[lo:hi]), agg_c, rank, world, gather, engine=_OracleEngine)
-        k = np.frombuffer(bdist.message_keys(cm), dtype=np.uint8).reshape(-1, 33)
-        fpc = bdist.row_fingerprints(k)
-        assert fpc[0] == fpc[n - 1] and ok_coll is True and RC.g2pubs.verify_aggregate(agg_c, pks, cm) is True
+        bdist._FP_TEST_MASK = 0x3
+        try:
+            k = np.frombuffer(bdist.message_keys(cm), dtype=np.uint8).reshape(-1, 33)
+            fpc = bdist.row_fingerprints(k, bdist._fingerprint_key(gather, world))
+            assert len(set(fpc.tolist())) < n                       # pigeonhole: 5 messages, 4 fingerprint values
+            ok_coll = bdist.sharded_verify_aggregate("g2pubs", cm[lo:hi], b"".join(pks[lo:hi]), agg_c, rank, world, gather, engine=_OracleEngine)
+            dupc = list(cm); dupc[n - 1] = dupc[0]
+            ok_coll_dup = bdist.sharded_verify_aggregate("g2pubs", dupc[lo:hi], b"".join(pks[lo:hi]), agg_c, rank, world, gather, engine=_OracleEngine)
+        finally:
+            bdist._FP_TEST_MASK = None
+        assert ok_coll is True and ok_coll_dup is False and RC.g2pubs.verify_aggregate(agg_c, pks, cm) is True
+        # the fingerprint key is the same on both ranks and not the default
+        kk = bdist._fingerprint_key(gather, world)
+        both = gather(np.array(kk, dtype=np.uint64).tobytes())
+        assert both[0] == both[1] and int(kk[1]) & 1
+        # a device failure on ONE rank (its aggregate_partial raises): no rank may hang in the all-gather of the partials;
+        # the failing rank re-raises its error, the other raises too
+        class _Failing(_OracleEngine):
+            @staticmethod
+            def aggregate_partial(group, msgs_, pks_):
+                if rank == 1:
+                    raise RuntimeError("simulated HIP failure on rank 1")
+                return _OracleEngine.aggregate_partial(group, msgs_, pks_)
+        try:
+            bdist.sharded_verify_aggregate("g2pubs", msgs[lo:hi], b"".join(pks[lo:hi]), agg, rank, world, gather, engine=_Failing)
+            raised = False
+        except RuntimeError as e:
+            raised = ("simulated" in str(e)) == (rank == 1)
+        assert raised
         q.put((rank, ok, ok_dup, ok_bad or ok_len or ok_inf or ok_infsig, RC.g2pubs.verify_aggregate(agg, pks, msgs)))
     finally:
         dist.destroy_process_group()
