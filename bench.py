@@ -1,38 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- BLS12-381 pairings/sec (batch verify path) on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
-torch.distributed.run with one rank per GPU.  A step is one pass of the hot path over one batch of
-synthetic input resident in HBM: BASELINE.json configs[1] -- 65 536 independent pairings
-(Miller loop + final exponentiation, the reference's bls.Pairing) per GPU.  W untimed steps, then
-exactly K timed steps bracketed by barrier + synchronize on both sides, MAX over ranks, one JSON line
-from rank 0.  Units shard across ranks with no data-path collective (weak scaling: 64k pairings per GPU).
-After the timed region every rank compares rows of its output with the oracle and the run FAILS on a mismatch.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  A step is one pass of the hot path over one batch of
+synthetic input resident in HBM: BASELINE.json configs[1] -- 65 536 independent pairings (Miller loop + final
+exponentiation, the reference's bls.Pairing) per GPU.  W untimed steps, then exactly K timed steps bracketed by barrier +
+synchronize on both sides, MAX over ranks, one JSON line from rank 0.  Units shard across GPUs with no data-path collective
+(weak scaling: 64k pairings per GPU).  After the timed region the output is compared with the oracle and the run FAILS on a
+mismatch.
 
-Extra objects on the line:
-  roofline     -- dominant kernel, algorithmic bytes (864 B per pairing) / its HIP-event duration measured
-                  on the launch stream, vs 8 TB/s HBM; `traffic` = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3
-                  PMC passes of this same command (profiles/rNN_counters.json).
-  valu         -- the bound that binds (integer VALU issue): measured VALU wave-instructions per launch from the same
-                  profile -> lane-instructions per pairing, and the nominal Fq-multiplication rate against the measured
-                  ceiling of the multiply core (profiles/r01_ubench2_fmul_15x27.log).
-  cpu_baseline -- the oracle (C restatement of the reference algorithm, oracle/refcpu.c) timed on this box's host cores
-                  on a bounded sample of the same workload (rank 0, N = 1).
-  verify_bench -- the batch-VERIFY workload under the same discipline (timed steps between fences, MAX over ranks):
-                  every rank verifies 65 536 (message, key, signature) tuples -- hash-to-curve, 2-pair Miller loop, final
-                  exponentiation, compare -- and, when N > 1, the RCCL all-reduce of the pass/fail bitmap is INSIDE every
-                  timed step (the north-star's only collective).
-  aggregate_bench -- BASELINE configs[3]: ONE 2^20-signature g2pubs VerifyAggregate (distinct messages) sharded over
-                  the N ranks (2^20 / N tuples per rank; partial products all-gathered, one final exponentiation).
-  reference_shapes -- the reference's own benchmark shapes (pairing_test.go:60-152, g2pubs/bls_test.go:215-256,
-                  g1pubs/verify_benchmark_test.go:15-85), GPU single-call latency and batch throughput beside the CPU
-                  restatement on ONE core (the reference's benchmarks are single-threaded).  N = 1 only.
+Two launch styles, same numbers at N = 1:
+  * under torch.distributed.run (RANK / WORLD_SIZE in the environment): one process per GPU, RCCL through torch.distributed;
+  * plain `python bench.py --gpus N`: ONE process drives N devices through the library (blsmi_init_devices(N)) -- the
+    deployment the Go API implies (one process, one call, g2pubs/bls.go:159, 240).  The headline step runs one resident
+    65 536-pairing batch per device concurrently (blsmi_pairing_batch_dev routes by buffer ownership); `inlibrary_bench`
+    times the split HOST entry points -- N x 65 536 pairings, N x 65 536 verifies with the library's own ncclAllReduce of
+    the bitmap inside every timed call, and the 2^20-signature VerifyAggregate with its ncclAllGather of partial products.
+
+Every BASELINE config has an entry under `configs` (value, roofline of its dominant kernel, CPU baseline of the same shape):
+  configs[0]  1 000 g2pubs.Verify tuples on the CPU restatement of the reference (plumbing), the GPU verdicts beside it
+  configs[1]  the headline (65 536 pairings per GPU)
+  configs[2]  2^20-point G1 and G2 scalar multiplication and MSM, inputs resident (blsmi_g*_mul_batch_dev / _msm_dev)
+  configs[3]  one 2^20-signature g2pubs VerifyAggregate, sharded over the N GPUs
+  configs[4]  one 262 144-message g1pubs VerifyAggregate on one GPU
+Rooflines: algorithmic bytes per unit x units per launch / the dominant kernel's duration measured with HIP events
+on the launch stream by the library itself (blsmi_set_profiling / blsmi_last_profile); `traffic` and the VALU counters come
+from the committed rocprofv3 PMC passes of this same command (profiles/rNN_counters.json) -- the line says which file, and
+"stale": true when any kernel source changed since (source digest recorded at profile time).
 """
 import argparse
 import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -41,30 +43,63 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PAIRINGS_PER_GPU = 65536
-BYTES_PER_PAIRING = 864            # 96 B G1 + 192 B G2 in, 576 B Fq12 out
 HBM_PEAK_GBS = 8000.0              # MI355X spec (MI355X_MICROARCH.md)
-# measured integer-VALU ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip,
-# profiles/r01_ubench2_fmul_15x27.log): 61.2e9 mul/s at 4 waves/SIMD, 56.7e9 at 2, 45.6e9 at 1
+# algorithmic bytes per unit
+BYTES = {"pairing": 864,           # 96 B G1 + 192 B G2 in, 576 B Fq12 out
+         "g1_mul": 224, "g2_mul": 416,          # point + 32-byte scalar in, point out
+         "g1_msm": 128, "g2_msm": 224,          # point + scalar in (one point out per launch)
+         "verify": 320,                         # 96 + 192 + 32-byte message in, 1 bit out (either package)
+         "g2pubs_aggregate": 224, "g1pubs_aggregate": 128}   # 32-byte message + key in
+# integer-VALU issue ceiling: 1 024 SIMDs x 64 lanes per wave-instruction / 4 cycles x clock (the int32 / v_mad_*64 rate, tools/ubench*)
+SIMDS, LANES, CYCLES_PER_VALU, CLOCK_GHZ = 1024, 64, 4.0, 2.4
+# measured ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip, profiles/r01_ubench2_fmul_15x27.log)
 VALU_PEAK_GMULS = 61.2
 VALU_PEAK_2WAVE_GMULS = 56.7
-FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate (Miller 6.9k + final exp 7.7k): the nominal work unit of `valu`
+FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate: the nominal work unit of `valu.nominal`
 R_ORDER = 52435875175126190479447740508185965837690552500527637822603658699938581184513
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# committed rocprofv3 counters (bench.py cannot read PMCs itself)
+# ---------------------------------------------------------------------------------------------------------------------
+def source_digest():
+    """sha256 over the kernel sources: recorded by tools/rocpd_summary.py at profile time, recomputed here -> `stale`"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "bls_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cuh", ".inc", ".h", ".py")) and not f.startswith("lat_programs"):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profile_counters():
-    """Per-kernel rocprofv3 counters of the newest committed profile round (profiles/rNN*_counters.json, written by
-    tools/rocpd_summary.py from separate --pmc passes of this same bench command).  bench.py cannot read PMCs itself:
-    it reports the committed measurement and names the file."""
-    import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))
     if not files:
-        return None, {}
+        return {"file": None, "stale": None, "kernels": {}}
     try:
-        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))["kernels"]
+        j = json.load(open(files[-1]))
+        dig = j.get("source_digest")
+        return {"file": os.path.relpath(files[-1], ROOT), "commit": j.get("commit"), "source_digest": dig,
+                "stale": (dig != source_digest()) if dig else True, "kernels": j["kernels"]}
     except (OSError, ValueError, KeyError):
-        return None, {}
+        return {"file": None, "stale": None, "kernels": {}}
 
 
+def counter_of(ctr, kernel, grid=None):
+    """counters of `kernel` at launch grid `grid` (lanes); the profile keeps one record per (kernel, grid)"""
+    k = ctr["kernels"].get(kernel)
+    if not k:
+        return {}
+    if grid is not None and "by_grid" in k and str(grid) in k["by_grid"]:
+        return k["by_grid"][str(grid)]
+    if grid is not None and k.get("grid") not in (None, grid) and k.get("pmc_grid") not in (None, grid):
+        return {}
+    return k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic inputs
+# ---------------------------------------------------------------------------------------------------------------------
 def _gens():
     g1gen = bytes.fromhex(
         "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
@@ -80,131 +115,101 @@ def _gens():
 def synth_inputs(engine, n, seed):
     """n (P_i, Q_i) pairs: P = a_j G1, Q = b_j G2 for 512 seeded scalars, tiled with a row rotation so that all
     n combinations are distinct.  Generated on the device by the library's own scalar multiplication."""
-    import hashlib
     base = 512
     sc = [hashlib.sha256(b"blsmi-bench-%d-%d" % (seed, i)).digest() for i in range(2 * base)]
     sc = [(int.from_bytes(s, "big") % (R_ORDER - 1) + 1).to_bytes(32, "big") for s in sc]
-    g1gen, g2gen = _gens()
-    g1b, _ = engine.g1_mul_batch(g1gen * base, b"".join(sc[:base]), base)
-    g2b, _ = engine.g2_mul_batch(g2gen * base, b"".join(sc[base:]), base)
+    g1b, _ = engine.g1_mul_generator_batch(b"".join(sc[:base]), base)
+    g2b, _ = engine.g2_mul_generator_batch(b"".join(sc[base:]), base)
     reps = (n + base - 1) // base
     g1 = np.tile(g1b, (reps, 1))[:n]
     g2 = np.concatenate([np.roll(g2b, -r, axis=0) for r in range(reps)])[:n]
     return np.ascontiguousarray(g1), np.ascontiguousarray(g2)
 
 
-def _verify_inputs(engine, dev, group, n, tag=0):
-    """n valid (message, public key, signature) tuples of one package, resident in HBM (signed on the device)."""
-    import hashlib
-    import torch
-    nk = 256
+def _verify_tuples(engine, group, n, tag=0, nk=256):
+    """n valid (message, public key, signature) tuples of one package as host arrays (signed on the device)"""
     sk = b"".join(hashlib.sha256(b"bench-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
     msgs = [b"Hello world! 16 characters %d" % (i + tag * n) for i in range(n)]
     buf = np.frombuffer(b"".join(msgs), dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.uint64); off[1:] = np.cumsum([len(m) for m in msgs])
-    g1gen, g2gen = _gens()
+    packed = engine.PackedMsgs.__new__(engine.PackedMsgs); packed.buf, packed.off, packed.n = buf, off, n
     if group == "g2pubs":
-        pks, _ = engine.g2_mul_batch(g2gen * nk, sk, nk)
-        h = engine.hash_g1_batch(msgs)
+        pks, _ = engine.g2_mul_generator_batch(sk, nk)
+        h = engine.hash_g1_batch(packed)
         sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
     else:
-        pks, _ = engine.g1_mul_batch(g1gen * nk, sk, nk)
-        h = engine.hash_g2_batch(msgs)
+        pks, _ = engine.g1_mul_generator_batch(sk, nk)
+        h = engine.hash_g2_batch(packed)
         sigs, _ = engine.g2_mul_batch(h.reshape(-1), sk * (n // nk), n)
-    allpk = np.tile(pks, (n // nk, 1))
-    return [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (buf.copy(), off.view(np.int64), allpk, sigs)]
+    allpk = np.ascontiguousarray(np.tile(pks, (n // nk, 1)))
+    return packed, allpk, np.ascontiguousarray(sigs)
 
 
-def verify_bench(engine, dev, rank, world, dist, use_dist, steps=5, warmup=1, n=65536):
-    """The batch-verify workload under bench.py's own timing discipline, both packages.  With a process group the
-    bitmap all-reduce (SUM over disjoint bit ownership == OR, RCCL) runs inside every timed step."""
-    import torch
-    out = {"tuples_per_gpu": n, "steps": steps, "warmup": warmup,
-           "collective": ("one all_reduce(SUM, int32 lanes, disjoint bit ownership) of the %d-byte bitmap over RCCL inside every timed step" % (world * n // 8)) if use_dist else "none (one GPU)"}
-    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=dev)
-    for group in ("g2pubs", "g1pubs"):
-        d = _verify_inputs(engine, dev, group, n, tag=rank)
-        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-        full = torch.zeros(world * n // 8, dtype=torch.int32, device=dev)
-
-        def step():
-            engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
-            if use_dist:
-                full.zero_()
-                full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
-                dist.all_reduce(full, op=dist.ReduceOp.SUM)
-
-        def fence():
-            if use_dist:
-                dist.barrier()
-            torch.cuda.synchronize()
-        for _ in range(warmup):
-            step()
-        fence(); t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        fence(); dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            assert bool((full == 255).all().item()), "every rank's tuples must verify and land in the shared bitmap"
-        assert bool(d_ok.all().item()), "synthetic tuples must all verify"
-        dt = float(t.item())
-        out[group + "_verifies_per_s"] = round(world * n * steps / dt, 1)
-        out[group + "_ms_per_step"] = round(dt / steps * 1e3, 3)
-    out["note"] = "all tuples valid; inputs resident in HBM; hash-to-curve on the GPU included; 1 Verify = 2 Miller-loop pairs + 1 final exponentiation + 1 hash"
-    return out
-
-
-def aggregate_bench(engine, dev, rank, world, dist, use_dist, n_total=1 << 20, reps=2):
-    """BASELINE configs[3]: one n_total-signature g2pubs VerifyAggregate over distinct 32-byte messages, block-sharded over the
-    ranks.  Per rank: duplicate screening, hash-to-curve, n/N Miller loops and the Fq12 product tree on its GPU; then the
-    digests and the 576-byte partial products are all-gathered (bls_amd/dist.py) and every rank finishes with one final
-    exponentiation.  Host buffers (what a caller of the Go API holds), so PCIe is included."""
-    import hashlib
-    import torch
-    from bls_amd import dist as bdist
-    n = n_total // world
-    lo = rank * n
-    nk = 256
+def _aggregate_inputs(engine, group, lo, n, nk=256):
+    """n (32-byte message, key) pairs with indices lo .. lo+n and this block's share of the aggregate signature"""
     sk = b"".join(hashlib.sha256(b"agg-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
     msgs = [hashlib.sha256(int(i).to_bytes(8, "little")).digest() for i in range(lo, lo + n)]
-    _, g2gen = _gens()
-    pks, _ = engine.g2_mul_batch(g2gen * nk, sk, nk)
-    allpk = np.ascontiguousarray(np.tile(pks, (n // nk, 1))).reshape(-1)
-    h = engine.hash_g1_batch(msgs)
-    sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
-    part = engine.g1_sum(sigs.reshape(-1), n)                              # this rank's share of the aggregate signature
-    if use_dist:
-        gather = bdist.torch_all_gather_bytes(dev)
-        parts = gather(part)
-        agg = engine.g1_sum(b"".join(parts), world)
+    packed = engine.PackedMsgs(msgs)
+    if group == "g2pubs":
+        pks, _ = engine.g2_mul_generator_batch(sk, nk)
+        h = engine.hash_g1_batch(packed)
+        sigs, _ = engine.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
+        part = engine.g1_sum(sigs.reshape(-1), n)
     else:
-        gather = None
-        agg = part
-    packed = engine.PackedMsgs(msgs)                                       # the C ABI's layout (what a Go caller would hold), built once
-    best = 1e9
-    ok = None
-    for _ in range(reps + 1):                                              # first repetition warms the pools
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        if use_dist:
-            ok = bdist.sharded_verify_aggregate("g2pubs", packed, allpk, agg, rank, world, gather)
-            dist.barrier()
-        else:
-            ok = engine.g2pubs_verify_aggregate(packed, allpk, agg)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if use_dist:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        best = min(best, float(t.item()))
-    assert ok is True, "the synthetic aggregate must verify"
-    return {"signatures": n * world, "signatures_per_gpu": n, "ms": round(best * 1e3, 2), "signatures_per_s": round(n * world / best, 1),
-            "exchange": ("all-gather of 8-byte message fingerprints (global duplicate rejection: each rank screens 1/world of them, full keys only on suspicion) + all-gather of %d x 576-byte Fq12 partial products over RCCL" % world) if use_dist else "none (one GPU)",
-            "note": "host buffers: PCIe included; min over %d repetitions; verdict True (false-verdict cases: tests/test_gpu_fullsize.py)" % reps}
+        pks, _ = engine.g1_mul_generator_batch(sk, nk)
+        h = engine.hash_g2_batch(packed)
+        sigs, _ = engine.g2_mul_batch(h.reshape(-1), sk * (n // nk), n)
+        part = engine.g2_sum(sigs.reshape(-1), n)
+    allpk = np.ascontiguousarray(np.tile(pks, (n // nk, 1))).reshape(-1)
+    return packed, allpk, part, pks
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# per-kernel timing through the library (HIP events on the launch stream) and the roofline object of a leg
+# ---------------------------------------------------------------------------------------------------------------------
+def read_profile(lib):
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.blsmi_last_profile(buf, ctypes.c_size_t(len(buf)))
+    out = {}
+    for item in buf.value.decode().split(";"):
+        if "=" in item:
+            k, v = item.split("=")
+            e = out.setdefault(k, [0.0, 0]); e[0] += float(v); e[1] += 1
+    return out          # kernel -> [total ms, launches]
+
+
+def profiled(lib, fn):
+    """run fn() once with the library's per-kernel event timing on; returns {kernel: [ms, launches]}"""
+    read_profile(lib)
+    lib.blsmi_set_profiling(1)
+    try:
+        fn()
+    finally:
+        lib.blsmi_set_profiling(0)
+    return read_profile(lib)
+
+
+def roofline_of(prof, units, bytes_per_unit, ctr, grid_of=None):
+    """roofline object of one leg: dominant kernel of `prof`, algorithmic bytes / its duration vs the HBM peak"""
+    if not prof:
+        return None
+    dom = max(prof, key=lambda k: prof[k][0])
+    ms, launches = prof[dom]
+    per_launch_ms = ms / max(1, launches)
+    algo = bytes_per_unit * units
+    achieved = algo / (ms * 1e-3) / 1e9
+    c = counter_of(ctr, dom, grid_of(dom) if grid_of else None)
+    traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8),
+            "traffic": traffic, "algorithmic_bytes_per_launch": algo, "bytes_per_unit": bytes_per_unit, "units_per_launch": units,
+            "kernel_ms": round(per_launch_ms, 4), "kernel_launches": launches,
+            "all_kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
+            "rocprof_avg_ms": round(c["avg_ns"] / 1e6, 4) if "avg_ns" in c else None}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle = C restatement of the reference algorithm, kind "port"), bounded samples
+# ---------------------------------------------------------------------------------------------------------------------
 def usable_cores():
     """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max / cfs_quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -222,44 +227,302 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(g1, g2, budget_s=12.0):
-    """Time the oracle's Pairing() (C port of the reference algorithm) on the host cores this container may use,
-    one thread per core, over a bounded sample."""
+def cpu_timed(work, per_thread, unit, what, budget_s):
+    """work(k, m): process m units as thread k.  Calibrates on 2 units, then runs per-core chunks for ~budget_s."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import refcpu as RC
     cores = usable_cores()
-    t0 = time.time()
-    RC.pairing_batch(g1[:4].tobytes(), g2[:4].tobytes(), 4)
-    per = (time.time() - t0) / 4
-    chunk = max(4, int(budget_s / per / 1.0))              # pairings per thread for ~budget_s of wall time
-    chunk = min(chunk, g1.shape[0] // cores)
-
-    def work(k):
-        lo = k * chunk
-        RC.pairing_batch(g1[lo:lo + chunk].tobytes(), g2[lo:lo + chunk].tobytes(), chunk)
+    t0 = time.time(); work(0, 2); per = (time.time() - t0) / 2
+    m = int(max(2, min(per_thread, budget_s / max(per, 1e-6))))
     t0 = time.time()
     with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(work, range(cores)))
+        list(ex.map(lambda k: work(k, m), range(cores)))
     dt = time.time() - t0
-    return {"value": round(cores * chunk / dt, 2), "unit": "pairings/s", "cores": cores, "kind": "port",
-            "sample": "%d reference-algorithm Pairing() calls of the same workload (%d per thread x %d threads = usable cores: "
-                      "affinity mask capped by the cgroup CPU quota; host reports %d logical CPUs; %.1f s wall); "
-                      "oracle/refcpu.c = C restatement of the Go reference (no Go toolchain on this image)" % (cores * chunk, chunk, cores, os.cpu_count() or 0, dt),
-            "single_core_pairings_per_s": round(1.0 / per, 2)}
+    return {"value": round(cores * m / dt, 2), "unit": unit, "cores": cores, "kind": "port",
+            "sample": "%d %s (%d per thread x %d threads = usable cores: affinity mask capped by the cgroup CPU quota; host reports %d logical CPUs; %.1f s wall); "
+                      "oracle/refcpu.c = C restatement of the Go reference (no Go toolchain on this image)" % (cores * m, what, m, cores, os.cpu_count() or 0, dt),
+            "single_core_per_s": round(1.0 / per, 2)}
 
 
-def self_check(engine, d_out, g1, g2, n):
-    """Outside the timed region: rows of the device output against the oracle's Pairing(), bit for bit (576 bytes each)."""
+def cpu_pairing(g1, g2, budget_s=8.0):
     from oracle import refcpu as RC
-    idx = sorted({0, 1, 63, 64, n // 3, n // 2, n - 65, n - 1} & set(range(n)))
-    got = d_out[idx].cpu().numpy().view(np.uint64)
-    for k, i in enumerate(idx):
-        want = RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]
-        if not np.array_equal(got[k], want):
-            return False, i, len(idx)
-    return True, -1, len(idx)
+    n = g1.shape[0]
+
+    def work(k, m):
+        lo = (k * m) % max(1, n - m)
+        RC.pairing_batch(g1[lo:lo + m].tobytes(), g2[lo:lo + m].tobytes(), m)
+    r = cpu_timed(work, n // usable_cores(), "pairings/s", "reference-algorithm Pairing() calls of the same workload", budget_s)
+    r["single_core_pairings_per_s"] = r["single_core_per_s"]
+    return r
 
 
+def cpu_mul(group, pts, ks, budget_s=2.5):
+    from oracle import refcpu as RC
+    fn = RC.g1_mul if group == "g1" else RC.g2_mul
+
+    def work(k, m):
+        for i in range(m):
+            j = (k * m + i) % pts.shape[0]
+            fn(pts[j].tobytes(), ks[j].tobytes())
+    return cpu_timed(work, 4096, "scalar multiplications/s", "reference-algorithm %s MulFR (bit-serial double-and-add, %s.go) of the same points and scalars" % (group.upper(), group), budget_s)
+
+
+def cpu_verify(group, packed, pks, sigs, budget_s=3.0):
+    from oracle import refcpu as RC
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    msgs = [bytes(packed.buf[int(packed.off[i]):int(packed.off[i + 1])]) for i in range(min(packed.n, 2048))]
+
+    def work(k, m):
+        idx = [(k * m + i) % len(msgs) for i in range(m)]
+        o.verify_batch([msgs[i] for i in idx], [pks[i].tobytes() for i in idx], [sigs[i].tobytes() for i in idx])
+    return cpu_timed(work, 1024, "verifies/s", "reference-algorithm %s.Verify calls (hash-to-curve + CompareTwoPairings) of the same tuples" % group, budget_s)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# legs
+# ---------------------------------------------------------------------------------------------------------------------
+class Env:
+    """what a leg needs: engine, lib, torch device(s), rank/world, collectives"""
+
+
+def fence(E):
+    import torch
+    if E.use_dist:
+        E.dist.barrier()
+    for d in E.devs:
+        torch.cuda.synchronize(d)
+
+
+def max_over_ranks(E, dt):
+    import torch
+    if not E.use_dist:
+        return dt
+    t = torch.tensor([dt], dtype=torch.float64, device=E.dev)
+    E.dist.all_reduce(t, op=E.dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def timed_steps(E, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    fence(E); t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence(E)
+    return max_over_ranks(E, time.perf_counter() - t0)
+
+
+def verify_bench(E, steps=5, warmup=1, n=65536):
+    """The batch-verify workload under bench.py's own timing discipline, both packages, inputs resident.  With a process
+    group the bitmap all-reduce (SUM over disjoint bit ownership == OR, RCCL) runs inside every timed step."""
+    import torch
+    engine, dev, rank, world, dist = E.engine, E.dev, E.rank, E.world, E.dist
+    out = {"tuples_per_gpu": n, "steps": steps, "warmup": warmup,
+           "collective": ("one all_reduce(SUM, int32 lanes, disjoint bit ownership) of the %d-byte bitmap over RCCL inside every timed step" % (world * n // 8)) if E.use_dist else "none (one GPU)"}
+    weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=dev)
+    for group in ("g2pubs", "g1pubs"):
+        packed, pks, sigs = _verify_tuples(engine, group, n, tag=rank)
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (packed.buf.copy(), packed.off.view(np.int64), pks, sigs)]
+        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+        full = torch.zeros(world * n // 8, dtype=torch.int32, device=dev)
+
+        def step():
+            engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+            if E.use_dist:
+                full.zero_()
+                full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
+                dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        dt = timed_steps(E, step, steps, warmup)
+        if E.use_dist:
+            assert bool((full == 255).all().item()), "every rank's tuples must verify and land in the shared bitmap"
+        assert bool(d_ok.all().item()), "synthetic tuples must all verify"
+        out[group + "_verifies_per_s"] = round(world * n * steps / dt, 1)
+        out[group + "_ms_per_step"] = round(dt / steps * 1e3, 3)
+        if rank == 0:
+            prof = profiled(E.lib, step)
+            out[group + "_roofline"] = roofline_of(prof, n, BYTES["verify"], E.ctr, lambda k: 2 * n if k.endswith("_pair") else n)
+            if world == 1 and E.cpu:
+                out[group + "_cpu_baseline"] = cpu_verify(group, packed, pks, sigs)
+    out["note"] = "all tuples valid; inputs resident in HBM; hash-to-curve on the GPU included; 1 Verify = 2 Miller-loop pairs + 1 final exponentiation + 1 hash"
+    return out
+
+
+def msm_bench(E, n=1 << 20, steps=3, warmup=1):
+    """BASELINE configs[2]: 2^20-point G1 and G2 scalar multiplication and MSM, inputs resident in HBM (rank 0 / device 0)."""
+    import torch
+    from oracle import refcpu as RC
+    engine, dev = E.engine, E.dev
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); k[:, 0] &= 0x3f
+    base = 4096
+    out = {"points": n, "steps": steps, "warmup": warmup, "note": "inputs and outputs resident in HBM (device-pointer entry points, blsmi 0.3); scalars uniform below 2^254; "
+           "points = 4096 distinct multiples of the generator, tiled"}
+    d_k = torch.from_numpy(k.reshape(-1)).to(dev)
+    for grp, pb in (("g1", 96), ("g2", 192)):
+        bk = rng.integers(0, 256, size=(base, 32), dtype=np.uint8); bk[:, 0] &= 0x3f
+        bpts, _ = (engine.g1_mul_generator_batch if grp == "g1" else engine.g2_mul_generator_batch)(bk.reshape(-1), base)
+        pts = np.ascontiguousarray(np.tile(bpts, (n // base, 1)))
+        d_p = torch.from_numpy(pts.reshape(-1)).to(dev)
+        d_out = torch.empty(n * pb, dtype=torch.uint8, device=dev); d_inf = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_one = torch.zeros(pb, dtype=torch.uint8, device=dev)
+
+        def mul_step():
+            engine.mul_batch_dev(grp, d_p.data_ptr(), d_k.data_ptr(), d_out.data_ptr(), d_inf.data_ptr(), n)
+
+        def msm_step():
+            engine.msm_dev(grp, d_p.data_ptr(), d_k.data_ptr(), n, d_one.data_ptr())
+        for name, step, units_bytes in ((grp + "_mul", mul_step, BYTES[grp + "_mul"]), (grp + "_msm", msm_step, BYTES[grp + "_msm"])):
+            dt = timed_steps(E, step, steps, warmup)
+            prof = profiled(E.lib, step)
+            out[name] = {"value": round(n * steps / dt, 1), "unit": "scalar multiplications/s" if name.endswith("mul") else "points/s",
+                         "ms_per_step": round(dt / steps * 1e3, 3), "roofline": roofline_of(prof, n, units_bytes, E.ctr)}
+        # parity gate of the leg: sampled multiples against the oracle, and MSM == sum of the multiples (device tree sum)
+        got = d_out.view(n, pb)
+        ref_mul = RC.g1_mul if grp == "g1" else RC.g2_mul
+        for i in (0, 1, 4097, n // 2, n - 1):
+            assert got[i].cpu().numpy().tobytes() == ref_mul(pts[i].tobytes(), k[i].tobytes()), "%s_mul row %d differs from the oracle" % (grp, i)
+        d_sum = torch.zeros(pb, dtype=torch.uint8, device=dev)
+        assert engine.sum_dev(grp, d_out.data_ptr(), 0, n, d_sum.data_ptr()) is False
+        assert torch.equal(d_sum, d_one), "%s MSM differs from the sum of the per-point multiples" % grp
+        if E.cpu:
+            out[grp + "_mul"]["cpu_baseline"] = cpu_mul(grp, pts[:4096], k[:4096])
+            out[grp + "_msm"]["cpu_baseline"] = dict(out[grp + "_mul"]["cpu_baseline"], note="the reference has no MSM: a caller loops MulFR and AddAssign; one MulFR per point is the CPU cost (the addition is <1 % of it)")
+        del d_p, d_out
+    return out
+
+
+def aggregate_dev_bench(E, group, n, reps=3):
+    """One n-message VerifyAggregate with messages and keys resident in HBM (blsmi_g*pubs_verify_aggregate_dev), rank 0 / device 0.
+    Duplicate rejection on the device included.  Verdict True; a one-wrong-key run must say False (outside the timed region)."""
+    import torch
+    engine, dev = E.engine, E.dev
+    packed, allpk, agg, pks = _aggregate_inputs(engine, group, 0, n)
+    d_m = torch.from_numpy(packed.buf.copy()).to(dev); d_o = torch.from_numpy(packed.off.view(np.int64).copy()).to(dev); d_k = torch.from_numpy(allpk).to(dev)
+    res = {}
+
+    def step():
+        res["ok"] = engine.verify_aggregate_dev(group, d_m.data_ptr(), d_o.data_ptr(), d_k.data_ptr(), agg, n)
+    dt = timed_steps(E, step, reps, 1)
+    assert res["ok"] is True, "the synthetic aggregate must verify"
+    prof = profiled(E.lib, step)
+    pkb = 192 if group == "g2pubs" else 96
+    bad = d_k.clone(); bad[pkb * (n // 3):pkb * (n // 3 + 1)] = torch.from_numpy(pks[(n // 3 + 1) % pks.shape[0]].copy()).to(dev)
+    assert engine.verify_aggregate_dev(group, d_m.data_ptr(), d_o.data_ptr(), bad.data_ptr(), agg, n) is False, "one wrong key must fail the aggregate"
+    out = {"signatures": n, "ms": round(dt / reps * 1e3, 2), "signatures_per_s": round(n * reps / dt, 1),
+           "roofline": roofline_of(prof, n, BYTES[group + "_aggregate"], E.ctr),
+           "note": "messages (32 bytes each), offsets and keys resident in HBM; duplicate-message rejection on the device (keyed fingerprints + radix sort) included; "
+                   "n Miller loops (two tuples per loop) + Fq12 product tree + ONE final exponentiation; verdict True, and False with one key replaced"}
+    return out, (packed, allpk, agg)
+
+
+def aggregate_bench(E, n_total=1 << 20, reps=2):
+    """BASELINE configs[3]: one n_total-signature g2pubs VerifyAggregate over distinct 32-byte messages, block-sharded over the
+    ranks (torchrun) -- per rank: duplicate screening, hash-to-curve, n/N Miller loops and the Fq12 product tree on its GPU; then
+    the digests and the 576-byte partial products are all-gathered (bls_amd/dist.py) and every rank finishes with one final
+    exponentiation -- or, in one process, through the library's split host entry point (blsmi_g2pubs_verify_aggregate).
+    Host buffers (what a caller of the Go API holds), so PCIe is included."""
+    import torch
+    from bls_amd import dist as bdist
+    engine, dev, rank, world, dist = E.engine, E.dev, E.rank, E.world, E.dist
+    n = n_total // world
+    packed, allpk, part, _ = _aggregate_inputs(engine, "g2pubs", rank * n, n)
+    if E.use_dist:
+        gather = bdist.torch_all_gather_bytes(dev)
+        agg = engine.g1_sum(b"".join(gather(part)), world)
+    else:
+        gather, agg = None, part
+    best, ok = 1e9, None
+    for _ in range(reps + 1):                                              # first repetition warms the pools
+        fence(E); t0 = time.perf_counter()
+        if E.use_dist:
+            ok = bdist.sharded_verify_aggregate("g2pubs", packed, allpk, agg, rank, world, gather)
+        else:
+            ok = engine.g2pubs_verify_aggregate(packed, allpk, agg)
+        fence(E)
+        best = min(best, max_over_ranks(E, time.perf_counter() - t0))
+    assert ok is True, "the synthetic aggregate must verify"
+    return {"signatures": n * world, "signatures_per_gpu": n, "ms": round(best * 1e3, 2), "signatures_per_s": round(n * world / best, 1),
+            "exchange": ("all-gather of 8-byte keyed message fingerprints (global duplicate rejection: each rank screens 1/world of them, full keys only on suspicion) + all-gather of %d x 576-byte Fq12 partial products over RCCL" % world) if E.use_dist else "none (one GPU)",
+            "note": "host buffers: PCIe included; min over %d repetitions; verdict True (false-verdict cases: tests/test_gpu_fullsize.py)" % reps}
+
+
+def config0(E):
+    """BASELINE configs[0]: 1 000 g2pubs tuples, every 16th corrupted, through g2pubs.Verify on the CPU restatement of the
+    reference (the plumbing case) and, beside it, through the library: the verdict tables must be identical."""
+    from oracle import refcpu as RC
+    engine = E.engine
+    n = 1000
+    packed, pks, sigs = _verify_tuples(engine, "g2pubs", 1024, tag=7, nk=64)
+    msgs = [bytes(packed.buf[int(packed.off[i]):int(packed.off[i + 1])]) for i in range(n)]
+    pks = pks[:n].copy(); sigs = sigs[:n].copy()
+    expect = np.ones(n, dtype=bool)
+    for i in range(15, n, 16):
+        kind = (i // 16) % 3
+        expect[i] = False
+        if kind == 0:
+            msgs[i] = msgs[i] + b"!"
+        elif kind == 1:
+            pks[i] = pks[(i + 1) % 64]
+        else:
+            y = int.from_bytes(sigs[i, 48:].tobytes(), "big")
+            sigs[i, 48:] = np.frombuffer(((RC_Q() - y) % RC_Q()).to_bytes(48, "big"), dtype=np.uint8)
+    t0 = time.perf_counter()
+    ok, _ = engine.g2pubs_verify_batch(msgs, pks.reshape(-1), sigs.reshape(-1))
+    gpu_s = time.perf_counter() - t0
+    assert np.array_equal(ok, expect), "configs[0]: library verdicts differ from the corruption schedule"
+    from concurrent.futures import ThreadPoolExecutor
+    cores = usable_cores()
+    per = (n + cores - 1) // cores
+    chunks = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        parts = list(ex.map(lambda c: RC.g2pubs.verify_batch(msgs[c[0]:c[1]], [pks[i].tobytes() for i in range(*c)], [sigs[i].tobytes() for i in range(*c)]), chunks))
+    cpu_s = time.time() - t0
+    cpu_ok = np.concatenate(parts)
+    assert np.array_equal(cpu_ok, expect), "configs[0]: oracle verdicts differ from the corruption schedule"
+    return {"workload": "1 000 (msg, G2 pubkey, G1 sig) tuples through g2pubs.Verify, every 16th corrupted (wrong message / wrong key / negated signature)",
+            "cpu": {"value": round(n / cpu_s, 1), "unit": "verifies/s", "cores": cores, "kind": "port", "wall_s": round(cpu_s, 2),
+                    "sample": "all 1 000 tuples on the C restatement of the reference (oracle/refcpu.c), %d threads" % cores},
+            "gpu": {"value": round(n / gpu_s, 1), "unit": "verifies/s", "ms_one_call": round(gpu_s * 1e3, 2), "path": "host buffers, one call of 1 000 tuples (latency path: one tuple per wave)"},
+            "verdicts_identical": True, "rejected": int((~expect).sum())}
+
+
+def RC_Q():
+    from oracle import pyref as P
+    return P.Q
+
+
+def inlibrary_bench(E, ndev, n_per_dev=65536, steps=3):
+    """One process, `ndev` devices behind the C ABI: the split HOST entry points.  Every call carries ndev x n_per_dev tuples in
+    host memory; the library cuts it into one block per device, each block on its own host thread and stream, and -- for the
+    verify batch with a bitmap -- completes the packed verdicts with ONE ncclAllReduce inside the call (the north-star's only
+    collective).  PCIe-inclusive by construction."""
+    engine = E.engine
+    n = ndev * n_per_dev
+    out = {"devices": engine.device_count(), "shards": engine.shard_count(), "tuples_per_call": n, "steps": steps,
+           "collective": "ncclAllReduce(uint8 SUM, disjoint bit ownership) of the %d-byte bitmap inside every verify call" % (n // 8) if ndev > 1 else "none (one device: the call is not split)"}
+    g1, g2 = synth_inputs(engine, n, seed=99)
+
+    def best(fn):
+        fn(); b = 1e9
+        for _ in range(steps):
+            t0 = time.perf_counter(); fn(); b = min(b, time.perf_counter() - t0)
+        return b
+    t = best(lambda: engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n))
+    out["pairings_per_s"] = round(n / t, 1); out["pairing_ms_per_call"] = round(t * 1e3, 2)
+    for group in ("g2pubs", "g1pubs"):
+        packed, pks, sigs = _verify_tuples(engine, group, n, tag=5)
+        fn = engine.g2pubs_verify_batch if group == "g2pubs" else engine.g1pubs_verify_batch
+        res = {}
+
+        def call():
+            res["ok"], res["bm"] = fn(packed, pks.reshape(-1), sigs.reshape(-1))
+        t = best(call)
+        assert res["ok"].all() and (res["bm"] == 255).all(), "in-library split verify: every tuple must verify and every bitmap byte must be complete"
+        out[group + "_verifies_per_s"] = round(n / t, 1); out[group + "_ms_per_call"] = round(t * 1e3, 2)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -267,9 +530,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairings", type=int, default=PAIRINGS_PER_GPU, help="pairings per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify-extra", action="store_true", help="skip verify_bench / aggregate_bench / reference_shapes")
+    ap.add_argument("--no-verify-extra", action="store_true", help="headline only: skip every other leg")
     ap.add_argument("--no-aggregate", action="store_true")
     ap.add_argument("--no-ref-shapes", action="store_true")
+    ap.add_argument("--no-msm", action="store_true")
     args = ap.parse_args()
 
     # The contract is ONE line on stdout.  Libraries print banners there (RCCL announces its version when the first
@@ -280,139 +544,220 @@ def main():
 
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    rank = int(os.environ.get("RANK", "0")) if torchrun else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if torchrun else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if torchrun else 1
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (no CPU fallback: the HIP path is the product)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or bool(os.environ.get("BLSMI_BENCH_FORCE_DIST"))     # the env switch exercises the RCCL path on a 1-GPU box
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if torchrun and world != args.gpus:
+        print("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+        sys.exit(2)
+    single_process_devices = args.gpus if not torchrun else 1            # one process driving N devices through the library
+    if single_process_devices > torch.cuda.device_count():
+        print("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
 
-    from bls_amd import engine
-    engine.init(local_rank)
-    n = args.pairings
-    g1, g2 = synth_inputs(engine, n, seed=rank)
-    d_g1 = torch.from_numpy(g1).to(dev)
-    d_g2 = torch.from_numpy(g2).to(dev)
-    d_out = torch.zeros((n, 72), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    from bls_amd import _native
+    E = Env()
+    E.rank, E.world, E.dist = rank, world, dist
+    E.use_dist = torchrun and (world > 1 or bool(os.environ.get("BLSMI_BENCH_FORCE_DIST")))
+    if not torchrun and os.environ.get("BLSMI_BENCH_FORCE_DIST"):          # exercise the RCCL path of the rank style on a 1-GPU box
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        E.use_dist = True
+    torch.cuda.set_device(local_rank)
+    E.dev = torch.device("cuda", local_rank)
+    E.devs = [torch.device("cuda", i) for i in range(single_process_devices)] if not torchrun else [E.dev]
+    if E.use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=E.dev)
+
+    from bls_amd import engine, _native
+    if torchrun:
+        engine.init(local_rank)
+    else:
+        engine.init_devices(single_process_devices)
     lib = _native.load()
+    E.engine, E.lib = engine, lib
+    E.ctr = profile_counters()
+    E.cpu = (world == 1 and single_process_devices == 1 and not args.no_cpu_baseline)
+    n = args.pairings
+    ndev = len(E.devs)
+
+    # ---- headline: configs[1], one resident batch per device ----------------------------------------------------------
+    g1, g2 = synth_inputs(engine, n, seed=rank)
+    bufs = []
+    for d in E.devs:
+        bufs.append((torch.from_numpy(g1).to(d), torch.from_numpy(g2).to(d), torch.zeros((n, 72), dtype=torch.int64, device=d)))
+    fence(E)
+
+    def step_dev(i):
+        a, b, o = bufs[i]
+        engine.pairing_batch_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), n)
 
     def step():
-        engine.pairing_batch_dev(d_g1.data_ptr(), d_g2.data_ptr(), d_out.data_ptr(), n)
-
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
+        if ndev == 1:
+            step_dev(0)
+        else:                                                              # one host thread per device; the C call releases the interpreter lock
+            th = [threading.Thread(target=step_dev, args=(i,)) for i in range(1, ndev)]
+            for t in th:
+                t.start()
+            step_dev(0)
+            for t in th:
+                t.join()
 
     for _ in range(args.warmup):
         step()
     lib.blsmi_set_profiling(1)
-    kms = []
-    fence()
+    read_profile(lib)
+    fence(E)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        a, b = ctypes.c_float(0), ctypes.c_float(0)
-        lib.blsmi_last_kernel_ms(ctypes.byref(a), ctypes.byref(b))
-        kms.append((a.value, b.value))
-    fence()
+    fence(E)
     dt = time.perf_counter() - t0
     lib.blsmi_set_profiling(0)
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    prof = read_profile(lib)                                               # the calling thread's device (device 0 / this rank), all timed steps
+    dt = max_over_ranks(E, dt)
+    total_gpus = world * ndev
 
-    # parity gate, outside the timed region, on every rank: a fast kernel with different results is not a result
-    good, bad_row, nrows = self_check(engine, d_out, g1, g2, n)
-    flag = torch.tensor([0 if good else 1], dtype=torch.int32, device=dev)
-    if use_dist:
+    # parity gate, outside the timed region, on every rank and device: a fast kernel with different results is not a result
+    from oracle import refcpu as RC
+    idx = sorted({0, 1, 63, 64, n // 3, n // 2, n - 65, n - 1} & set(range(n)))
+    good, bad_at = True, None
+    for di, (_, _, o) in enumerate(bufs):
+        got = o[idx].cpu().numpy().view(np.uint64)
+        for kk, i in enumerate(idx):
+            if not np.array_equal(got[kk], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]):
+                good, bad_at = False, (di, i)
+    flag = torch.tensor([0 if good else 1], dtype=torch.int32, device=E.dev)
+    if E.use_dist:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()):
-        print("bench.py: SELF-CHECK FAILED: device output differs from the oracle's Pairing() (rank %d row %d)" % (rank, bad_row), file=sys.stderr)
+        print("bench.py: SELF-CHECK FAILED: device output differs from the oracle's Pairing() (rank %d, device/row %s)" % (rank, bad_at), file=sys.stderr)
         sys.exit(3)
+    checksum = int(bufs[0][2][::997].sum().item()) & 0xffffffff
 
     extras = {}
-    if not args.no_verify_extra:                                     # all ranks take part in the collectives
-        for name, fn in (("verify_bench", lambda: verify_bench(engine, dev, rank, world, dist, use_dist)),
-                         ("aggregate_bench", None if args.no_aggregate else (lambda: aggregate_bench(engine, dev, rank, world, dist, use_dist)))):
-            if fn is None:
-                continue
-            try:
-                extras[name] = fn()
-            except Exception as e:  # noqa: BLE001 -- an extra must never cost the headline line
-                extras[name] = {"error": repr(e)[:300]}
-    checksum = int(d_out[::997].sum().item()) & 0xffffffff
-    if rank == 0:
-        ml = float(np.mean([k[0] for k in kms])); fe = float(np.mean([k[1] for k in kms]))
-        suffix = "" if os.environ.get("BLSMI_LAYOUT") == "single" else "_pair"
-        kname = {"ml": "k_miller1h" + suffix, "fe": "k_final_exp" + suffix}      # the kernels of blsmi_pairing_batch_dev (blsmi.hip: pairing_dev, mode 0)
-        dom, dom_ms = (kname["fe"], fe) if fe >= ml else (kname["ml"], ml)
-        achieved = BYTES_PER_PAIRING * n / (dom_ms * 1e-3) / 1e9
-        value = world * n * args.steps / dt
-        per_gpu = value / world
-        cfile, ctr = profile_counters()
-        scale = n / 65536.0
 
-        def traffic_of(k):
-            c = ctr.get(k, {})
-            return (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * scale if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
-        valu_insts = [ctr.get(kname[k], {}).get("SQ_INSTS_VALU") for k in ("ml", "fe")]
-        lane_instr = (sum(valu_insts) * 64 / 65536.0) if all(v is not None for v in valu_insts) else None
+    def leg(name, fn):
+        try:
+            extras[name] = fn()
+        except Exception as e:  # noqa: BLE001 -- an extra must never cost the headline line
+            extras[name] = {"error": repr(e)[:400]}
+    agg_dev_inputs = {}
+    if not args.no_verify_extra:
+        if ndev == 1:                                                      # rank style (or one device): all ranks take part in the collectives
+            leg("verify_bench", lambda: verify_bench(E))
+            if not args.no_aggregate:
+                leg("aggregate_bench", lambda: aggregate_bench(E))
+        if rank == 0 and ndev == 1 and world == 1:
+            if not args.no_msm:
+                leg("msm_bench", lambda: msm_bench(E))
+            if not args.no_aggregate:
+                def _agg(group, m):
+                    r, inp = aggregate_dev_bench(E, group, m)
+                    agg_dev_inputs[group] = inp
+                    return r
+                leg("g2pubs_aggregate_dev_bench", lambda: _agg("g2pubs", 1 << 20))
+                leg("g1pubs_aggregate_bench", lambda: _agg("g1pubs", 1 << 18))
+            leg("config0", lambda: config0(E))
+        if not torchrun:                                                   # one process behind the C ABI: the split host entry points
+            leg("inlibrary_bench", lambda: inlibrary_bench(E, ndev))
+            if ndev > 1 and not args.no_aggregate:
+                leg("aggregate_bench", lambda: aggregate_bench(E))
+
+    if rank == 0:
+        suffix = "" if os.environ.get("BLSMI_LAYOUT") == "single" else "_pair"
+        kname = {"ml": "k_miller1h" + suffix, "fe": "k_final_exp" + suffix}
+        ml = prof.get(kname["ml"], [0.0, 1]); fe = prof.get(kname["fe"], [0.0, 1])
+        ml_ms, fe_ms = ml[0] / max(1, ml[1]), fe[0] / max(1, fe[1])
+        grid = 2 * n if suffix else n
+        value = total_gpus * n * args.steps / dt
+        per_gpu = value / total_gpus
+        ctr = E.ctr
+        roof = roofline_of({k: [v[0] / max(1, v[1]), 1] for k, v in prof.items()}, n, BYTES["pairing"], ctr, lambda k: grid)
+        if roof:
+            roof["traffic_unit"] = "bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes) of %s" % ctr["file"]
+            roof["kernel_ms"] = {kname["ml"]: round(ml_ms, 3), kname["fe"]: round(fe_ms, 3)}
+            tr = {}
+            for k in kname.values():
+                c = counter_of(ctr, k, grid)
+                tr[k] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * (n / 65536.0) if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+            roof["traffic_all"] = tr
+            roof["note"] = "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"
+        valu_insts = [counter_of(ctr, kname[k], grid).get("SQ_INSTS_VALU") for k in ("ml", "fe")]
+        lane_instr = (sum(valu_insts) * LANES / 65536.0) if all(v is not None for v in valu_insts) else None
+        issue_peak = SIMDS * LANES / CYCLES_PER_VALU * CLOCK_GHZ * 1e9       # lane-instructions per second per GPU
         line = {
             "metric": "BLS12-381 pairings/sec (batch verify)", "value": round(value, 1), "unit": "pairings/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "n_gpus": total_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (15 x 27-bit limbs, int64 accumulate)",
             "data": "synthetic",
+            "launch": "torchrun: one process per GPU" if torchrun else "single process: %d device(s) behind the C ABI (blsmi_init_devices)" % ndev,
+            "devices": total_gpus, "rccl_ranks": world if E.use_dist else (ndev if ndev > 1 else 0),
+            "library": engine.version(),
             "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exp) per GPU per step, inputs resident in HBM, "
-                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py; %d rows per rank re-checked against the oracle after the timed region)" % (n, nrows),
-                       "pairings_per_gpu": n, "parallelism": "shard%d" % world,
+                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py; %d rows per device re-checked against the oracle after the timed region)" % (n, len(idx)),
+                       "pairings_per_gpu": n, "parallelism": "shard%d" % total_gpus,
                        "layout": "one tuple per lane" if suffix == "" else "lane pair per tuple (one Fq2 coefficient per lane), 2 waves/SIMD"},
-            "self_check": {"rows_per_rank": nrows, "against": "oracle Pairing() (oracle/refcpu.c), bit-exact 576-byte Fq12", "passed": True},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 8),
-                         "traffic": traffic_of(dom),
-                         "traffic_unit": "bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes) of %s" % cfile,
-                         "algorithmic_bytes_per_launch": BYTES_PER_PAIRING * n,
-                         "kernel_ms": {kname["ml"]: round(ml, 3), kname["fe"]: round(fe, 3)},
-                         "traffic_all": {kname[k]: traffic_of(kname[k]) for k in ("ml", "fe")},
-                         "note": "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"},
-            "valu": {"bound": "int32 VALU issue (v_mad_i64_i32)",
+            "self_check": {"rows_per_device": len(idx), "against": "oracle Pairing() (oracle/refcpu.c), bit-exact 576-byte Fq12", "passed": True},
+            "roofline": roof,
+            "valu": {"bound": "int32 VALU issue (v_mad_i64_i32): %d SIMDs x %d lanes / %.0f cycles x %.1f GHz" % (SIMDS, LANES, CYCLES_PER_VALU, CLOCK_GHZ),
                      "lane_instructions_per_pairing": None if lane_instr is None else round(lane_instr),
-                     "lane_instructions_source": "SQ_INSTS_VALU (wave-instructions per 65 536-pairing launch) x 64 / 65 536, both pairing kernels, %s" % cfile,
-                     "giga_lane_instructions_per_s": None if lane_instr is None else round(per_gpu * lane_instr / 1e9, 1),
-                     "achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2),
-                     "peak": VALU_PEAK_GMULS, "unit": "G Fq-mul/s", "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_GMULS, 4),
-                     "frac_of_2wave_per_simd_peak": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_2WAVE_GMULS, 4),
-                     "note": "peak = measured issue ceiling of the 15x27 Montgomery multiply core per GPU (profiles/r01_ubench2_fmul_15x27.log); "
-                             "achieved = pairings/s x 14.6k nominal Fq multiplications per pairing (SURVEY 8d); the instruction count is a measurement"},
+                     "lane_instructions_source": "SQ_INSTS_VALU (wave-instructions per 65 536-pairing launch) x 64 / 65 536, both pairing kernels, %s" % ctr["file"],
+                     "achieved": None if lane_instr is None else round(per_gpu * lane_instr / 1e12, 3),
+                     "peak": round(issue_peak / 1e12, 3), "unit": "T lane-instructions/s per GPU",
+                     "frac": None if lane_instr is None else round(per_gpu * lane_instr / issue_peak, 4),
+                     "nominal": {"achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2), "peak": VALU_PEAK_GMULS, "unit": "G Fq-mul/s",
+                                 "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_GMULS, 4),
+                                 "frac_of_2wave_per_simd_peak": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_2WAVE_GMULS, 4),
+                                 "note": "pairings/s x 14.6k nominal Fq multiplications (SURVEY 8d) against the measured ceiling of the multiply core (profiles/r01_ubench2_fmul_15x27.log)"},
+                     "note": "frac = measured VALU lane-instructions per second / issue peak: the instruction COUNT is a committed measurement (same command, PMC pass), the RATE is this run's"},
+            "counters": {"file": ctr["file"], "commit": ctr.get("commit"), "source_digest": ctr.get("source_digest"), "stale": ctr["stale"],
+                         "note": "traffic / VALU counts are read from this committed rocprofv3 PMC round; stale = a kernel source changed since it was taken"},
             "checksum": checksum,
         }
         line.update(extras)
-        if world == 1 and not args.no_verify_extra and not args.no_ref_shapes:
+        if world == 1 and ndev == 1 and not args.no_verify_extra and not args.no_ref_shapes:
             try:
                 from tools import reference_shapes
                 line["reference_shapes"] = reference_shapes.run(engine)
             except Exception as e:  # noqa: BLE001
                 line["reference_shapes"] = {"error": repr(e)[:300]}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(g1, g2)
+        if E.cpu:
+            line["cpu_baseline"] = cpu_pairing(g1, g2)
+            if "g2pubs_aggregate_dev_bench" in line and "error" not in line["g2pubs_aggregate_dev_bench"] and "verify_bench" in line:
+                pass
+        # ---- one entry per BASELINE config ----
+        cfg = {}
+        if "config0" in line:
+            cfg["0"] = line["config0"]
+        cfg["1"] = {"workload": line["config"]["workload"], "value": line["value"], "unit": "pairings/s", "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "frac", "traffic")} if roof else None,
+                    "cpu_baseline": {k: line["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in line else None}
+        if "msm_bench" in line and "error" not in line["msm_bench"]:
+            cfg["2"] = {"workload": "2^20-point G1 and G2 scalar multiplication + MSM, resident", **{k: line["msm_bench"][k] for k in ("g1_mul", "g1_msm", "g2_mul", "g2_msm") if k in line["msm_bench"]}}
+        if "aggregate_bench" in line and "error" not in line["aggregate_bench"]:
+            cfg["3"] = {"workload": "one 2^20-signature g2pubs VerifyAggregate, distinct messages, %d GPU(s)" % total_gpus,
+                        "host_buffers": {k: line["aggregate_bench"][k] for k in ("ms", "signatures_per_s", "exchange")}}
+            if "g2pubs_aggregate_dev_bench" in line and "error" not in line["g2pubs_aggregate_dev_bench"]:
+                cfg["3"]["resident"] = line["g2pubs_aggregate_dev_bench"]
+        if "g1pubs_aggregate_bench" in line and "error" not in line["g1pubs_aggregate_bench"]:
+            cfg["4"] = dict(workload="one 262 144-message g1pubs VerifyAggregate (G1 pubkeys, G2 signatures), one GPU", **line["g1pubs_aggregate_bench"])
+        if E.cpu and "verify_bench" in line and "g2pubs_cpu_baseline" in line["verify_bench"]:
+            vb = line["verify_bench"]
+            # the CPU does n + 1 full pairings + n hashes per aggregate: ~ one Verify's work per signature (2 Miller loops + FE + hash vs 1 + FE + hash)
+            for key, grp in (("3", "g2pubs"), ("4", "g1pubs")):
+                if key in cfg and grp + "_cpu_baseline" in vb:
+                    cfg[key]["cpu_baseline"] = dict(vb[grp + "_cpu_baseline"], note="per signature the reference's VerifyAggregate does one hash-to-curve + one full Pairing (n + 1 pairings in all, "
+                                                    "g2pubs/bls.go:262-268); %s.Verify on the same host (hash + 2-pair Miller loop + final exponentiation) is the closest timed shape, within ~25 %% of it" % grp)
+        line["configs"] = cfg
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
-    if use_dist:
+    if E.use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -72,6 +72,8 @@ struct Ctx {
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     bool busy = false;
     Device* dev = nullptr;
+    // per-kernel timing (blsmi_set_profiling): events recorded between the major kernels of the call that holds this context
+    std::vector<hipEvent_t> pev; std::vector<const char*> pname; size_t pused = 0;
     hipError_t ensure_aux() {
         if (aux[0]) return hipSuccess;
         hipError_t e;
@@ -111,6 +113,8 @@ bool g_use_gen_lines = true;           // BLSMI_GEN_LINES=0 recomputes the gener
 // optional per-kernel timing (HIP events on the launch stream) for bench.py's roofline object; results are per calling thread
 std::atomic<bool> g_profile{false};
 thread_local float tl_last_ms[2] = {0.f, 0.f};
+// Segments (kernel name, milliseconds) of the profiled calls this thread made since it last read them (blsmi_last_profile).
+thread_local std::vector<std::pair<const char*, float>> tl_prof;
 
 // ---- RCCL, loaded on demand (a single-GPU deployment never needs it) ---------------------------------------------
 struct Rccl {
@@ -156,6 +160,7 @@ int init_device(Device& d) {            // caller holds g_mu
 }
 // Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
 // (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
+std::atomic<bool> g_mul_subgroup{true}; // scalar multiplication through the endomorphisms (multiplicands in the subgroup); BLSMI_MUL_GENERIC=1 / blsmi_set_mul_assume_subgroup(0): plain ladder
 std::atomic<size_t> g_lat_max{4096};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely)
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
@@ -174,6 +179,7 @@ int ensure_init_list(const int* devs, int ndev) {
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
     if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
     for (int i = 0; i < ndev; i++) {
         g_dev[i].id = devs[i]; g_dev[i].index = i;
@@ -209,6 +215,29 @@ int ensure_init_default() {             // lazy initialisation by the first entr
 inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
 int device_index_of_ordinal(int ordinal) { for (int i = 0; i < g_ndev; i++) if (g_dev[i].id == ordinal) return i; return -1; }
 
+// prof_mark(name): called right before the launch of a major kernel (name = nullptr: after the last one).  Segment i runs from
+// mark i to mark i + 1 on the launch stream and carries the name of mark i; the marks of a call are turned into
+// (name, ms) pairs when its context lease ends (every entry point is blocking, so the stream is idle by then).
+#define g_stream_ (tl_ctx->stream)
+inline void prof_mark(const char* name) {
+    if (!g_profile.load(std::memory_order_relaxed) || !tl_ctx) return;
+    Ctx& c = *tl_ctx;
+    if (c.pused == c.pev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; c.pev.push_back(e); c.pname.push_back(nullptr); }
+    if (hipEventRecord(c.pev[c.pused], g_stream_) != hipSuccess) return;
+    c.pname[c.pused++] = name;
+}
+inline void prof_collect(Ctx& c) {
+    if (c.pused < 2) { c.pused = 0; return; }
+    (void)hipEventSynchronize(c.pev[c.pused - 1]);
+    for (size_t i = 0; i + 1 < c.pused; i++) {
+        if (!c.pname[i]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c.pev[i], c.pev[i + 1]) == hipSuccess) tl_prof.emplace_back(c.pname[i], ms);
+    }
+    if (tl_prof.size() > 16384) tl_prof.erase(tl_prof.begin(), tl_prof.begin() + 8192);   // nobody is reading: keep the newest
+    c.pused = 0;
+}
+
 // Lease of one call context for the duration of an entry point.  dev_index < 0: any device (the one with the fewest
 // contexts in use, scanning from a rotating start, so that concurrent callers spread over the GPUs).
 struct CtxLease {
@@ -236,11 +265,13 @@ struct CtxLease {
         if (hipSetDevice(c->dev->id) != hipSuccess) { rc = BLSMI_E_HIP; return; }      // the current device is per-thread state
         if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = BLSMI_E_HIP; return; }
         c->busy = true; c->dev->leased++;
+        c->pused = 0;
         outer = tl_ctx;
         tl_ctx = mine = c;
     }
     ~CtxLease() {
         if (!mine) return;
+        if (mine->pused) { prof_mark(nullptr); prof_collect(*mine); }
         { std::lock_guard<std::mutex> lk(g_mu); mine->busy = false; mine->dev->leased--; }
         tl_ctx = outer;
         if (outer) (void)hipSetDevice(outer->dev->id);
@@ -355,6 +386,8 @@ BLSMI_API void blsmi_shutdown(void) {
             (void)hipStreamSynchronize(c.stream);
             c.ws.release();
             for (auto& e : c.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            for (auto& e : c.pev) (void)hipEventDestroy(e);
+            c.pev.clear(); c.pname.clear(); c.pused = 0;
             for (auto& a : c.aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
             if (c.fork) { (void)hipEventDestroy(c.fork); c.fork = nullptr; }
             for (auto& j : c.join) if (j) { (void)hipEventDestroy(j); j = nullptr; }
@@ -375,40 +408,38 @@ BLSMI_API const char* blsmi_version(void) { return g_version; }
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;
     if (mode == 0 && n <= g_lat_max) {                                     // small call: one pairing per wave (k_lat.hip)
+        prof_mark("k_lat:pairing1");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(LAT_PAIRING1_OFFSET), s, (const u8*)g_gens.lat + LAT_PAIRING1_OFFSET,
                            (const u8*)d_g1, (size_t)96, (const u8*)d_g2, (size_t)192, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, (u8*)nullptr, (u64*)d_out, n);
+        prof_mark(nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
         return BLSMI_OK;
     }
     if (mode == 1 && n <= g_lat_max) {                                     // small MillerLoop call: the reference's steps as a level program
+        prof_mark("k_lat:miller1x");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(LAT_MILLER1X_OFFSET), s, (const u8*)g_gens.lat + LAT_MILLER1X_OFFSET,
                            (const u8*)d_g1, (size_t)96, (const u8*)d_g2, (size_t)192, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, (u8*)nullptr, (u64*)d_out, n);
+        prof_mark(nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
         return BLSMI_OK;
     }
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
-    const bool prof = g_profile.load();
-    if (prof && !tl_ctx->ev[0]) for (auto& e : tl_ctx->ev) HIPCHK(hipEventCreate(&e));
-    if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[0], s));
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
     // mode 1 (MillerLoop): the reference's steps; mode 0 (Pairing): the homogeneous steps
+    prof_mark(g_pair_layout ? (mode ? "k_miller1_pair" : "k_miller1h_pair") : (mode ? "k_miller1" : "k_miller1h"));
     if (g_pair_layout) hipLaunchKernelGGL(mode ? k_miller1_pair : k_miller1h_pair, dim3(pblocks), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
     else hipLaunchKernelGGL(mode ? k_miller1 : k_miller1h, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
-    if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[1], s));
+    prof_mark(g_pair_layout ? "k_final_exp_pair" : "k_final_exp");
     if (g_pair_layout) hipLaunchKernelGGL(k_final_exp_pair, dim3(pblocks), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
     else hipLaunchKernelGGL(k_final_exp, dim3(nblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, mode);
-    if (prof) HIPCHK(hipEventRecord(tl_ctx->ev[2], s));
+    prof_mark(nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));      // blocking entry point: results are ready on return
-    if (prof) {
-        HIPCHK(hipEventElapsedTime(&tl_last_ms[0], tl_ctx->ev[0], tl_ctx->ev[1]));
-        HIPCHK(hipEventElapsedTime(&tl_last_ms[1], tl_ctx->ev[1], tl_ctx->ev[2]));
-    }
     return BLSMI_OK;
 }
 // Enable/disable per-kernel HIP-event timing of blsmi_pairing_batch[_dev]; read back (by the calling thread, for its own
@@ -418,12 +449,32 @@ BLSMI_API int blsmi_set_latency_threshold(size_t max_tuples) {
     g_lat_max.store(max_tuples);
     return BLSMI_OK;
 }
+BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
+    g_mul_subgroup.store(on != 0);
+    return BLSMI_OK;
+}
 BLSMI_API int blsmi_set_profiling(int on) {
     g_profile.store(on != 0);
     return BLSMI_OK;
 }
+// the calling thread's profile log as "name=ms;name=ms;..." (kernels in launch order; a name may repeat), read-and-clear.
+// Returns the length needed (excluding the terminator); the text is truncated to cap - 1 characters.
+BLSMI_API int blsmi_last_profile(char* out, size_t cap) {
+    std::string t;
+    char tmp[96];
+    for (auto& p : tl_prof) { snprintf(tmp, sizeof tmp, "%s=%.4f;", p.first, p.second); t += tmp; }
+    tl_prof.clear();
+    if (out && cap) { const size_t k = std::min(cap - 1, t.size()); memcpy(out, t.data(), k); out[k] = 0; }
+    return (int)t.size();
+}
+// Miller-loop / final-exponentiation kernel times of the calling thread's last profiled blsmi_pairing_batch[_dev] call
+// (kept for callers of blsmi 0.2; reads the same log without clearing it)
 BLSMI_API int blsmi_last_kernel_ms(float* miller_ms, float* final_exp_ms) {
     if (!miller_ms || !final_exp_ms) return BLSMI_E_ARG;
+    for (auto& p : tl_prof) {
+        if (!strncmp(p.first, "k_miller1", 9)) tl_last_ms[0] = p.second;
+        else if (!strncmp(p.first, "k_final_exp", 11)) tl_last_ms[1] = p.second;
+    }
     *miller_ms = tl_last_ms[0]; *final_exp_ms = tl_last_ms[1];
     return BLSMI_OK;
 }
@@ -541,17 +592,33 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
     if (m <= g_lat_max) {                                                  // small call: one multiplication per wave (k_lat.hip, SEL levels)
         const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
         DBuf good; HIPCHK(good.alloc(m, s));
+        prof_mark(PB == 96 ? "k_lat:mul1" : "k_lat:mul2");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)m), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, base, stride,
                            d_scalars, (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), m);
+        prof_mark(nullptr);
         hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(m)), dim3(WG), 0, s, (const u8*)good.as<u8>(), base, stride, PB / 4, d_out, d_inf, m);
         HIPCHK(hipGetLastError());
         return BLSMI_OK;                                                   // `good` is released in stream order
     }
+    // points of the prime-order subgroup (the default): the ladder through the curve endomorphisms (glv.cuh) -- half / a quarter
+    // of the doublings; arbitrary curve points (blsmi_set_mul_assume_subgroup(0)): the plain fixed-window ladder
+    const bool glv = g_mul_subgroup.load(std::memory_order_relaxed);
+    if (glv) {
+        prof_mark(PB == 192 ? (g_pair_layout ? "k_g2_mul_glv_pair" : "k_g2_mul_glv") : "k_g1_mul_glv");
+        if (PB == 192 && g_pair_layout) hipLaunchKernelGGL(k_g2_mul_glv_pair, dim3((unsigned)((m + PT - 1) / PT)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
+        else if (PB == 192) hipLaunchKernelGGL(k_g2_mul_glv, dim3(nblocks(m)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
+        else hipLaunchKernelGGL(k_g1_mul_glv, dim3(nblocks(m)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
+        prof_mark(nullptr);
+        HIPCHK(hipGetLastError());
+        return BLSMI_OK;
+    }
+    prof_mark(PB == 192 ? (g_pair_layout ? "k_g2_mul_pair" : "k_g2_mul") : "k_g1_mul");
     if (PB == 192 && g_pair_layout)                                        // G2: lane-pair kernel, two waves per SIMD
         hipLaunchKernelGGL(k_g2_mul_pair, dim3((unsigned)((m + PT - 1) / PT)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
     else
         hipLaunchKernelGGL(kernel, dim3(nblocks(m)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
+    prof_mark(nullptr);
     HIPCHK(hipGetLastError());
     return BLSMI_OK;
 }
@@ -607,6 +674,7 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
         // projective formulas, two product levels per addition) -- ~10 us a level instead of ~70-140
         const size_t p0 = W == 3 ? LAT_SUM0_1_OFFSET : LAT_SUM0_2_OFFSET, p1 = W == 3 ? LAT_SUM1_1_OFFSET : LAT_SUM1_2_OFFSET, pf = W == 3 ? LAT_SUMFIN_1_OFFSET : LAT_SUMFIN_2_OFFSET;
         const u8* L = (const u8*)g_gens.lat;
+        prof_mark("k_lat:sum");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)half), dim3(64), lat_lds_bytes(p0), s, L + p0, d_pts, (size_t)PB, d_inf, (size_t)0, (const u8*)nullptr, half,
                            (const u8*)nullptr, n, (const u8*)nullptr, (u8*)nullptr, b0.as<u64>(), half);
         i32* src = b0.as<i32>(); i32* dst = b1.as<i32>();
@@ -622,11 +690,14 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(pf), s, L + pf, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)1, (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), (size_t)1);
         hipLaunchKernelGGL(k_good_to_flag, dim3(1), dim3(WG), 0, s, (const u8*)good.as<u8>(), d_out_inf);
+        prof_mark(nullptr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
         return BLSMI_OK;
     }
+    prof_mark(W == 3 ? "k_g1_sum0" : "k_g2_sum0");
     hipLaunchKernelGGL(k0, dim3(nblocks(half)), dim3(WG), 0, s, d_pts, d_inf, b0.as<i32>(), n, half);
+    prof_mark(W == 3 ? "k_g1_sum" : "k_g2_sum");
     i32* src = b0.as<i32>(); i32* dst = b1.as<i32>();
     size_t cur = half;
     while (cur > 1) {
@@ -635,7 +706,9 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
         std::swap(src, dst);
         cur = h;
     }
+    prof_mark(W == 3 ? "k_g1_sum_final" : "k_g2_sum_final");
     hipLaunchKernelGGL(kfinal, dim3(1), dim3(WG), 0, s, (const i32*)src, d_out, d_out_inf);
+    prof_mark(nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     return BLSMI_OK;
@@ -701,7 +774,9 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     HIPCHK(ch0.alloc(sizeof(i32) * jw * nct)); HIPCHK(ch1.alloc(sizeof(i32) * jw * ((per_win + 1) / 2) * nwin));
     HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(dmax.p, 0, sizeof(u32), s));
+    prof_mark("k_msm_hist");
     hipLaunchKernelGGL(k_msm_hist, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, n, c, nwin, hist.as<u32>());
+    prof_mark("k_msm_max");
     // Skewed scalars (many equal digits) would leave one lane adding a whole bucket by itself: beyond 2048 points in
     // any bucket the caller falls back to the per-point multiples, whose cost does not depend on the scalars.
     hipLaunchKernelGGL(k_msm_max, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, dmax.as<u32>());
@@ -709,21 +784,27 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (biggest > 2048) return BLSMI_E_SKEW;
+    prof_mark("k_msm_scan");
     hipLaunchKernelGGL(k_msm_scan, dim3(nwin), dim3(256), 0, s, (const u32*)hist.as<u32>(), offs.as<u32>(), cursor.as<u32>(), c);
+    prof_mark("k_msm_scatter");
     hipLaunchKernelGGL(k_msm_scatter, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, n, c, nwin, cursor.as<u32>(), idx.as<u32>());
     // buckets ranked by population, so that the 64 lanes of a wave add about the same number of points (msm.inc)
     DBuf cls, perm;
     HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(cls.p, 0, sizeof(u32) * 256, s));
     const unsigned cb = (unsigned)((nb + 255) / 256);
+    prof_mark("k_msm_class_*");
     hipLaunchKernelGGL(k_msm_class_hist, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, cls.as<u32>());
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(256), 0, s, (const u32*)cls.as<u32>(), cls.as<u32>() + 256, cls.as<u32>() + 512);
     hipLaunchKernelGGL(k_msm_class_scatter, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, (const u32*)(cls.as<u32>() + 256), cls.as<u32>() + 512, perm.as<u32>());
+    prof_mark(W == 6 ? (g_pair_layout ? "k_g2_msm_bucket_pair" : "k_g2_msm_bucket") : "k_g1_msm_bucket");
     if (W == 6 && g_pair_layout)                                           // G2: a lane pair per bucket, two waves per SIMD
         hipLaunchKernelGGL(k_g2_msm_bucket_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), n, c, nb);
     else
         hipLaunchKernelGGL(k.bucket, dim3(nblocks(nb)), dim3(WG), 0, s, d_pts, (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), n, c, nb);
+    prof_mark(W == 6 ? "k_g2_msm_chunk" : "k_g1_msm_chunk");
     hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    prof_mark(W == 6 ? "k_g2_msm_fold" : "k_g1_msm_fold");
     i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
     size_t seg = per_win;
     while (seg > 1) {
@@ -738,9 +819,11 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
     if (g_lat_max > 0 && c == 16 && nwin == 16) {                          // (the latency path switched off: the one-lane kernel below)
         const size_t prog = W == 3 ? LAT_MSMFIN1_OFFSET : LAT_MSMFIN2_OFFSET;
         DBuf good; HIPCHK(good.alloc(1, s));
+        prof_mark(W == 3 ? "k_lat:msmfin1" : "k_lat:msmfin2");
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)nwin,
                            (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), (size_t)1);
+        prof_mark(nullptr);
         HIPCHK(hipGetLastError());
         u8 good_h = 0;
         HIPCHK(hipMemcpyAsync(&good_h, good.p, 1, hipMemcpyDeviceToHost, s));

@@ -1,6 +1,7 @@
 // k_curve.hip -- scalar multiplication, point sums, the bucket-method MSM, and the Fq6 / curve unit ops of the parity tests.
 #include "tower.cuh"
 #include "device_io.cuh"
+#include "glv.cuh"
 
 KERNEL k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
@@ -90,6 +91,18 @@ KERNEL k_mul_finish(const u8* good, const u8* pts, size_t pt_stride, int rec_wor
 }
 KERNEL2 k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
 KERNEL k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_batch_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
+// The same multiplications through the curve endomorphisms (glv.cuh): half (G1) / a quarter (G2) of the doublings.  For points of
+// the prime-order subgroup -- the default of the scalar-multiplication entry points, see blsmi_set_mul_assume_subgroup.
+template <class F, int PB>
+__device__ void mul_glv_body(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;
+    const Aff<F> p = load_aff<F>(pts + pt_stride * tt);
+    const Aff<F> a = jac_to_affine(glv_mul<F>(p, scalars + 32 * tt));
+    if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
+}
+KERNEL2 k_g1_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
+KERNEL k_g2_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
 
 // Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
 template <class F> struct jac_words { static constexpr int value = sizeof(F) / sizeof(FpS) * 3; };
@@ -204,5 +217,13 @@ __global__ void __launch_bounds__(WG, 2) k_g2_mul_pair(const u8* pts, size_t pt_
         }
     }
     const P2::G2AffP a = jac_to_affine(res);
+    if (t < n) { pair_store_g2(out + (size_t)192 * t, par, a); if (!par) out_inf[t] = a.inf ? 1 : 0; }
+}
+__global__ void __launch_bounds__(WG, 2) k_g2_mul_glv_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const int par = threadIdx.x & 1;
+    const size_t t = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t tt = t < n ? t : n - 1;
+    const P2::G2AffP p = pair_load_g2(pts + pt_stride * tt, par);
+    const P2::G2AffP a = jac_to_affine(glv_mul<P2::Fp2S>(p, scalars + 32 * tt));
     if (t < n) { pair_store_g2(out + (size_t)192 * t, par, a); if (!par) out_inf[t] = a.inf ? 1 : 0; }
 }

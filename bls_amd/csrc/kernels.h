@@ -63,6 +63,8 @@ __global__ void k_good_to_flag(const u8* good, i32* flag);
 __global__ void k_mul_finish(const u8* good, const u8* pts, size_t pt_stride, int rec_words, u8* out, u8* out_inf, size_t n);
 __global__ void k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g1_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g2_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
 __global__ void k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
 __global__ void k_g1_sum(const i32* src, i32* dst, size_t n, size_t half);
@@ -71,6 +73,7 @@ __global__ void k_g1_sum_final(const i32* src, u8* out, i32* out_inf);
 __global__ void k_g2_sum_final(const i32* src, u8* out, i32* out_inf);
 __global__ void k_g2_msm_bucket_pair(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb);
 __global__ void k_g2_mul_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g2_mul_glv_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 // msm.inc
 __global__ void k_msm_hist(const u8* scalars, size_t n, int c, int nwin, u32* hist);
 __global__ void k_msm_scan(const u32* hist, u32* offs, u32* cursor, int c);

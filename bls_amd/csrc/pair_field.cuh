@@ -3,7 +3,7 @@
 // waves per SIMD.  Include AFTER every one-element-per-lane use of BLSMI_FP2_K in the translation unit (fp2_pair.inc
 // re-points that macro at the lane-pair form of a constant).
 #pragma once
-#include "curve.cuh"
+#include "glv.cuh"        // (curve.cuh + the one-element-per-lane endomorphisms, which must see BLSMI_FP2_K before it is re-pointed)
 
 namespace blsmi {
 namespace pairl {
@@ -22,6 +22,8 @@ template <int L, int V> BLSMI_DEV Fp2S f_inv(const Fp2<L, V>& a) { return fp2_st
 template <int L, int V> BLSMI_DEV Fp2<L, V> f_select(i32 m, const Fp2<L, V>& a, const Fp2<L, V>& b) { return fp2_select(m, a, b); }
 using G2JacP = Jac<Fp2S>;
 using G2AffP = Aff<Fp2S>;
+#include "glv_endo2.inc"                                                  // psi, psi^2, psi^3 on lane-pair Jacobian points (glv.cuh finds them by argument-dependent lookup)
 }  // namespace pairl
+template <> struct glv_shape<pairl::Fp2S> { using type = GlvG2; };
 template <> struct field_consts<pairl::Fp2S> { static BLSMI_DEV pairl::Fp2S zero() { return pairl::fp2_zero(); } static BLSMI_DEV pairl::Fp2S one() { return pairl::fp2_one(); } };
 }  // namespace blsmi

@@ -61,6 +61,12 @@ def set_latency_threshold(max_tuples):
     _check(_lib().blsmi_set_latency_threshold(C.c_size_t(int(max_tuples))), "blsmi_set_latency_threshold")
 
 
+def set_mul_assume_subgroup(on=True):
+    """scalar multiplications through the curve endomorphisms (multiplicands in the prime-order subgroup; the default) or,
+    with on=False, the plain windowed ladder that serves every curve point"""
+    _check(_lib().blsmi_set_mul_assume_subgroup(C.c_int(1 if on else 0)), "blsmi_set_mul_assume_subgroup")
+
+
 def shutdown():
     _lib().blsmi_shutdown.restype = None
     _lib().blsmi_shutdown()

@@ -72,6 +72,11 @@ int blsmi_set_profiling(int on);
  * Go API (g2pubs/bls.go:159-162), same results.  Default 4096 (environment BLSMI_LAT_MAX); 0 switches it off. */
 int blsmi_set_latency_threshold(size_t max_tuples);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
+/* General form: with profiling on, every entry point records HIP events on its launch stream between its major kernels.  This
+ * returns the calling thread's log since it last asked, as "kernel=ms;kernel=ms;..." in launch order (a name repeats when a
+ * kernel is launched several times; "k_lat:<program>" = a level program of the latency path), and clears it.  Return value:
+ * the length needed.  Only unsplit calls are logged (the shard threads of a split call keep their own logs). */
+int blsmi_last_profile(char *out, size_t cap);
 /* Miller loop only (pairing.go:16-75 with one pair per tuple), same output format */
 int blsmi_miller_loop_batch(const uint8_t *g1_aff, const uint8_t *g2_aff, uint64_t *out_fq12, size_t n);
 /* Final exponentiation only (pairing.go:79-129) on n Fq12 values in the output format */
@@ -81,6 +86,13 @@ int blsmi_final_exponentiation_batch(const uint64_t *in_fq12, uint64_t *out_fq12
  * AggregateSignatures g2pubs/bls.go:165-192; BASELINE config 3) --------------------------------
  * out[i] = k_i * P_i in affine form; out_inf[i] = 1 when the result is the point at infinity
  * (its 96/192 bytes are then zero).  in_inf may be NULL (all finite). */
+/* The multiplicands must be points of the PRIME-ORDER SUBGROUP -- which every point the g1pubs / g2pubs API can hand to a
+ * multiplication is (hash points: Sign; the generators: PrivToPub; keys and signatures that passed Deserialize*'s subgroup
+ * check).  For them the multiplication runs through the curve endomorphisms (G1: k = k1 + k2 z^2 with phi; G2: base-|x| digits
+ * with psi -- bls_amd/csrc/glv.cuh), half / a quarter of the reference's doublings, the same group element and affine bytes.
+ * For ARBITRARY curve points (the reference's bit-serial MulFR accepts any) call blsmi_set_mul_assume_subgroup(0) first -- or set
+ * BLSMI_MUL_GENERIC=1 -- and the plain fixed-window ladder is used.  Process-wide switch, default 1. */
+int blsmi_set_mul_assume_subgroup(int on);
 int blsmi_g1_mul_batch(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
 int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
 /* k_i * generator (PrivToPub g2pubs/bls.go:138-140 uses G2, g1pubs/bls.go:144-146 uses G1).
