@@ -86,7 +86,8 @@ struct Ctx {
 constexpr int MAX_CTX = 16;
 constexpr int MAX_DEV = 16;
 // G1/G2 generators in wire form and the generator's prepared lines, written once per device at init (read-only afterwards)
-struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; u8* lat = nullptr; };   // lat: the latency-path programs (k_lat.hip)
+struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; u8* lat = nullptr;         // lat: the latency-path programs (k_lat.hip)
+              i32* fixed1 = nullptr; i32* fixed2 = nullptr; };                                    // fixed-base tables of the generators (k_curve.hip: PrivToPub)
 struct Device {
     int id = -1;                        // HIP device ordinal
     int index = 0;                      // position in g_dev
@@ -139,6 +140,7 @@ struct Rccl {
 bool g_have_comm = false;
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, g_rccl.GetErrorString(r_)); return BLSMI_E_RCCL; } } while (0)
 
+inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
 int init_device(Device& d) {            // caller holds g_mu
     HIPCHK(hipSetDevice(d.id));
     hipMemPool_t pool;
@@ -154,6 +156,24 @@ int init_device(Device& d) {            // caller holds g_mu
         HIPCHK(hipGetLastError());
         HIPCHK(hipMalloc((void**)&d.gens.lat, LAT_TOTAL_BYTES));
         HIPCHK(hipMemcpy(d.gens.lat, blsmi_lat_blob, LAT_TOTAL_BYTES, hipMemcpyHostToDevice));
+        // fixed-base tables of the generators (PrivToPub): [d 256^w] G for d = 1 .. 255, w = 0 .. 31, computed by the
+        // scalar-multiplication kernels themselves (the generators lie in the subgroup: endomorphism ladder)
+        {
+            constexpr size_t NE = 32 * 255;
+            std::vector<uint8_t> sc(NE * 32, 0);
+            for (int w = 0; w < 32; w++) for (int dd = 1; dd < 256; dd++) sc[((size_t)w * 255 + dd - 1) * 32 + 31 - w] = (uint8_t)dd;
+            u8 *dsc = nullptr, *wire = nullptr, *inf = nullptr;
+            HIPCHK(hipMalloc((void**)&dsc, NE * 32)); HIPCHK(hipMalloc((void**)&wire, NE * 192)); HIPCHK(hipMalloc((void**)&inf, NE));
+            HIPCHK(hipMemcpy(dsc, sc.data(), NE * 32, hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void**)&d.gens.fixed1, sizeof(i32) * NE * 2 * NL)); HIPCHK(hipMalloc((void**)&d.gens.fixed2, sizeof(i32) * NE * 4 * NL));
+            hipLaunchKernelGGL(k_g1_mul_glv, dim3(nblocks(NE)), dim3(WG), 0, nullptr, (const u8*)d.gens.g1, (size_t)0, (const u8*)dsc, wire, inf, NE);
+            hipLaunchKernelGGL(k_fixed_table_from_wire, dim3(nblocks(NE * 2)), dim3(WG), 0, nullptr, (const u8*)wire, 2, d.gens.fixed1, NE);
+            hipLaunchKernelGGL(k_g2_mul_glv_pair, dim3((unsigned)((NE + PT - 1) / PT)), dim3(WG), 0, nullptr, (const u8*)d.gens.g2, (size_t)0, (const u8*)dsc, wire, inf, NE);
+            hipLaunchKernelGGL(k_fixed_table_from_wire, dim3(nblocks(NE * 4)), dim3(WG), 0, nullptr, (const u8*)wire, 4, d.gens.fixed2, NE);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+            (void)hipFree(dsc); (void)hipFree(wire); (void)hipFree(inf);
+        }
         HIPCHK(hipDeviceSynchronize());
     }
     return BLSMI_OK;
@@ -212,7 +232,6 @@ int ensure_init_default() {             // lazy initialisation by the first entr
     const int d0 = 0;
     return ensure_init_list(&d0, 1);
 }
-inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
 int device_index_of_ordinal(int ordinal) { for (int i = 0; i < g_ndev; i++) if (g_dev[i].id == ordinal) return i; return -1; }
 
 // prof_mark(name): called right before the launch of a major kernel (name = nullptr: after the last one).  Segment i runs from
@@ -394,7 +413,7 @@ BLSMI_API void blsmi_shutdown(void) {
             (void)hipStreamDestroy(c.stream);
             c.stream = nullptr;
         }
-        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); (void)hipFree(dv.gens.lat); dv.gens = Gens{}; }
+        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); (void)hipFree(dv.gens.lat); (void)hipFree(dv.gens.fixed1); (void)hipFree(dv.gens.fixed2); dv.gens = Gens{}; }
         hipMemPool_t pool;
         if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     }
@@ -589,12 +608,31 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
     const u8* d_gen = gen_group == 1 ? g_gens.g1 : g_gens.g2;            // the leased device's copy of the generator
     const u8* base = d_pts ? d_pts : d_gen;
     const size_t stride = d_pts ? (size_t)PB : 0;
-    if (m <= g_lat_max) {                                                  // small call: one multiplication per wave (k_lat.hip, SEL levels)
+    if (!d_pts) {
+        // the generator as the common multiplicand (PrivToPub): the device's fixed-base table -- 32 mixed additions, no doublings.
+        // Small calls: one scalar per wave (the 32 table entries meet in a tree of additions across the lanes).
+        const i32* table = PB == 96 ? g_gens.fixed1 : g_gens.fixed2;
+        static const size_t wave_max = []{ const char* v = getenv("BLSMI_FIXED_WAVE_MAX"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)2048; }();
+        if (m <= wave_max && m <= g_lat_max) {
+            prof_mark(PB == 96 ? "k_g1_mul_fixed_wave" : "k_g2_mul_fixed_wave");
+            if (PB == 96) hipLaunchKernelGGL(k_g1_mul_fixed_wave, dim3((unsigned)m), dim3(WG), 0, s, table, d_scalars, d_out, d_inf, m);
+            else hipLaunchKernelGGL(k_g2_mul_fixed_wave, dim3((unsigned)m), dim3(WG), 0, s, table, d_scalars, d_out, d_inf, m);
+        } else {
+            prof_mark(PB == 96 ? "k_g1_mul_fixed" : "k_g2_mul_fixed");
+            if (PB == 96) hipLaunchKernelGGL(k_g1_mul_fixed, dim3(nblocks(m)), dim3(WG), 0, s, table, d_scalars, d_out, d_inf, m);
+            else hipLaunchKernelGGL(k_g2_mul_fixed, dim3(nblocks(m)), dim3(WG), 0, s, table, d_scalars, d_out, d_inf, m);
+        }
+        prof_mark(nullptr);
+        HIPCHK(hipGetLastError());
+        return BLSMI_OK;
+    }
+    if (m <= g_lat_max && g_mul_subgroup.load(std::memory_order_relaxed)) { // small call: one multiplication per wave (k_lat.hip, SEL levels over the decomposed scalar)
         const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
-        DBuf good; HIPCHK(good.alloc(m, s));
+        DBuf good, rec; HIPCHK(good.alloc(m, s)); HIPCHK(rec.alloc(64 * m, s));
+        hipLaunchKernelGGL(k_glv_recode, dim3(nblocks(m)), dim3(WG), 0, s, d_scalars, PB == 96 ? 1 : 2, rec.as<u8>(), m);
         prof_mark(PB == 96 ? "k_lat:mul1" : "k_lat:mul2");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)m), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, base, stride,
-                           d_scalars, (size_t)32, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
+                           (const u8*)rec.as<u8>(), (size_t)64, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), m);
         prof_mark(nullptr);
         hipLaunchKernelGGL(k_mul_finish, dim3(nblocks(m)), dim3(WG), 0, s, (const u8*)good.as<u8>(), base, stride, PB / 4, d_out, d_inf, m);

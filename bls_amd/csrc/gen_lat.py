@@ -11,7 +11,7 @@ the same code on its own job:
     LIN   S[dst] = normalise( sum_i c_i S[s_i] )  (value-reduced when asked)   recombination of products
     SQR   S[dst] = 3 ( sum_i c_i S[s_i] )^2                                  the squaring core: levels that hold squarings only
     INV   S[dst] = 1 / S[s]                                                    (one lane; safegcd)
-    SEL   S[dst] = S[base + digit_w(scalar) * stride]                          table entry picked by a 4-bit digit of the tuple's scalar
+    SEL   S[dst] = S[base + digit_w(record) * stride]                          table entry picked by a 4-bit digit of the tuple's digit record
     LOAD  S[dst] = input record element           OUT / CHECK: results leave LDS
 
 S = LDS slots of one Fq each (15 signed 27-bit limbs, Montgomery R = 2^405, the representation of fp.cuh).  This script
@@ -30,8 +30,10 @@ CompareTwoPairings (pairing.go:140-147).  The Miller loop here uses homogeneous 
 Miller value by a factor in Fq2*, which the final exponentiation removes: FinalExponentiation(MillerLoop) -- the only
 thing that leaves this path -- is the same field element, bit for bit.
 """
+import os
 import struct
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 X_ABS = 0xd201000000010000
@@ -995,10 +997,16 @@ def build_msm_final_program(b, T, kind, nwin=16, c=16):
 
 
 def build_mul_program(b, T, kind):
-    """[k] P for a run-time 256-bit scalar k (g1.go:80-90 / g2.go MulFR: same group element): fixed 4-bit windows, the table
-    0 P .. 15 P lives in a reserved slot block and a SEL level picks entry digit_w(k) per window -- the control flow does not
-    depend on the scalar.  Inputs: the affine point (buffer 0), the scalar as 32 big-endian bytes (buffer 1).
+    """[k] P for a run-time 256-bit scalar k and P in the prime-order subgroup (g1.go:80-90 / g2.go MulFR: same group element),
+    through the curve endomorphisms (glv_model.py): the scalar arrives DECOMPOSED, as the 64-byte big-endian digit record a small
+    kernel (k_glv_recode) writes -- G1: k1 in bits [0, 256), k2 in [256, 512) with k = k1 + k2 z^2; G2: the base-z digits d_i in
+    bits [128 i, 128 i + 128) -- and every sub-scalar walks fixed 4-bit windows over its own table: 0 P .. 15 P and the images
+    of those entries under -phi (G1) / -psi, psi^2, -psi^3 (G2).  A SEL level picks an entry per table and window; the picked
+    entries are summed (one / two addition levels, beside the four doublings of the accumulator) and join the accumulator
+    with one addition: 33 (G1) / 17 (G2) windows instead of 64, the same two product levels per doubling.  The control flow
+    does not depend on the scalar.  Inputs: the affine point (buffer 0), the digit record (buffer 1).
     Output: the affine product and its Z (zero for the point at infinity)."""
+    import glv_model as GLV
     six = kind == "mul2"
     F = Fld2(b, T) if six else Fld1(b)
     C = Curve(F)
@@ -1010,16 +1018,29 @@ def build_mul_program(b, T, kind):
     tab = [(F.zero(), F.one(), F.zero()), P]
     for d in range(2, 16):
         tab.append(C.dbl(tab[d // 2]) if d % 2 == 0 else C.add(tab[d - 1], P))
+    tab = [tuple(F.lin(c) for c in q) for q in tab]
     flat = (lambda q: [q[0][0], q[0][1], q[1][0], q[1][1], q[2][0], q[2][1]]) if six else (lambda q: [q[0], q[1], q[2]])
     unflat = (lambda v: ((v[0], v[1]), (v[2], v[3]), (v[4], v[5]))) if six else (lambda v: (v[0], v[1], v[2]))
-    tid = b.table([flat(q) for q in tab])
+    if six:
+        t1 = [C.neg(psi_proj(F, q)) for q in tab]                                       # -psi
+        t2 = [psi_proj(F, psi_proj(F, q)) for q in tab]                                 # psi^2
+        t3 = [C.neg(psi_proj(F, q)) for q in t2]                                        # -psi^3
+        tables, nwin, stride = [tab, t1, t2, t3], GLV.G2_LAT_NWIN, 32                   # digit i: bits [128 i, 128 i + 68) = windows 32 i ..
+    else:
+        beta = F.const(g1_beta())
+        t1 = [(F.lin(F.mul(beta, q[0])), F.neg(q[1]), q[2]) for q in tab]               # -phi (X : Y : Z) = (beta X : -Y : Z)
+        tables, nwin, stride = [tab, t1], GLV.G1_LAT_NWIN, 64
+    tids = [b.table([flat(q) for q in t]) for t in tables]
     R = None
-    for w in range(63, -1, -1):
+    for w in range(nwin - 1, -1, -1):
         if R is not None:
             for _ in range(4):
                 R = C.dbl(R)
-        Sw = unflat(b.select(tid, w))
-        R = Sw if R is None else C.add(R, Sw)
+        S = [unflat(b.select(tid, i * stride + w)) for i, tid in enumerate(tids)]
+        U = C.add(S[0], S[1])
+        if six:
+            U = C.add(U, C.add(S[2], S[3]))
+        R = U if R is None else C.add(R, U)
     x, y = C.to_affine(R)
     outs = F.coords(x) + F.coords(y)
     b.out = ("outaff", outs + [b.lin(F.norm(R[2]), True)], len(outs))
@@ -1260,7 +1281,7 @@ def encode(p):
                 xs = [n.aux[0] | (n.aux[1] << 4)]; ys = []
             elif k == K_SEL:                                             # raw fields: slot of entry 0, window; stride
                 tid, j, w = n.aux
-                xs = [p.table_base[tid] + j, w]; ys = [p.table_ncoord[tid]]
+                xs = [p.table_base[tid] + j, w]; ys = [p.table_ncoord[tid], 63]   # 63: the last byte of the 64-byte digit record holds windows 0, 1
             assert len(xs) <= 7 and len(ys) <= 7
             ntx, nty = max(ntx, len(xs)), max(nty, len(ys))
             rows.append([n.slot] + xs + [NOTERM] * (7 - len(xs)) + ys + [NOTERM] * (7 - len(ys)) + [flags])

@@ -123,6 +123,19 @@ template <class F> struct glv_shape;
 template <> struct glv_shape<FpS> { using type = GlvG1; };
 template <> struct glv_shape<Fp2S> { using type = GlvG2; };
 
+// res += sign(d) * endo_S(tab[|d|]): one summand of one window.  Out of line so that the ladder's loop body is four calls, not four
+// inlined copies whose temporaries all compete for registers.
+BLSMI_DEV Jac<FpS> glv_endo0(const Jac<FpS>& p) { return p; }
+template <int S, class F>
+__device__ __noinline__ void glv_accumulate(Jac<F>& res, const Jac<F>* tab, i32 d) {
+    const i32 neg = d >> 31;                                                // all-ones for a negative digit
+    Jac<F> e = tab[(d ^ neg) - neg];
+    if constexpr (S == 1) e = glv_endo1(e);
+    if constexpr (S == 2) e = glv_endo2(e);
+    if constexpr (S == 3) e = glv_endo3(e);
+    e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
+    res = jac_add(res, e);
+}
 // [k] P for P in the subgroup: signed-window ladder over the sub-scalars, one shared table.  F = FpS (G1), Fp2S (G2, either layout).
 template <class F>
 __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
@@ -139,35 +152,11 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
     Jac<F> res = jac_zero<F>();
     for (int w = G::NWIN - 1; w >= 0; w--) {
         if (w != G::NWIN - 1) { res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); }
-        {
-            const i32 d = booth5(sub[0], w);
-            const i32 neg = d >> 31;                                        // all-ones for a negative digit
-            Jac<F> e = tab[(d ^ neg) - neg];
-            e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
-            res = jac_add(res, e);
-        }
-        {
-            const i32 d = booth5(sub[1], w);
-            const i32 neg = d >> 31;
-            Jac<F> e = glv_endo1(tab[(d ^ neg) - neg]);
-            e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
-            res = jac_add(res, e);
-        }
+        glv_accumulate<0>(res, tab, booth5(sub[0], w));
+        glv_accumulate<1>(res, tab, booth5(sub[1], w));
         if constexpr (G::NS == 4) {
-            {
-                const i32 d = booth5(sub[2], w);
-                const i32 neg = d >> 31;
-                Jac<F> e = glv_endo2(tab[(d ^ neg) - neg]);
-                e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
-                res = jac_add(res, e);
-            }
-            {
-                const i32 d = booth5(sub[3], w);
-                const i32 neg = d >> 31;
-                Jac<F> e = glv_endo3(tab[(d ^ neg) - neg]);
-                e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
-                res = jac_add(res, e);
-            }
+            glv_accumulate<2>(res, tab, booth5(sub[2], w));
+            glv_accumulate<3>(res, tab, booth5(sub[3], w));
         }
     }
     return res;

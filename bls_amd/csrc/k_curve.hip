@@ -101,8 +101,102 @@ __device__ void mul_glv_body(const u8* pts, size_t pt_stride, const u8* scalars,
     const Aff<F> a = jac_to_affine(glv_mul<F>(p, scalars + 32 * tt));
     if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
 }
+// The digit record the scalar-multiplication level programs read (gen_lat.py build_mul_program, glv_model.lat_record_g*): 64
+// big-endian bytes per scalar -- group 1: k1 | k2 << 256 with k = k1 + k2 z^2; group 2: sum d_i << 128 i with k = sum d_i z^i.
+KERNEL k_glv_recode(const u8* scalars, int group, u8* rec, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    u32 k[8];
+    scalar_words(scalars + 32 * t, k);
+    u32 w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = 0;
+    if (group == 1) {
+        u32 k2[5], k1[5];
+        udivmod_recip<8, 4, 7, 5>(k, C_GLV_Z2, C_GLV_MZ2, k2, k1);
+#pragma unroll
+        for (int i = 0; i < 5; i++) { w[i] = k1[i]; w[8 + i] = k2[i]; }
+    } else {
+        u32 q1[7], q2[5], q3[3], r[3];
+        udivmod_recip<8, 2, 9, 7>(k, C_GLV_Z, C_GLV_MZ, q1, r);
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[i] = r[i];
+        udivmod_recip<7, 2, 9, 5>(q1, C_GLV_Z, C_GLV_MZ, q2, r);
+#pragma unroll
+        for (int i = 0; i < 3; i++) w[4 + i] = r[i];
+        udivmod_recip<5, 2, 9, 3>(q2, C_GLV_Z, C_GLV_MZ, q3, r);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { w[8 + i] = r[i]; w[12 + i] = q3[i]; }
+    }
+    u32* o = reinterpret_cast<u32*>(rec + 64 * t);
+#pragma unroll
+    for (int i = 0; i < 16; i++) o[i] = __builtin_bswap32(w[15 - i]);
+}
 KERNEL2 k_g1_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
 KERNEL k_g2_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
+
+// ---- fixed-base multiplication of the group generators (PrivToPub, g2pubs/bls.go:138-140, g1pubs/bls.go:144-146) ------------------
+// [k] G = sum_w T[w][byte_w(k)] with T[w][d] = [d 256^w] G for d = 1 .. 255, w = 0 .. 31: thirty-two mixed additions and no
+// doubling at all (the windowed / endomorphism ladders spend 252 / 125 doublings).  The table is built once per device at start-up
+// by the scalar-multiplication kernel itself (blsmi.hip init_device) and kept as raw limbs: entry (w, d) at word ((w 255 + d - 1) E)
+// with E = 2 (G1) / 4 (G2) field elements of 15 words.  980 KB for G1, 1.9 MB for G2: resident in L2.
+constexpr int FIXED_WINDOWS = 32, FIXED_ENTRIES = 255;
+template <class F> BLSMI_DEV Aff<F> fixed_entry(const i32* table, int w, u32 d);
+BLSMI_DEV FpS raw_load(const i32* p) { FpS x; for (int j = 0; j < NL; j++) x.v[j] = p[j]; return x; }
+template <> BLSMI_DEV G1Aff fixed_entry<FpS>(const i32* table, int w, u32 d) {
+    const i32* e = table + ((size_t)w * FIXED_ENTRIES + (d ? d - 1 : 0)) * 2 * NL;
+    G1Aff a; a.x = raw_load(e); a.y = raw_load(e + NL); a.inf = d ? 0 : -1; return a;
+}
+template <> BLSMI_DEV G2Aff fixed_entry<Fp2S>(const i32* table, int w, u32 d) {
+    const i32* e = table + ((size_t)w * FIXED_ENTRIES + (d ? d - 1 : 0)) * 4 * NL;
+    G2Aff a; a.x.c0 = raw_load(e); a.x.c1 = raw_load(e + NL); a.y.c0 = raw_load(e + 2 * NL); a.y.c1 = raw_load(e + 3 * NL); a.inf = d ? 0 : -1; return a;
+}
+// affine wire records (what the multiplication kernel wrote) -> the raw-limb table
+KERNEL k_fixed_table_from_wire(const u8* wire, int elems, i32* table, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n * elems) return;
+    const FpS x = load_be48(wire + 48 * t);
+    for (int j = 0; j < NL; j++) table[t * NL + j] = x.v[j];
+}
+// throughput form: one scalar per lane
+template <class F, int PB>
+__device__ void mul_fixed_body(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;
+    const u8* s = scalars + 32 * tt;
+    Jac<F> res = jac_zero<F>();
+    for (int w = 0; w < FIXED_WINDOWS; w++) res = jac_add_affine(res, fixed_entry<F>(table, w, s[31 - w]));
+    const Aff<F> a = jac_to_affine(res);
+    if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
+}
+KERNEL2 k_g1_mul_fixed(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_fixed_body<FpS, 96>(table, scalars, out, out_inf, n); }
+KERNEL k_g2_mul_fixed(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_fixed_body<Fp2S, 192>(table, scalars, out, out_inf, n); }
+// latency form: one scalar per WAVE -- lane w fetches the entry of window w, the 32 points meet in a five-level tree of
+// additions across the lanes (a point travels by wave shuffles), lane 0 converts to affine: 5 dependent additions + one inversion
+// instead of 32 + one.
+template <class F> BLSMI_DEV Jac<F> jac_shfl_down(const Jac<F>& p, int off) {
+    Jac<F> r;
+    const i32* src = reinterpret_cast<const i32*>(&p);
+    i32* dst = reinterpret_cast<i32*>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(Jac<F>) / 4); i++) dst[i] = __shfl_down(src[i], off);
+    return r;
+}
+template <class F, int PB>
+__device__ void mul_fixed_wave_body(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+    const size_t t = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int w = lane & (FIXED_WINDOWS - 1);
+    Aff<F> e = fixed_entry<F>(table, w, scalars[32 * t + 31 - w]);
+    if (lane >= FIXED_WINDOWS) e.inf = -1;
+    Jac<F> acc = to_jac(e);
+#pragma unroll 1
+    for (int off = FIXED_WINDOWS / 2; off >= 1; off >>= 1) acc = jac_add(acc, jac_shfl_down(acc, off));
+    const Aff<F> a = jac_to_affine(acc);
+    if (lane == 0) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
+}
+KERNEL2 k_g1_mul_fixed_wave(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_fixed_wave_body<FpS, 96>(table, scalars, out, out_inf, n); }
+KERNEL k_g2_mul_fixed_wave(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_fixed_wave_body<Fp2S, 192>(table, scalars, out, out_inf, n); }
 
 // Point sums: level 0 reads affine bytes pairwise into Jacobian SoA; later levels halve the array.
 template <class F> struct jac_words { static constexpr int value = sizeof(F) / sizeof(FpS) * 3; };

@@ -182,13 +182,13 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             const FpS y = fp_inv(x);                                           // inverse(0) = 0
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] = y.v[i];
-        } else if (kind == K_SEL) {                                            // table entry picked by a 4-bit digit of the tuple's scalar (buffer 1, 32 big-endian bytes)
-            // raw fields: tx[0] = slot of entry 0, tx[1] = window (0 = least significant), ty[0] = slots per entry
+        } else if (kind == K_SEL) {                                            // table entry picked by a 4-bit digit of the tuple's digit record (buffer 1, big-endian bytes)
+            // raw fields: tx[0] = slot of entry 0, tx[1] = window (0 = least significant), ty[0] = slots per entry, ty[1] = index of the record's last byte
 #pragma unroll
             for (int i = 0; i < NL; i++) r[i] = 0;
             if (lane < njobs) {
                 const u32 w = tx[1];
-                const u32 digit = ((u32)(b1 + s1 * t)[31 - (w >> 1)] >> ((w & 1u) * 4u)) & 15u;
+                const u32 digit = ((u32)(b1 + s1 * t)[ty[1] - (w >> 1)] >> ((w & 1u) * 4u)) & 15u;
                 const int4* p = reinterpret_cast<const int4*>(S + (tx[0] + digit * ty[0]) * SLOT_WORDS);
                 const int4 a = p[0], b = p[1], d = p[2], e = p[3];
                 r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;

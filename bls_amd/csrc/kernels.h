@@ -63,8 +63,14 @@ __global__ void k_good_to_flag(const u8* good, i32* flag);
 __global__ void k_mul_finish(const u8* good, const u8* pts, size_t pt_stride, int rec_words, u8* out, u8* out_inf, size_t n);
 __global__ void k_g1_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g2_mul(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_glv_recode(const u8* scalars, int group, u8* rec, size_t n);
 __global__ void k_g1_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g2_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_fixed_table_from_wire(const u8* wire, int elems, i32* table, size_t n);
+__global__ void k_g1_mul_fixed(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g2_mul_fixed(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g1_mul_fixed_wave(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n);
+__global__ void k_g2_mul_fixed_wave(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
 __global__ void k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
 __global__ void k_g1_sum(const i32* src, i32* dst, size_t n, size_t half);

@@ -430,11 +430,12 @@ def test_sharded_verify_aggregate_single_process(eng):
                     return gather
                 # pass 1: record each rank's contributions; pass 2: replay with full gathers
                 contrib = []
-                import hashlib
+                fkey = (np.uint64(0x1234567890abcdef), np.uint64(0xfedcba0987654321))   # the nonce the ranks would have agreed on
+                bdist._FP_KEYS[world] = fkey
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
                     keys = np.frombuffer(bdist.message_keys(msgs[lo:hi]), dtype=np.uint8).reshape(-1, 33)
-                    dig = bdist.row_fingerprints(keys).tobytes() + b"\x00"          # fingerprints + status byte
+                    dig = bdist.row_fingerprints(keys, fkey).tobytes() + b"\x00"    # fingerprints + status byte
                     part = eng.aggregate_partial(group, msgs[lo:hi], b"".join(pk_list[lo:hi]))[0].tobytes() + b"\x00"
                     contrib.append((dig, part))
                 outs = []
@@ -444,6 +445,7 @@ def test_sharded_verify_aggregate_single_process(eng):
                     seq = iter([[c[0] for c in contrib], [b"\x00"] * world, [c[1] for c in contrib]])
                     outs.append(bdist.sharded_verify_aggregate(group, msgs[lo:hi], b"".join(pk_list[lo:hi]), agg, r, world, lambda b: next(seq)))
                 assert len(set(outs)) == 1
+                bdist._FP_KEYS.pop(world, None)
                 return outs[0]
             assert run(pks) is True
             assert run([pks[1], pks[0]] + pks[2:]) is False

@@ -175,14 +175,17 @@ def test_msm_final_programs():
 
 
 def test_scalar_multiplication_programs():
-    """[k] P with a run-time scalar: SEL levels index the table 0 P .. 15 P by the 4-bit digits of k (g1.go:80-90, g2.go MulFR)"""
+    """[k] P with a run-time scalar (g1.go:80-90, g2.go MulFR) through the endomorphisms: SEL levels index the tables 0 P .. 15 P and
+    their images under phi / psi by the 4-bit digits of the decomposed scalar"""
+    import glv_model as GLV
     xs = P.XORShift(41)
     Pa, Qa = _pt(xs)
     for kind, Fd, pt, six in (("mul1", P.F1, Pa, False), ("mul2", P.F2, Qa, True)):
         p = G.schedule(G.build_program(kind))
         inp = [pt[0][0], pt[0][1], pt[1][0], pt[1][1]] if six else [pt[0], pt[1]]
-        for k in (P.rand_fr(xs), 1, 0, P.R_ORDER - 1, (1 << 255) + 12345, P.R_ORDER):
-            out = G.simulate(p, {0: inp, "scalar": k})
+        for k in (P.rand_fr(xs), 1, 0, P.R_ORDER - 1, (1 << 255) + 12345, P.R_ORDER, (1 << 256) - 1, GLV.Z2, GLV.Z**3 + 5):
+            rec = (GLV.lat_record_g2 if six else GLV.lat_record_g1)(k)           # what k_glv_recode hands the program (glv_model.py)
+            out = G.simulate(p, {0: inp, "scalar": rec})
             want = P.jac_to_affine(Fd, P.affine_mul(Fd, pt, k)) if k % P.R_ORDER else None
             if want is None:
                 assert out[-1] == 0                                             # the point at infinity: Z = 0
