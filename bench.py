@@ -193,6 +193,7 @@ def roofline_of(prof, units, bytes_per_unit, ctr, grid_of=None):
     """roofline object of one leg: dominant kernel of `prof`, algorithmic bytes / its duration vs the HBM peak"""
     if not prof:
         return None
+    prof = {k: v for k, v in prof.items() if not k.startswith("(")} or prof     # "(between)": gaps between the marked kernels
     dom = max(prof, key=lambda k: prof[k][0])
     ms, launches = prof[dom]
     per_launch_ms = ms / max(1, launches)
@@ -203,7 +204,7 @@ def roofline_of(prof, units, bytes_per_unit, ctr, grid_of=None):
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8),
             "traffic": traffic, "algorithmic_bytes_per_launch": algo, "bytes_per_unit": bytes_per_unit, "units_per_launch": units,
             "kernel_ms": round(per_launch_ms, 4), "kernel_launches": launches,
-            "all_kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:8]},
+            "all_kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:10]},
             "rocprof_avg_ms": round(c["avg_ns"] / 1e6, 4) if "avg_ns" in c else None}
 
 

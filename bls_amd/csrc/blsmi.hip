@@ -61,8 +61,40 @@ struct Workspace {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
+// Temporaries of one call: a bump allocator over a grow-only block of device memory that belongs to the call context.  Every entry
+// point used to take its temporaries from the stream-ordered pool (hipMallocAsync / hipFreeAsync); a dozen such pairs cost a
+// 2^20-point MSM 2.5 ms of its 14.6 and every small call ~0.1 ms.  A context serves one call at a time and the entry points are
+// blocking, so "free" is resetting the offset when the next call leases the context.  A request that does not fit is served by an
+// overflow block; the next reset merges everything into one block of the peak size (steady state: no allocation at all).
+struct Arena {
+    struct Block { char* p; size_t cap; };
+    std::vector<Block> blocks;
+    size_t used = 0, overflow = 0;
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (!blocks.empty() && used + bytes <= blocks[0].cap) { void* r = blocks[0].p + used; used += bytes; return r; }
+        void* q = nullptr;
+        const size_t want = blocks.empty() ? std::max(bytes, (size_t)1 << 20) : bytes;
+        if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        blocks.push_back({(char*)q, want});
+        if (blocks.size() == 1) { used = bytes; return q; }
+        overflow += want;
+        return q;
+    }
+    void reset() {                                                         // caller: the context's previous call has completed
+        if (overflow) {
+            const size_t total = blocks[0].cap + overflow + (overflow >> 2);
+            release();
+            void* q = nullptr;
+            if (hipMalloc(&q, total) == hipSuccess) blocks.push_back({(char*)q, total}); else (void)hipGetLastError();
+        }
+        used = 0; overflow = 0;
+    }
+    void release() { for (auto& b : blocks) (void)hipFree(b.p); blocks.clear(); used = 0; overflow = 0; }
+};
 struct Device;
 struct Ctx {
+    Arena arena;
     hipStream_t stream = nullptr;
     Workspace ws;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -249,9 +281,10 @@ inline void prof_collect(Ctx& c) {
     if (c.pused < 2) { c.pused = 0; return; }
     (void)hipEventSynchronize(c.pev[c.pused - 1]);
     for (size_t i = 0; i + 1 < c.pused; i++) {
-        if (!c.pname[i]) continue;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c.pev[i], c.pev[i + 1]) == hipSuccess) tl_prof.emplace_back(c.pname[i], ms);
+        // an unnamed segment is the time between the end of one marked kernel and the start of the next: small kernels, copies,
+        // allocation and host work the stream waited for -- reported as "(between)" so that the marks add up to the call
+        if (hipEventElapsedTime(&ms, c.pev[i], c.pev[i + 1]) == hipSuccess) tl_prof.emplace_back(c.pname[i] ? c.pname[i] : "(between)", ms);
     }
     if (tl_prof.size() > 16384) tl_prof.erase(tl_prof.begin(), tl_prof.begin() + 8192);   // nobody is reading: keep the newest
     c.pused = 0;
@@ -285,6 +318,7 @@ struct CtxLease {
         if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = BLSMI_E_HIP; return; }
         c->busy = true; c->dev->leased++;
         c->pused = 0;
+        c->arena.reset();                                                   // the temporaries of the context's previous call
         outer = tl_ctx;
         tl_ctx = mine = c;
     }
@@ -312,13 +346,10 @@ int device_index_of_pointer(const void* p) {
     return device_index_of_ordinal(a.device);
 }
 
-// RAII device temporary from the stream-ordered pool of the leased context's stream
+// Device temporary of the current call, from the leased context's arena (released when the context is leased again)
 struct DBuf {
     void* p = nullptr;
-    hipStream_t s = nullptr;
-    // st: the stream whose work uses the buffer (allocation and release are ordered on it); default: the lease's stream
-    hipError_t alloc(size_t bytes, hipStream_t st = nullptr) { s = st ? st : g_stream; return hipMallocAsync(&p, bytes ? bytes : 1, s); }
-    ~DBuf() { if (p) (void)hipFreeAsync(p, s); }
+    hipError_t alloc(size_t bytes, hipStream_t = nullptr) { p = tl_ctx->arena.alloc(bytes ? bytes : 1); return p ? hipSuccess : hipErrorOutOfMemory; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -404,6 +435,7 @@ BLSMI_API void blsmi_shutdown(void) {
             if (!c.stream) continue;
             (void)hipStreamSynchronize(c.stream);
             c.ws.release();
+            c.arena.release();
             for (auto& e : c.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
             for (auto& e : c.pev) (void)hipEventDestroy(e);
             c.pev.clear(); c.pname.clear(); c.pused = 0;
@@ -851,28 +883,90 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
         std::swap(src, dst);
         seg = half;
     }
-    // Horner over the windows (240 dependent doublings) and ToAffine: one wave as a level program of the latency path
-    // (k_lat.hip: msmfin1 / msmfin2, two product levels per doubling) instead of one lane (k.final: 3 / 8 ms)
+    // Horner over the 16 windows (240 dependent doublings) and ToAffine on one lane: this is the path for ARBITRARY curve points
+    // (blsmi_set_mul_assume_subgroup(0)); the default path (msm_bucket_glv_dev) has a level program for its shorter tail
     static_assert(W == 3 || W == 6, "G1 / G2");
-    if (g_lat_max > 0 && c == 16 && nwin == 16) {                          // (the latency path switched off: the one-lane kernel below)
+    prof_mark(W == 6 ? "k_g2_msm_final" : "k_g1_msm_final");
+    hipLaunchKernelGGL(k.final, dim3(1), dim3(WG), 0, s, (const i32*)src, nwin, c, d_out, d_flag);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));                                       // temporaries die with this scope
+    return BLSMI_OK;
+}
+// The bucket method for points of the prime-order subgroup (msm.inc, second half): scalars decomposed through the endomorphisms
+// (G1: 8 bucket-windows fed by 2 n items, G2: 4 fed by 4 n), points converted to raw limbs once.  Same result as msm_bucket_dev.
+template <int PB, int W>
+static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s) {
+    constexpr int c = 16;
+    static const int K = []{ const char* v = getenv("BLSMI_MSM_CHUNK"); const int k = v ? atoi(v) : 8; return (k >= 2 && k <= 64 && !(k & (k - 1))) ? k : 8; }();   // buckets per chunk lane
+    constexpr int nbw = W == 3 ? 8 : 4, sh = W == 3 ? 3 : 2, NS = 16 / nbw;
+    constexpr size_t RAWW = W == 3 ? 48 : 244;
+    const size_t B1 = (size_t)1 << c, nb = B1 * nbw, per_win_chunks = B1 / K, nct = per_win_chunks * nbw, per_win_items = (size_t)NS * n;
+    const size_t jw = (size_t)W * NL + 1;
+    if (n >= ((size_t)1 << 30)) return BLSMI_E_ARG;                         // the item word keeps the stream in bits 30-31
+    DBuf raw, rec, hist, offs, cursor, idx, buckets, ch0, ch1, dmax, cls, perm;
+    HIPCHK(raw.alloc(sizeof(i32) * RAWW * n, s)); HIPCHK(rec.alloc(32 * n, s));
+    HIPCHK(hist.alloc(sizeof(u32) * nb, s)); HIPCHK(offs.alloc(sizeof(u32) * nb, s)); HIPCHK(cursor.alloc(sizeof(u32) * nb, s)); HIPCHK(dmax.alloc(sizeof(u32), s));
+    HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s)); HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
+    HIPCHK(ch0.alloc(sizeof(i32) * jw * nct, s)); HIPCHK(ch1.alloc(sizeof(i32) * jw * ((per_win_chunks + 1) / 2) * nbw, s));
+    HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
+    HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
+    HIPCHK(hipMemsetAsync(dmax.p, 0, sizeof(u32), s));
+    HIPCHK(hipMemsetAsync(cls.p, 0, sizeof(u32) * 256, s));
+    prof_mark(W == 3 ? "k_msm_prep_g1" : "k_msm_prep_g2");
+    if (W == 3) hipLaunchKernelGGL(k_msm_prep_g1, dim3(nblocks(n)), dim3(WG), 0, s, d_pts, d_scalars, raw.as<i32>(), rec.as<u8>(), n);
+    else hipLaunchKernelGGL(k_msm_prep_g2, dim3(nblocks(n)), dim3(WG), 0, s, d_pts, d_scalars, raw.as<i32>(), rec.as<u8>(), n);
+    prof_mark("k_msm_hist_glv");
+    hipLaunchKernelGGL(k_msm_hist_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, hist.as<u32>());
+    prof_mark("k_msm_max");
+    hipLaunchKernelGGL(k_msm_max, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, dmax.as<u32>());
+    u32 biggest = 0;
+    HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
+    prof_mark("k_msm_scan");
+    hipLaunchKernelGGL(k_msm_scan, dim3(nbw), dim3(256), 0, s, (const u32*)hist.as<u32>(), offs.as<u32>(), cursor.as<u32>(), c);
+    prof_mark("k_msm_scatter_glv");
+    hipLaunchKernelGGL(k_msm_scatter_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, sh, cursor.as<u32>(), idx.as<u32>());
+    prof_mark("k_msm_class_*");
+    const unsigned cb = (unsigned)((nb + 255) / 256);
+    hipLaunchKernelGGL(k_msm_class_hist, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, cls.as<u32>());
+    hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(256), 0, s, (const u32*)cls.as<u32>(), cls.as<u32>() + 256, cls.as<u32>() + 512);
+    hipLaunchKernelGGL(k_msm_class_scatter, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, (const u32*)(cls.as<u32>() + 256), cls.as<u32>() + 512, perm.as<u32>());
+    prof_mark(nullptr);
+    // the digit passes above do not depend on the verdict: the host learns it while they run.  Skewed scalars (a bucket beyond
+    // 2048 items would be one lane's serial work) fall back to the per-point multiples, whose cost does not depend on the scalars.
+    HIPCHK(hipStreamSynchronize(s));
+    if (biggest > 2048) return BLSMI_E_SKEW;
+    prof_mark(W == 3 ? "k_g1_msm_bucket_raw" : "k_g2_msm_bucket_raw_pair");
+    if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
+    else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
+    prof_mark(W == 6 ? "k_g2_msm_chunk" : "k_g1_msm_chunk");
+    hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    prof_mark(W == 6 ? "k_g2_msm_fold" : "k_g1_msm_fold");
+    i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
+    size_t seg = per_win_chunks;
+    while (seg > 1) {
+        const size_t half = (seg + 1) / 2;
+        hipLaunchKernelGGL(k.fold, dim3(nblocks(half * nbw)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nbw);
+        std::swap(src, dst);
+        seg = half;
+    }
+    if (g_lat_max > 0) {                                                   // Horner over the 8 / 4 windows + ToAffine: one wave (k_lat.hip: msmfin1 / msmfin2)
         const size_t prog = W == 3 ? LAT_MSMFIN1_OFFSET : LAT_MSMFIN2_OFFSET;
         DBuf good; HIPCHK(good.alloc(1, s));
         prof_mark(W == 3 ? "k_lat:msmfin1" : "k_lat:msmfin2");
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, (const u8*)nullptr, (size_t)0,
-                           (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)nwin,
+                           (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)nbw,
                            (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), (size_t)1);
+        hipLaunchKernelGGL(k_good_to_flag, dim3(1), dim3(WG), 0, s, (const u8*)good.as<u8>(), d_flag);
         prof_mark(nullptr);
         HIPCHK(hipGetLastError());
-        u8 good_h = 0;
-        HIPCHK(hipMemcpyAsync(&good_h, good.p, 1, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(hipMemsetAsync(d_flag, good_h ? 0 : 1, sizeof(i32), s));    // nonzero = the sum is the point at infinity (record all zero)
         HIPCHK(hipStreamSynchronize(s));
         return BLSMI_OK;
     }
-    hipLaunchKernelGGL(k.final, dim3(1), dim3(WG), 0, s, (const i32*)src, nwin, c, d_out, d_flag);
+    prof_mark(W == 6 ? "k_g2_msm_final" : "k_g1_msm_final");
+    hipLaunchKernelGGL(k.final, dim3(1), dim3(WG), 0, s, (const i32*)src, nbw, c, d_out, d_flag);
+    prof_mark(nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));                                       // temporaries die with this scope
+    HIPCHK(hipStreamSynchronize(s));
     return BLSMI_OK;
 }
 // sum_i k_i P_i with everything resident on the leased device: bucket method from bucket_min points on (unless the digits
@@ -881,7 +975,8 @@ template <int PB, int W, class KM, class K0, class K1, class K2>
 static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s) {
     static const size_t bucket_min = []{ const char* v = getenv("BLSMI_MSM_BUCKET_MIN"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1 << 17; }();
     int rc = BLSMI_E_SKEW;
-    if (n >= bucket_min) rc = msm_bucket_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s);
+    if (n >= bucket_min) rc = g_mul_subgroup.load(std::memory_order_relaxed) ? msm_bucket_glv_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s)
+                                                                           : msm_bucket_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s);
     if (rc != BLSMI_E_SKEW) return rc;
     DBuf dm, dinf;
     HIPCHK(dm.alloc((size_t)PB * n, s)); HIPCHK(dinf.alloc(n, s));

@@ -869,7 +869,8 @@ def build_program(kind):
     if kind in ("subgrp1", "subgrp2"):
         return build_subgroup_program(b, pr.T, kind)
     if kind in ("msmfin1", "msmfin2"):
-        return build_msm_final_program(b, pr.T, kind)
+        # the endomorphism MSM (msm.inc): 8 windows of 16 bits for G1 (two 128-bit halves), 4 for G2 (four 64-bit digits)
+        return build_msm_final_program(b, pr.T, kind, nwin=8 if kind == "msmfin1" else 4)
     if kind in ("mul1", "mul2"):
         return build_mul_program(b, pr.T, kind)
     if kind in ("sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):

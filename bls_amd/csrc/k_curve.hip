@@ -321,3 +321,26 @@ __global__ void __launch_bounds__(WG, 2) k_g2_mul_glv_pair(const u8* pts, size_t
     const P2::G2AffP a = jac_to_affine(glv_mul<P2::Fp2S>(p, scalars + 32 * tt));
     if (t < n) { pair_store_g2(out + (size_t)192 * t, par, a); if (!par) out_inf[t] = a.inf ? 1 : 0; }
 }
+// G2 bucket accumulation over the raw-limb items of the endomorphism MSM (msm.inc): a lane pair per bucket, lane `par` loads its
+// own coefficient of the item's variant (P, -psi P, psi^2 P, -psi^3 P).
+BLSMI_DEV P2::G2AffP raw_item_g2_pair(const i32* raw, u32 item, int par) {
+    const i32* o = raw + (size_t)RAW2_WORDS * (item & 0x3fffffffu) + (size_t)(item >> 30) * 4 * NL + par * NL;
+    P2::G2AffP a;
+    a.x = P2::wrap(raw_load(o)); a.y = P2::wrap(raw_load(o + 2 * NL));
+    a.inf = raw[(size_t)RAW2_WORDS * (item & 0x3fffffffu) + 240];
+    return a;
+}
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_raw_pair(const i32* raw, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t per_win, size_t nb) {
+    const int par = threadIdx.x & 1;
+    const size_t j = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t jj = j < nb ? j : nb - 1;
+    const size_t t = perm[jj];
+    const u32 cnt = j < nb ? hist[t] : 0;
+    const u32* slice = idx + (t >> 16) * per_win + offs[t];
+    P2::G2JacP acc = jac_zero<P2::Fp2S>();
+    for (u32 k = 0; k < cnt; k++) acc = jac_add_affine(acc, raw_item_g2_pair(raw, slice[k], par));
+    if (j < nb) {
+        soa_store(buckets, nb, t, 0 + par, acc.x.c); soa_store(buckets, nb, t, 2 + par, acc.y.c); soa_store(buckets, nb, t, 4 + par, acc.z.c);
+        if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
+    }
+}

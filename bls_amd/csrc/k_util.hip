@@ -61,25 +61,23 @@ __global__ void __launch_bounds__(256) k_dup_in_runs(const u64* fp, const u32* i
 
 namespace blsmi_util {
 // *d_flag (device int, cleared by the caller or here) becomes nonzero when a message is empty or occurs twice.
-// Enqueues on s; temporaries come from the stream-ordered pool and are released on s.  Returns a hipError_t as int.
-int dup_check_async(const void* d_msgs, const void* d_off, size_t n, uint64_t key0, uint64_t key1, int* d_flag, hipStream_t s) {
+// Enqueues on s; temporaries (20 n bytes + the sort's scratch) come from the caller's allocator and must live until s has run them.
+// Returns a hipError_t as int.
+int dup_check_async(const void* d_msgs, const void* d_off, size_t n, uint64_t key0, uint64_t key1, int* d_flag, hipStream_t s,
+                    const std::function<void*(size_t)>& scratch) {
     hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), s);
     if (e != hipSuccess || n == 0) return (int)e;
     if (n >= 0x7fffffffull) { const int one = 1; return (int)hipMemcpyAsync(d_flag, &one, sizeof one, hipMemcpyHostToDevice, s); }   // not representable: reject
-    u64 *fp0 = nullptr, *fp1 = nullptr; u32 *ix0 = nullptr, *ix1 = nullptr; void* tmp = nullptr;
     size_t tmp_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, fp0, fp1, ix0, ix1, (int)n, 0, 64, s);
-    auto fail = [&](hipError_t err) { for (void* p : {(void*)fp0, (void*)fp1, (void*)ix0, (void*)ix1, tmp}) if (p) (void)hipFreeAsync(p, s); return (int)err; };
-    if ((e = hipMallocAsync((void**)&fp0, 8 * n, s)) != hipSuccess) return fail(e);
-    if ((e = hipMallocAsync((void**)&fp1, 8 * n, s)) != hipSuccess) return fail(e);
-    if ((e = hipMallocAsync((void**)&ix0, 4 * n, s)) != hipSuccess) return fail(e);
-    if ((e = hipMallocAsync((void**)&ix1, 4 * n, s)) != hipSuccess) return fail(e);
-    if ((e = hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 1, s)) != hipSuccess) return fail(e);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const u64*)nullptr, (u64*)nullptr, (const u32*)nullptr, (u32*)nullptr, (int)n, 0, 64, s);
+    u64* fp0 = (u64*)scratch(8 * n); u64* fp1 = (u64*)scratch(8 * n);
+    u32* ix0 = (u32*)scratch(4 * n); u32* ix1 = (u32*)scratch(4 * n);
+    void* tmp = scratch(tmp_bytes ? tmp_bytes : 1);
+    if (!fp0 || !fp1 || !ix0 || !ix1 || !tmp) return (int)hipErrorOutOfMemory;
     const unsigned blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_msg_fingerprint, dim3(blocks), dim3(256), 0, s, (const u8*)d_msgs, (const u64*)d_off, n, (u64)key0, (u64)key1, fp0, ix0, d_flag);
-    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, fp0, fp1, ix0, ix1, (int)n, 0, 64, s)) != hipSuccess) return fail(e);
+    if ((e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, fp0, fp1, ix0, ix1, (int)n, 0, 64, s)) != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_dup_in_runs, dim3(blocks), dim3(256), 0, s, (const u64*)fp1, (const u32*)ix1, (const u8*)d_msgs, (const u64*)d_off, n, d_flag);
-    e = hipGetLastError();
-    return fail(e);                                                        // releases the temporaries (stream-ordered) either way
+    return (int)hipGetLastError();
 }
 }  // namespace blsmi_util
