@@ -12,8 +12,8 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 # translation units of libblsmi.so: the host side + one unit per kernel family, compiled in parallel
-_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_pairing_single.hip", "k_hash.hip", "k_curve.hip", "k_lat.hip", "k_util.hip"]
-LAT_BIN = os.path.join(CSRC, "lat_programs.bin")          # level programs of the latency path (gen_lat.py), embedded into blsmi.hip.o
+_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_hash.hip", "k_curve.hip", "k_lat.hip", "k_util.hip"]
+LAT_BIN = os.path.join(CSRC, "lat_programs.z")            # level programs of the latency path (gen_lat.py), zlib-compressed, embedded into blsmi.hip.o
 BUILD_DIR = os.path.join(CSRC, "build")
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
 
@@ -86,7 +86,7 @@ def build(force=False, verbose=False):
     failed = [u for u, p in procs if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", SO_PATH] + [os.path.join(BUILD_DIR, u + ".o") for u in _UNITS]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", SO_PATH] + [os.path.join(BUILD_DIR, u + ".o") for u in _UNITS] + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -25,11 +25,24 @@
 #include <thread>
 #include <random>
 
-// The level programs of the latency path (gen_lat.py -> lat_programs.bin), embedded in the host object.
+// The level programs of the latency path (gen_lat.py -> lat_programs.bin, 19 MB of 32-byte job descriptors), embedded in the host
+// object zlib-compressed (lat_programs.z, 1.3 MB) and inflated once when the library initialises.
 #if !defined(__HIP_DEVICE_COMPILE__)
-__asm__(".section .rodata\n.balign 256\n.global blsmi_lat_blob\n.hidden blsmi_lat_blob\nblsmi_lat_blob:\n.incbin \"" BLSMI_LAT_BIN "\"\n.previous\n");
+__asm__(".section .rodata\n.balign 256\n.global blsmi_lat_z\n.hidden blsmi_lat_z\nblsmi_lat_z:\n.incbin \"" BLSMI_LAT_BIN "\"\n.global blsmi_lat_z_end\n.hidden blsmi_lat_z_end\nblsmi_lat_z_end:\n.previous\n");
 #endif
-extern "C" const unsigned char blsmi_lat_blob[];
+extern "C" const unsigned char blsmi_lat_z[];
+extern "C" const unsigned char blsmi_lat_z_end[];
+#include <zlib.h>
+static std::vector<unsigned char> g_lat_host;                             // the inflated programs (host copy: program headers are read from it)
+#define blsmi_lat_blob (g_lat_host.data())
+static int inflate_programs() {                                           // caller holds g_mu
+    if (!g_lat_host.empty()) return 0;
+    std::vector<unsigned char> out(LAT_TOTAL_BYTES);
+    uLongf n = LAT_TOTAL_BYTES;
+    if (uncompress(out.data(), &n, blsmi_lat_z, (uLong)(blsmi_lat_z_end - blsmi_lat_z)) != Z_OK || n != LAT_TOTAL_BYTES) return -1;
+    g_lat_host.swap(out);
+    return 0;
+}
 
 namespace {
 // Host state.  The library drives a LIST of devices from one process (blsmi_init_devices; blsmi_init binds a single one).
@@ -186,6 +199,7 @@ int init_device(Device& d) {            // caller holds g_mu
         HIPCHK(hipMalloc((void**)&d.gens.lines, sizeof(i32) * 68 * 3 * 2 * NL));
         hipLaunchKernelGGL(k_prepare_generator_lines, dim3(1), dim3(WG), 0, nullptr, (const u8*)d.gens.g2, d.gens.lines);
         HIPCHK(hipGetLastError());
+        if (inflate_programs()) { fprintf(stderr, "blsmi: the embedded level programs do not inflate\n"); return BLSMI_E_ARG; }
         HIPCHK(hipMalloc((void**)&d.gens.lat, LAT_TOTAL_BYTES));
         HIPCHK(hipMemcpy(d.gens.lat, blsmi_lat_blob, LAT_TOTAL_BYTES, hipMemcpyHostToDevice));
         // fixed-base tables of the generators (PrivToPub): [d 256^w] G for d = 1 .. 255, w = 0 .. 31, computed by the

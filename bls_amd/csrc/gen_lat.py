@@ -1332,6 +1332,8 @@ def main():
             out += b"\0"
         print(name, stats(p), "bytes=%d" % len(blob))
     (here / "lat_programs.bin").write_bytes(bytes(out))
+    import zlib
+    (here / "lat_programs.z").write_bytes(zlib.compress(bytes(out), 9))    # what libblsmi.so embeds (inflated once at start-up): 19 MB -> 1.3 MB
     with open(here / "lat_programs.h", "w") as f:
         f.write("// Generated by gen_lat.py -- offsets of the latency-path programs inside lat_programs.bin\n#pragma once\n")
         for name, off, ln in index:

@@ -8,18 +8,19 @@ constexpr int PT = WG / 2;          // tuples per workgroup of the lane-pair ker
 // k_pairing_single.hip
 __global__ void k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_miller1h(const u8* g1, const u8* g2, i32* fbuf, size_t n);
-__global__ void k_final_exp(const i32* fbuf, u64* out, size_t n, int mode);
-__global__ void k_fq12_from_m384(const u64* in, i32* fbuf, size_t n);
 __global__ void k_prepare_generator_lines(const u8* g2, i32* table);
 __global__ void k_miller2(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
+__global__ void k_debug_prepare_single(const u8* g2, i32* table);
+__global__ void k_debug_lines_to_m384(const i32* table, u64* out);
+// k_fe_single.hip
+__global__ void k_final_exp(const i32* fbuf, u64* out, size_t n, int mode);
+__global__ void k_fq12_from_m384(const u64* in, i32* fbuf, size_t n);
 __global__ void k_final_exp_is_one(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
 __global__ void k_fq12_prod_level(const i32* src, i32* dst, size_t n, size_t half);
 __global__ void k_fq12_aos_to_soa(const i32* aos, i32* soa, size_t n);
 __global__ void k_fq12_one(i32* f);
 __global__ void k_final_exp_equal(const i32* a, const i32* b, i32* ok);
 __global__ void k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_t n);
-__global__ void k_debug_prepare_single(const u8* g2, i32* table);
-__global__ void k_debug_lines_to_m384(const i32* table, u64* out);
 // k_pairing_pair.hip
 __global__ void k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_debug_prepare_pair(const u8* g2, i32* table);
