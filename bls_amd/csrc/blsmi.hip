@@ -227,7 +227,8 @@ int init_device(Device& d) {            // caller holds g_mu
 // Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
 // (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
 std::atomic<bool> g_mul_subgroup{true}; // scalar multiplication through the endomorphisms (multiplicands in the subgroup); BLSMI_MUL_GENERIC=1 / blsmi_set_mul_assume_subgroup(0): plain ladder
-std::atomic<size_t> g_lat_max{4096};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely)
+std::atomic<size_t> g_lat_max{8192};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely).  The two paths meet at ~10 000 tuples
+                                        // for pairings and verifies alike (tools/crossover.py: 8192 pairings 8.4 ms against 10.7, 16 384: 16.4 against 11.3)
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {

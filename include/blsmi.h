@@ -69,7 +69,7 @@ int blsmi_pairing_batch_dev(const void *d_g1_aff, const void *d_g2_aff, void *d_
 int blsmi_set_profiling(int on);
 /* Latency path: pairing / verify batches of at most `max_tuples` tuples run ONE TUPLE PER WAVE (the pairing spread over
  * 64 lanes, field elements staged in LDS) instead of one per lane pair: ~10x lower latency for the one-tuple-per-call
- * Go API (g2pubs/bls.go:159-162), same results.  Default 4096 (environment BLSMI_LAT_MAX); 0 switches it off. */
+ * Go API (g2pubs/bls.go:159-162), same results.  Default 8192 (environment BLSMI_LAT_MAX) -- the two paths cross at ~10 000 tuples --; 0 switches it off. */
 int blsmi_set_latency_threshold(size_t max_tuples);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
 /* General form: with profiling on, every entry point records HIP events on its launch stream between its major kernels.  This

@@ -15,9 +15,9 @@ def eng(request):
     default for <= 4096 tuples) and through the throughput kernels (one tuple per lane pair)."""
     from bls_amd import engine
     engine.init(0)
-    engine.set_latency_threshold(4096 if request.param == "latency-path" else 0)
+    engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
     yield engine
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
 
 
 def test_pairing_generator_kat(eng, kats):

@@ -31,9 +31,9 @@ def eng(request):
     default for <= 4096 tuples) and through the throughput kernels (one tuple per lane pair)."""
     from bls_amd import engine
     engine.init(0)
-    engine.set_latency_threshold(4096 if request.param == "latency-path" else 0)
+    engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
     yield engine
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
 
 
 def _g2pubs_tuples(n, seed, every):
@@ -371,7 +371,7 @@ def test_latency_and_throughput_paths_agree_on_4096_tuples():
     g1b, _ = engine.g1_mul_batch(RC.g1_generator() * base, k1, base); g2b, _ = engine.g2_mul_batch(RC.g2_generator() * base, k2, base)
     g1 = np.tile(g1b, (n // base, 1)); g2 = np.concatenate([np.roll(g2b, -r, axis=0) for r in range(n // base)])
     try:
-        engine.set_latency_threshold(4096)
+        engine.set_latency_threshold(8192)
         a = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
         engine.set_latency_threshold(0)
         b = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
@@ -385,13 +385,13 @@ def test_latency_and_throughput_paths_agree_on_4096_tuples():
         sigs, _ = engine.g1_mul_batch(h.reshape(-1), b"".join(sks[i % base] for i in range(n)), n)
         allpk = np.stack([pks[(i + (1 if i % 7 == 6 else 0)) % base] for i in range(n)])
         expect = [i % 7 != 6 for i in range(n)]
-        engine.set_latency_threshold(4096)
+        engine.set_latency_threshold(8192)
         ok_lat, _ = engine.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
         engine.set_latency_threshold(0)
         ok_thr, _ = engine.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
         assert list(ok_lat) == expect and list(ok_thr) == expect
     finally:
-        engine.set_latency_threshold(4096)
+        engine.set_latency_threshold(8192)
 
 
 # ---- in-library multi-device split -----------------------------------------------------------------------------------------

@@ -31,9 +31,9 @@ Q = P.Q
 def eng(request):
     from bls_amd import engine
     engine.init(0)
-    engine.set_latency_threshold(4096 if request.param == "latency-path" else 0)
+    engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
     yield engine
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
 
 
 def _dev(x):
@@ -344,7 +344,7 @@ def test_soak_slice_latency_programs_against_throughput_kernels():
             assert np.array_equal(outs[0][i], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]), i
         msgs = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in rng.integers(0, 200, size=1500)]
         for fn, ref in ((engine.hash_g1_batch, RC.hash_g1), (engine.hash_g2_batch, RC.hash_g2)):
-            engine.set_latency_threshold(4096); x = fn(msgs)
+            engine.set_latency_threshold(8192); x = fn(msgs)
             engine.set_latency_threshold(0); y = fn(msgs)
             assert np.array_equal(x, y)
             for i in rng.integers(0, len(msgs), size=12):
@@ -352,7 +352,7 @@ def test_soak_slice_latency_programs_against_throughput_kernels():
         m = 1500
         k = scal(m); k[::7, :20] = 0; k[::11] = 0
         for mul, pts, ref in ((engine.g1_mul_batch, g1[:m], RC.g1_mul), (engine.g2_mul_batch, g2[:m], RC.g2_mul)):
-            engine.set_latency_threshold(4096); x, ix = mul(pts.reshape(-1), k.reshape(-1), m)
+            engine.set_latency_threshold(8192); x, ix = mul(pts.reshape(-1), k.reshape(-1), m)
             engine.set_latency_threshold(0); y, iy = mul(pts.reshape(-1), k.reshape(-1), m)
             assert np.array_equal(x, y) and np.array_equal(ix, iy)
             assert ix[::11].all()
@@ -377,7 +377,7 @@ def test_soak_slice_latency_programs_against_throughput_kernels():
         for i in (0, 4, 5, 9, nv - 1):
             assert RC.g2pubs.verify(vm[i], pks[i].tobytes(), sg[i].tobytes()) == bool(expect[i])
     finally:
-        engine.set_latency_threshold(4096)
+        engine.set_latency_threshold(8192)
 
 
 # ---- every shard size the 8-GPU run will see, on this one GPU (item 2) --------------------------------------------

@@ -26,15 +26,15 @@ print("pairing soak ok: %d tuples on both paths, %d oracle samples (%.1f s)" % (
 # hashes, both packages, odd lengths, both the one-lane and the two-lane kernels
 msgs = [bytes(rng.integers(0, 256, size=int(l), dtype=np.uint8)) for l in rng.integers(0, 200, size=3000)]
 for name, fn, ref in (("g1", engine.hash_g1_batch, RC.hash_g1), ("g2", engine.hash_g2_batch, RC.hash_g2)):
-    engine.set_latency_threshold(4096); a = fn(msgs[:2000])
+    engine.set_latency_threshold(8192); a = fn(msgs[:2000])
     engine.set_latency_threshold(0); b = fn(msgs[:2000])
     assert np.array_equal(a, b), name
     for i in rng.integers(0, 2000, size=60):
         assert a[i].tobytes() == ref(msgs[i]), (name, i)
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
 dom = bytes(rng.integers(0, 256, size=8, dtype=np.uint8))
 m32 = [bytes(rng.integers(0, 256, size=32, dtype=np.uint8)) for _ in range(600)]
-a = engine.hash_g2_with_domain_batch(m32, dom); engine.set_latency_threshold(0); b = engine.hash_g2_with_domain_batch(m32, dom); engine.set_latency_threshold(4096)
+a = engine.hash_g2_with_domain_batch(m32, dom); engine.set_latency_threshold(0); b = engine.hash_g2_with_domain_batch(m32, dom); engine.set_latency_threshold(8192)
 assert np.array_equal(a, b)
 for i in rng.integers(0, 600, size=25):
     assert a[i].tobytes() == RC.hash_g2_with_domain(m32[i], dom), i
@@ -43,9 +43,9 @@ print("hash soak ok")
 m = 3000
 k = scal(m); k[::7, :20] = 0; k[::11] = 0
 for name, mul, pts, ref in (("g1", engine.g1_mul_batch, g1[:m], RC.g1_mul), ("g2", engine.g2_mul_batch, g2[:m], RC.g2_mul)):
-    engine.set_latency_threshold(4096); a, ia = mul(pts.reshape(-1), k.reshape(-1), m)
+    engine.set_latency_threshold(8192); a, ia = mul(pts.reshape(-1), k.reshape(-1), m)
     engine.set_latency_threshold(0); b, ib = mul(pts.reshape(-1), k.reshape(-1), m)
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
     assert np.array_equal(a, b) and np.array_equal(ia, ib), name
     assert ia[::11].all() and not ia[1::11][:50].any()
     for i in rng.integers(0, m, size=40):
@@ -55,9 +55,9 @@ print("scalar multiplication soak ok")
 # compressed wire format: valid points through both decompression paths (subgroup test as a level program / in the kernel)
 for name, comp, dec, pts, cb in (("g1", engine.g1_compress_batch, engine.g1_decompress_batch, g1[:m], 48), ("g2", engine.g2_compress_batch, engine.g2_decompress_batch, g2[:m], 96)):
     c = comp(pts.reshape(-1), m)
-    engine.set_latency_threshold(4096); ra = dec(np.asarray(c).reshape(-1), m, True)
+    engine.set_latency_threshold(8192); ra = dec(np.asarray(c).reshape(-1), m, True)
     engine.set_latency_threshold(0); rb = dec(np.asarray(c).reshape(-1), m, True)
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
     for x, y in zip(ra, rb):
         assert np.array_equal(np.asarray(x), np.asarray(y)), name
     assert np.array_equal(np.asarray(ra[0]).reshape(m, -1), pts.reshape(m, -1)), name
@@ -66,9 +66,9 @@ print("decompression soak ok")
 import random
 rnd = random.Random(7)
 def both(fn):
-    engine.set_latency_threshold(4096); a = fn()
+    engine.set_latency_threshold(8192); a = fn()
     engine.set_latency_threshold(0); b = fn()
-    engine.set_latency_threshold(4096)
+    engine.set_latency_threshold(8192)
     return a, b
 def same(a, b):
     if isinstance(a, tuple):
