@@ -28,7 +28,7 @@ template <class F> BLSMI_DEV Jac<F> jac_select(i32 m, const Jac<F>& a, const Jac
 }
 
 // g1.go:343-397 / g2.go:389-443.  Doubling infinity returns infinity (z stays 0: nz = 2*y*z).
-template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g) {
+template <class F> BLSMI_DEV Jac<F> jac_double_i(const Jac<F>& g) {
     const F a = f_store(f_sqr(g.x));
     const F b = f_store(f_sqr(g.y));
     const F c = f_store(f_sqr(b));
@@ -45,7 +45,8 @@ template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g) {
 
 // g1.go:485-559 / g2.go:532-606 (mixed addition).  Special cases as the reference:
 // g infinite -> o; o infinite -> g; same point -> double; opposite points -> z3 = 0 (infinity).
-template <class F> __device__ __noinline__ Jac<F> jac_add_affine(const Jac<F>& g, const Aff<F>& o) {
+template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g);
+template <class F> BLSMI_DEV Jac<F> jac_add_affine_i(const Jac<F>& g, const Aff<F>& o) {
     const F z1z1 = f_store(f_sqr(g.z));
     const F u2 = f_store(f_mul(o.x, z1z1));
     const F s2 = f_store(f_mul(f_mul(o.y, g.z), z1z1));
@@ -73,7 +74,7 @@ template <class F> __device__ __noinline__ Jac<F> jac_add_affine(const Jac<F>& g
 }
 
 // g1.go:400-482 / g2.go:446-529 (general addition)
-template <class F> __device__ __noinline__ Jac<F> jac_add(const Jac<F>& g, const Jac<F>& o) {
+template <class F> BLSMI_DEV Jac<F> jac_add_i(const Jac<F>& g, const Jac<F>& o) {
     const F z1z1 = f_store(f_sqr(g.z));
     const F z2z2 = f_store(f_sqr(o.z));
     const F u1 = f_store(f_mul(g.x, z2z2));
@@ -101,6 +102,14 @@ template <class F> __device__ __noinline__ Jac<F> jac_add(const Jac<F>& g, const
     r = jac_select(o.inf & ~g.inf, g, r);
     return r;
 }
+
+// Out-of-line forms (one copy of each body per translation unit): the point travels through the lane's scratch on every call, which is
+// what the ladders with a point or two of live state want to avoid -- they use the *_i forms above and keep the accumulator in
+// registers (rocprofv3, profiles/r03a: the out-of-line G1 kernels issued one VALU instruction per 8-9 cycles per SIMD against 5
+// for the pairing kernels, behind 3.5 TB/s of argument traffic).
+template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g) { return jac_double_i(g); }
+template <class F> __device__ __noinline__ Jac<F> jac_add_affine(const Jac<F>& g, const Aff<F>& o) { return jac_add_affine_i(g, o); }
+template <class F> __device__ __noinline__ Jac<F> jac_add(const Jac<F>& g, const Jac<F>& o) { return jac_add_i(g, o); }
 
 // g1.go:322-340 / g2.go:365-386
 template <class F> __device__ __noinline__ Aff<F> jac_to_affine(const Jac<F>& g) {

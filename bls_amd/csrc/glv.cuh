@@ -123,20 +123,19 @@ template <class F> struct glv_shape;
 template <> struct glv_shape<FpS> { using type = GlvG1; };
 template <> struct glv_shape<Fp2S> { using type = GlvG2; };
 
-// res += sign(d) * endo_S(tab[|d|]): one summand of one window.  Out of line so that the ladder's loop body is four calls, not four
-// inlined copies whose temporaries all compete for registers.
-BLSMI_DEV Jac<FpS> glv_endo0(const Jac<FpS>& p) { return p; }
-template <int S, class F>
-__device__ __noinline__ void glv_accumulate(Jac<F>& res, const Jac<F>* tab, i32 d) {
-    const i32 neg = d >> 31;                                                // all-ones for a negative digit
-    Jac<F> e = tab[(d ^ neg) - neg];
-    if constexpr (S == 1) e = glv_endo1(e);
-    if constexpr (S == 2) e = glv_endo2(e);
-    if constexpr (S == 3) e = glv_endo3(e);
-    e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
-    res = jac_add(res, e);
+// endo_s(e), s = the stream: run-time form of glv_endo1/2/3 for the rolled loop of the ladder (one copy of the addition body).
+// G1: stream 1 = -phi: (beta X, -Y, Z)
+BLSMI_DEV Jac<FpS> glv_endo_s(const Jac<FpS>& p, int s) {
+    const i32 m = -(i32)(s & 1);
+    Jac<FpS> r;
+    r.x = fp_select(m, fp_store(fp_mul(p.x, C_BETA)), p.x);
+    r.y = fp_select(m, fp_store(fp_neg(p.y)), p.y);
+    r.z = p.z; r.inf = p.inf;
+    return r;
 }
 // [k] P for P in the subgroup: signed-window ladder over the sub-scalars, one shared table.  F = FpS (G1), Fp2S (G2, either layout).
+// The accumulator stays in registers for the whole ladder: the doubling and addition bodies are inlined ONCE each (rolled inner
+// loops over the five doublings and over the streams), only the field cores are calls.
 template <class F>
 __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
     using G = typename glv_shape<F>::type;
@@ -150,13 +149,19 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
     tab[2] = jac_double(tab[1]);
     for (int j = 3; j <= 16; j++) tab[j] = jac_add_affine(tab[j - 1], p);
     Jac<F> res = jac_zero<F>();
+#pragma unroll 1
     for (int w = G::NWIN - 1; w >= 0; w--) {
-        if (w != G::NWIN - 1) { res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); res = jac_double(res); }
-        glv_accumulate<0>(res, tab, booth5(sub[0], w));
-        glv_accumulate<1>(res, tab, booth5(sub[1], w));
-        if constexpr (G::NS == 4) {
-            glv_accumulate<2>(res, tab, booth5(sub[2], w));
-            glv_accumulate<3>(res, tab, booth5(sub[3], w));
+        if (w != G::NWIN - 1) {
+#pragma unroll 1
+            for (int d = 0; d < 5; d++) res = jac_double_i(res);
+        }
+#pragma unroll 1
+        for (int s = 0; s < G::NS; s++) {
+            const i32 d = booth5(sub[s], w);
+            const i32 neg = d >> 31;                                        // all-ones for a negative digit
+            Jac<F> e = glv_endo_s(tab[(d ^ neg) - neg], s);
+            e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
+            res = jac_add_i(res, e);
         }
     }
     return res;

@@ -165,7 +165,8 @@ __device__ void mul_fixed_body(const i32* table, const u8* scalars, u8* out, u8*
     const size_t tt = t < n ? t : n - 1;
     const u8* s = scalars + 32 * tt;
     Jac<F> res = jac_zero<F>();
-    for (int w = 0; w < FIXED_WINDOWS; w++) res = jac_add_affine(res, fixed_entry<F>(table, w, s[31 - w]));
+#pragma unroll 1
+    for (int w = 0; w < FIXED_WINDOWS; w++) res = jac_add_affine_i(res, fixed_entry<F>(table, w, s[31 - w]));
     const Aff<F> a = jac_to_affine(res);
     if (t < n) { store_aff(out + (size_t)PB * t, a); out_inf[t] = a.inf ? 1 : 0; }
 }
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_raw_pair(const i32* raw
     const u32 cnt = j < nb ? hist[t] : 0;
     const u32* slice = idx + (t >> 16) * per_win + offs[t];
     P2::G2JacP acc = jac_zero<P2::Fp2S>();
-    for (u32 k = 0; k < cnt; k++) acc = jac_add_affine(acc, raw_item_g2_pair(raw, slice[k], par));
+    for (u32 k = 0; k < cnt; k++) acc = jac_add_affine_i(acc, raw_item_g2_pair(raw, slice[k], par));   // inlined: the accumulator stays in registers
     if (j < nb) {
         soa_store(buckets, nb, t, 0 + par, acc.x.c); soa_store(buckets, nb, t, 2 + par, acc.y.c); soa_store(buckets, nb, t, 4 + par, acc.z.c);
         if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
