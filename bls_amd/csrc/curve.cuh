@@ -140,18 +140,20 @@ template <class F> BLSMI_DEV Jac<F> aff_mul_u256(const Aff<F>& p, const u32 k[8]
 // multiplication by a public 64-bit constant (ClearH, hash.go:306-309: |x| = 0xd201000000010000)
 template <class F> BLSMI_DEV Jac<F> aff_mul_u64_public(const Aff<F>& p, u64 k) {
     Jac<F> res = to_jac(p);
-    for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
-        res = jac_double(res);
-        if ((k >> i) & 1) res = jac_add_affine(res, p);
+#pragma unroll 1
+    for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {                  // the accumulator stays in registers (inlined bodies, one copy each)
+        res = jac_double_i(res);
+        if ((k >> i) & 1) res = jac_add_affine_i(res, p);
     }
     return res;
 }
 // the same for a Jacobian base point (general additions; g2.go:609-619)
 template <class F> BLSMI_DEV Jac<F> jac_mul_u64_public(const Jac<F>& p, u64 k) {
     Jac<F> res = p;
+#pragma unroll 1
     for (int i = 62 - __builtin_clzll(k); i >= 0; i--) {
-        res = jac_double(res);
-        if ((k >> i) & 1) res = jac_add(res, p);
+        res = jac_double_i(res);
+        if ((k >> i) & 1) res = jac_add_i(res, p);
     }
     return res;
 }
