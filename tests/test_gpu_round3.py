@@ -396,3 +396,81 @@ def test_eight_logical_shards_full_size_on_one_gpu(rccl):
     rccl=1 routes the exchanges through a real (one-rank) RCCL communicator."""
     res = _worker({"BLSMI_SHARDS": "8", "BLSMI_FORCE_RCCL": rccl}, [])
     assert res["shards"] == 8 and res["ok"], res
+
+
+# ---- endomorphism scalar multiplication: edge scalars, both paths, and the opt-out for arbitrary curve points ---------------------
+def test_endomorphism_scalar_multiplication_edge_scalars(eng):
+    """The decompositions behind the default scalar multiplication (bls_amd/csrc/glv.cuh, glv_model.py) are integer identities for
+    EVERY 256-bit scalar: the boundaries of the divisions (multiples of z and z^2, r, 2^256 - 1 ...) against the oracle's bit-serial
+    MulFR (g1.go:80-90, g2.go:92-102), on the latency programs and the throughput ladders, for points, the generators (fixed-base
+    tables) and the MSM (whose digit pass reduces mod r first)."""
+    Z = P.BLS_X; Z2 = Z * Z; R = P.R_ORDER
+    ks = [0, 1, 2, Z - 1, Z, Z + 1, Z2 - 1, Z2, Z2 + 1, Z**3 - 1, Z**3, Z**3 + 1, R - 1, R, R + 1, 2 * R, (1 << 128) - 1, 1 << 128, (1 << 129) - 1,
+          (1 << 255) - 1, 1 << 255, (1 << 256) - 1, (1 << 256) - Z2, 0x0101010101010101010101010101010101010101010101010101010101010101 ]
+    xs = P.XORShift(909)
+    ks += [P.rand_int(xs, 1 << 256) for _ in range(11)]
+    n = len(ks)
+    kb = b"".join(k.to_bytes(32, "big") for k in ks)
+    p1 = [rand_g1(xs) for _ in range(n)]; p2 = [rand_g2(xs) for _ in range(n)]
+    for pts, mul, gen_mul, msm, ref_mul, ref_sum, gen in ((p1, eng.g1_mul_batch, eng.g1_mul_generator_batch, eng.g1_msm, RC.g1_mul, RC.g1_sum, RC.g1_generator()),
+                                                          (p2, eng.g2_mul_batch, eng.g2_mul_generator_batch, eng.g2_msm, RC.g2_mul, RC.g2_sum, RC.g2_generator())):
+        out, inf = mul(b"".join(pts), kb, n)
+        want = [ref_mul(p, k.to_bytes(32, "big")) for p, k in zip(pts, ks)]
+        for i in range(n):
+            assert (want[i] is None) == bool(inf[i]) and (want[i] is None or out[i].tobytes() == want[i]), (i, hex(ks[i]))
+        out, inf = gen_mul(kb, n)
+        for i in range(n):
+            e = ref_mul(gen, ks[i].to_bytes(32, "big"))
+            assert (e is None) == bool(inf[i]) and (e is None or out[i].tobytes() == e), (i, hex(ks[i]))
+        fin = [w for w in want if w is not None]
+        assert msm(b"".join(pts), kb, n) == ref_sum(b"".join(fin), len(fin))
+
+
+def test_scalar_multiplication_of_arbitrary_curve_points_needs_the_opt_out(eng):
+    """For a curve point OUTSIDE the subgroup the endomorphisms are not multiplications, so the default ladder is not MulFR there;
+    blsmi_set_mul_assume_subgroup(0) selects the plain windowed ladder, which is -- for every curve point (g1.go:80-90)."""
+    g1s, g2s = _torsion_points()
+    xs = P.XORShift(910)
+    ks = [sk_bytes(xs) for _ in range(4)]
+    try:
+        eng.set_mul_assume_subgroup(False)
+        out, inf = eng.g1_mul_batch(b"".join(g1s[:4]), b"".join(ks), 4)
+        for i in range(4):
+            assert out[i].tobytes() == RC.g1_mul(g1s[i], ks[i]) and not inf[i]
+        out, inf = eng.g2_mul_batch(b"".join(g2s[:4]), b"".join(ks), 4)
+        for i in range(4):
+            assert out[i].tobytes() == RC.g2_mul(g2s[i], ks[i]) and not inf[i]
+        # subgroup points: both modes agree with the oracle
+        p = rand_g1(xs)
+        assert eng.g1_mul_batch(p, ks[0], 1)[0][0].tobytes() == RC.g1_mul(p, ks[0])
+    finally:
+        eng.set_mul_assume_subgroup(True)
+    p = rand_g1(xs)
+    assert eng.g1_mul_batch(p, ks[0], 1)[0][0].tobytes() == RC.g1_mul(p, ks[0])
+
+
+def test_msm_bucket_method_with_scalars_beyond_r_and_points_at_infinity():
+    """n = 2^17 (the bucket method over decomposed scalars): scalars up to 2^256 - 1 (the digit pass reduces them mod r first), a few
+    all-zero records (infinity) among the points; the result equals the oracle's multiple of the generator for the folded scalar."""
+    import torch
+    from bls_amd import engine as eng
+    eng.init(0)
+    n = 1 << 17
+    rng = np.random.default_rng(77)
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)                      # full 256-bit scalars
+    base = 32
+    bk = rng.integers(0, 256, size=(base, 32), dtype=np.uint8); bk[:, 0] &= 0x3f
+    for grp, pb, gen, ref_mul in (("g1", 96, RC.g1_generator(), RC.g1_mul), ("g2", 192, RC.g2_generator(), RC.g2_mul)):
+        bpts, _ = (eng.g1_mul_generator_batch if grp == "g1" else eng.g2_mul_generator_batch)(bk.reshape(-1), base)
+        pts = np.tile(bpts, (n // base, 1)).copy()
+        holes = [5, 70000, n - 1]
+        for h in holes:
+            pts[h] = 0                                                             # the all-zero record: the point at infinity
+        got = (eng.g1_msm if grp == "g1" else eng.g2_msm)(pts.reshape(-1), k.reshape(-1), n)
+        acc = 0
+        kk = k.reshape(n // base, base, 32)
+        skip = {(h // base, h % base) for h in holes}
+        for j in range(base):
+            col = sum(int.from_bytes(kk[i, j].tobytes(), "big") for i in range(n // base) if (i, j) not in skip)
+            acc = (acc + int.from_bytes(bk[j].tobytes(), "big") * col) % P.R_ORDER
+        assert got == ref_mul(gen, acc.to_bytes(32, "big")), grp
