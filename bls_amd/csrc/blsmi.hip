@@ -910,7 +910,8 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
 // The bucket method for points of the prime-order subgroup (msm.inc, second half): scalars decomposed through the endomorphisms
 // (G1: 8 bucket-windows fed by 2 n items, G2: 4 fed by 4 n), points converted to raw limbs once.  Same result as msm_bucket_dev.
 template <int PB, int W>
-static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s) {
+static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s,
+                              const std::function<int()>& points_arrive = {}) {
     constexpr int c = 16;
     static const int K = []{ const char* v = getenv("BLSMI_MSM_CHUNK"); const int k = v ? atoi(v) : 8; return (k >= 2 && k <= 64 && !(k & (k - 1))) ? k : 8; }();   // buckets per chunk lane
     constexpr int nbw = W == 3 ? 8 : 4, sh = W == 3 ? 3 : 2, NS = 16 / nbw;
@@ -927,9 +928,9 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(dmax.p, 0, sizeof(u32), s));
     HIPCHK(hipMemsetAsync(cls.p, 0, sizeof(u32) * 256, s));
-    prof_mark(W == 3 ? "k_msm_prep_g1" : "k_msm_prep_g2");
-    if (W == 3) hipLaunchKernelGGL(k_msm_prep_g1, dim3(nblocks(n)), dim3(WG), 0, s, d_pts, d_scalars, raw.as<i32>(), rec.as<u8>(), n);
-    else hipLaunchKernelGGL(k_msm_prep_g2, dim3(nblocks(n)), dim3(WG), 0, s, d_pts, d_scalars, raw.as<i32>(), rec.as<u8>(), n);
+    prof_mark(W == 3 ? "k_msm_recode_g1" : "k_msm_recode_g2");
+    if (W == 3) hipLaunchKernelGGL(k_msm_recode_g1, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, rec.as<u8>(), n);
+    else hipLaunchKernelGGL(k_msm_recode_g2, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, rec.as<u8>(), n);
     prof_mark("k_msm_hist_glv");
     hipLaunchKernelGGL(k_msm_hist_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, hist.as<u32>());
     prof_mark("k_msm_max");
@@ -946,21 +947,30 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     hipLaunchKernelGGL(k_msm_class_scan, dim3(1), dim3(256), 0, s, (const u32*)cls.as<u32>(), cls.as<u32>() + 256, cls.as<u32>() + 512);
     hipLaunchKernelGGL(k_msm_class_scatter, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, (const u32*)(cls.as<u32>() + 256), cls.as<u32>() + 512, perm.as<u32>());
     prof_mark(nullptr);
-    // the digit passes above do not depend on the verdict: the host learns it while they run.  Skewed scalars (a bucket beyond
-    // 2048 items would be one lane's serial work) fall back to the per-point multiples, whose cost does not depend on the scalars.
+    // The digit passes above need the scalars only: the host form copies the POINTS now, beside them (points_arrive), and only
+    // then are the points converted to raw limbs.  Skewed scalars (a bucket beyond 2048 items would be one lane's serial work)
+    // fall back to the per-point multiples, whose cost does not depend on the scalars.
+    if (points_arrive) { const int rc = points_arrive(); if (rc) return rc; }
+    prof_mark(W == 3 ? "k_msm_rawpts_g1" : "k_msm_rawpts_g2");
+    if (W == 3) hipLaunchKernelGGL(k_msm_rawpts_g1, dim3(nblocks(n)), dim3(WG), 0, s, d_pts, raw.as<i32>(), n);
+    else hipLaunchKernelGGL(k_msm_rawpts_g2, dim3(nblocks(n)), dim3(WG), 0, s, d_pts, raw.as<i32>(), n);
+    prof_mark(nullptr);
     HIPCHK(hipStreamSynchronize(s));
     if (biggest > 2048) return BLSMI_E_SKEW;
     prof_mark(W == 3 ? "k_g1_msm_bucket_raw" : "k_g2_msm_bucket_raw_pair");
     if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
     else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
-    prof_mark(W == 6 ? "k_g2_msm_chunk" : "k_g1_msm_chunk");
-    hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
-    prof_mark(W == 6 ? "k_g2_msm_fold" : "k_g1_msm_fold");
+    const bool pairk = W == 6 && g_pair_layout;                            // G2: a lane pair per chunk / per pair of chunk sums, two waves per SIMD
+    prof_mark(W == 6 ? (pairk ? "k_g2_msm_chunk_pair" : "k_g2_msm_chunk") : "k_g1_msm_chunk");
+    if (pairk) hipLaunchKernelGGL(k_g2_msm_chunk_pair, dim3((unsigned)((nct + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    else hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    prof_mark(W == 6 ? (pairk ? "k_g2_msm_fold_pair" : "k_g2_msm_fold") : "k_g1_msm_fold");
     i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
     size_t seg = per_win_chunks;
     while (seg > 1) {
         const size_t half = (seg + 1) / 2;
-        hipLaunchKernelGGL(k.fold, dim3(nblocks(half * nbw)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nbw);
+        if (pairk) hipLaunchKernelGGL(k_g2_msm_fold_pair, dim3((unsigned)((half * nbw + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nbw);
+        else hipLaunchKernelGGL(k.fold, dim3(nblocks(half * nbw)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nbw);
         std::swap(src, dst);
         seg = half;
     }
@@ -987,12 +997,17 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
 // sum_i k_i P_i with everything resident on the leased device: bucket method from bucket_min points on (unless the digits
 // are skewed), per-point multiples + tree sum below.  Result: affine bytes at d_out, infinity flag (i32) at d_flag.  Synchronises s.
 template <int PB, int W, class KM, class K0, class K1, class K2>
-static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s) {
+static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s,
+                        const std::function<int()>& points_arrive = {}) {
     static const size_t bucket_min = []{ const char* v = getenv("BLSMI_MSM_BUCKET_MIN"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1 << 17; }();
     int rc = BLSMI_E_SKEW;
-    if (n >= bucket_min) rc = g_mul_subgroup.load(std::memory_order_relaxed) ? msm_bucket_glv_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s)
-                                                                           : msm_bucket_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s);
+    bool arrived = !points_arrive;                                         // the host form hands over its copy of the points: issued at the latest before the first kernel that reads them
+    auto arrive_once = [&]() -> int { if (arrived) return BLSMI_OK; arrived = true; return points_arrive(); };
+    if (n >= bucket_min && g_mul_subgroup.load(std::memory_order_relaxed)) rc = msm_bucket_glv_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s, arrive_once);
+    else if (n >= bucket_min) { rc = arrive_once(); if (!rc) rc = msm_bucket_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s); }
     if (rc != BLSMI_E_SKEW) return rc;
+    rc = arrive_once();
+    if (rc) return rc;
     DBuf dm, dinf;
     HIPCHK(dm.alloc((size_t)PB * n, s)); HIPCHK(dinf.alloc(n, s));
     rc = mul_dev_core<PB>(kmul, d_pts, 0, d_scalars, dm.as<u8>(), dinf.as<u8>(), n, s);
@@ -1006,9 +1021,18 @@ static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, cons
     LOCK_AND_INIT();
     DBuf dp, ds, dout, dflag;
     HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
-    HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
+    // scalars first; the points follow while the digit passes (which need the scalars only) run
     HIPCHK(hipMemcpyAsync(ds.p, scalars, 32 * n, hipMemcpyHostToDevice, g_stream));
-    int rc = msm_dev_core<PB, W>(mk, kmul, k0, k1, kfinal, dp.as<u8>(), ds.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    // (on a side stream: a copy from pageable memory issued on the compute stream would wait for the kernels queued there)
+    HIPCHK(tl_ctx->ensure_aux());
+    hipStream_t st = g_stream, side = tl_ctx->aux[0];
+    hipEvent_t arrived = tl_ctx->join[0];
+    int rc = msm_dev_core<PB, W>(mk, kmul, k0, k1, kfinal, dp.as<u8>(), ds.as<u8>(), n, dout.as<u8>(), dflag.as<i32>(), g_stream, [&]() -> int {
+        HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, side));
+        HIPCHK(hipEventRecord(arrived, side));
+        HIPCHK(hipStreamWaitEvent(st, arrived, 0));
+        return BLSMI_OK;
+    });
     if (rc) return rc;
     i32 flag = 0;
     HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream));

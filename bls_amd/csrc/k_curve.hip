@@ -345,3 +345,42 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_raw_pair(const i32* raw
         if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
     }
 }
+// The running-sum pass and the fold of the MSM for G2 in the lane-pair layout (the one-lane k_g2_msm_chunk runs one wave per SIMD with
+// 494 spilled registers, one VALU instruction per 13.7 cycles: profiles/r03a): a lane pair per chunk / per pair of chunk sums.
+BLSMI_DEV P2::G2JacP pair_soa_load(const i32* buf, size_t n, size_t t, int par) {
+    P2::G2JacP p;
+    p.x = P2::wrap(soa_load(buf, n, t, 0 + par)); p.y = P2::wrap(soa_load(buf, n, t, 2 + par)); p.z = P2::wrap(soa_load(buf, n, t, 4 + par));
+    p.inf = buf[(size_t)6 * NL * n + t];
+    return p;
+}
+BLSMI_DEV void pair_soa_store(i32* buf, size_t n, size_t t, int par, const P2::G2JacP& p) {
+    soa_store(buf, n, t, 0 + par, p.x.c); soa_store(buf, n, t, 2 + par, p.y.c); soa_store(buf, n, t, 4 + par, p.z.c);
+    if (!par) buf[(size_t)6 * NL * n + t] = p.inf;
+}
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_chunk_pair(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nchunks_total) {
+    const int par = threadIdx.x & 1;
+    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t t = t0 < nchunks_total ? t0 : nchunks_total - 1;         // both lanes of a pair stay active
+    const size_t per_win = ((size_t)1 << c) / K;
+    const size_t w = t / per_win, j = t % per_win;
+    const size_t lo = j * K;
+    P2::G2JacP running = jac_zero<P2::Fp2S>(), local = jac_zero<P2::Fp2S>();
+#pragma unroll 1
+    for (int k = K - 1; k >= 0; k--) {
+        running = jac_add_i(running, pair_soa_load(buckets, nb, (w << c) + lo + k, par));
+        local = jac_add_i(local, running);
+    }
+    if (j == 0) local = jac_add(local, jac_neg(running));                  // lo - 1 = -1
+    else local = jac_add(local, jac_mul_u64_public(running, (u64)(lo - 1)));
+    if (t0 < nchunks_total) pair_soa_store(chunks, nchunks_total, t, par, local);
+}
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_fold_pair(const i32* src, i32* dst, size_t seg, size_t half, int nwin) {
+    const int par = threadIdx.x & 1;
+    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t total = half * nwin;
+    const size_t t = t0 < total ? t0 : total - 1;
+    const size_t w = t / half, j = t % half;
+    P2::G2JacP r = pair_soa_load(src, seg * nwin, w * seg + j, par);
+    if (j + half < seg) r = jac_add(r, pair_soa_load(src, seg * nwin, w * seg + j + half, par));
+    if (t0 < total) pair_soa_store(dst, half * nwin, t, par, r);
+}
