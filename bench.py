@@ -200,6 +200,10 @@ def roofline_of(prof, units, bytes_per_unit, ctr, grid_of=None):
     algo = bytes_per_unit * units
     achieved = algo / (ms * 1e-3) / 1e9
     c = counter_of(ctr, dom, grid_of(dom) if grid_of else None)
+    if not grid_of and "by_grid" in ctr["kernels"].get(dom, {}):          # launch grid not stated: the profile's record of this kernel that ran closest to this duration
+        recs = [r for r in ctr["kernels"][dom]["by_grid"].values() if "avg_ns" in r]
+        if recs:
+            c = min(recs, key=lambda r: abs(r["avg_ns"] / 1e6 - per_launch_ms))
     traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8),
             "traffic": traffic, "algorithmic_bytes_per_launch": algo, "bytes_per_unit": bytes_per_unit, "units_per_launch": units,
