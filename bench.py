@@ -414,7 +414,7 @@ def aggregate_dev_bench(E, group, n, reps=3):
     assert engine.verify_aggregate_dev(group, d_m.data_ptr(), d_o.data_ptr(), bad.data_ptr(), agg, n) is False, "one wrong key must fail the aggregate"
     out = {"signatures": n, "ms": round(dt / reps * 1e3, 2), "signatures_per_s": round(n * reps / dt, 1),
            "roofline": roofline_of(prof, n, BYTES[group + "_aggregate"], E.ctr),
-           "note": "messages (32 bytes each), offsets and keys resident in HBM; duplicate-message rejection on the device (keyed fingerprints + radix sort) included; "
+           "note": "messages (32 bytes each), offsets and keys resident in HBM; duplicate-message rejection on the device (keyed open-addressing table, exact comparisons) included; "
                    "n Miller loops (two tuples per loop) + Fq12 product tree + ONE final exponentiation; verdict True, and False with one key replaced"}
     return out, (packed, allpk, agg)
 

@@ -167,7 +167,8 @@ int blsmi_g1pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const v
 
 /* device-pointer forms of VerifyAggregate (g2pubs/bls.go:240-270, g1pubs/bls.go:252-282, :300-311): messages, offsets (or the
  * 8-byte domain) and keys resident on one of the library's devices, the aggregate signature in HOST memory (one point).  The
- * duplicate-message rejection runs on the device as well (keyed fingerprints, radix sort, exact comparison inside runs).
+ * duplicate-message rejection runs on the device as well (a keyed open-addressing table; every occupied slot of a probe sequence is
+ * compared exactly).
  * The call runs on the device that owns d_pks and is not split over devices.  (Added in blsmi 0.3.) */
 int blsmi_g2pubs_verify_aggregate_dev(const void *d_msgs, const void *d_off, const void *d_pks, const uint8_t sig[96], size_t n, int *ok, void *stream);
 int blsmi_g1pubs_verify_aggregate_dev(const void *d_msgs, const void *d_off, const void *d_pks, const uint8_t sig[192], size_t n, int *ok, void *stream);

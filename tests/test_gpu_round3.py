@@ -474,3 +474,19 @@ def test_msm_bucket_method_with_scalars_beyond_r_and_points_at_infinity():
             col = sum(int.from_bytes(kk[i, j].tobytes(), "big") for i in range(n // base) if (i, j) not in skip)
             acc = (acc + int.from_bytes(bk[j].tobytes(), "big") * col) % P.R_ORDER
         assert got == ref_mul(gen, acc.to_bytes(32, "big")), grp
+
+
+@pytest.mark.parametrize("force", ["", "1"])
+def test_device_duplicate_table_and_its_fallback(force):
+    """Duplicate-message rejection of VerifyAggregate for n > 4096 (g2pubs/bls.go:245-261): the device's keyed open-addressing table
+    (k_util.hip) and -- BLSMI_DUP_FORCE_SORT=1 -- the path it takes when a probe sequence grows too long: the reference's sort on the
+    host.  Same verdicts for a clean set, one duplicate, an empty message and n equal messages, resident and host buffers."""
+    env = dict(os.environ)
+    env.pop("BLSMI_DUP_FORCE_SORT", None)
+    if force:
+        env["BLSMI_DUP_FORCE_SORT"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dup_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("DUP_RESULT ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    res = json.loads(line[-1][len("DUP_RESULT "):])
+    assert res["forced"] == bool(force) and res["ok"], res
