@@ -330,8 +330,11 @@ def verify_bench(E, steps=5, warmup=1, n=65536):
         d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
         full = torch.zeros(world * n // 8, dtype=torch.int32, device=dev)
 
-        def step():
+        def local_step():
             engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+
+        def step():
+            local_step()
             if E.use_dist:
                 full.zero_()
                 full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
@@ -343,7 +346,7 @@ def verify_bench(E, steps=5, warmup=1, n=65536):
         out[group + "_verifies_per_s"] = round(world * n * steps / dt, 1)
         out[group + "_ms_per_step"] = round(dt / steps * 1e3, 3)
         if rank == 0:
-            prof = profiled(E.lib, step)
+            prof = profiled(E.lib, local_step)                            # rank 0 alone: no collective in here
             out[group + "_roofline"] = roofline_of(prof, n, BYTES["verify"], E.ctr, lambda k: 2 * n if k.endswith("_pair") else n)
             if world == 1 and E.cpu:
                 out[group + "_cpu_baseline"] = cpu_verify(group, packed, pks, sigs)
