@@ -912,8 +912,7 @@ static int msm_bucket_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scal
 template <int PB, int W>
 static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s,
                               const std::function<int()>& points_arrive = {}) {
-    constexpr int c = 16;
-    static const int K = []{ const char* v = getenv("BLSMI_MSM_CHUNK"); const int k = v ? atoi(v) : 8; return (k >= 2 && k <= 64 && !(k & (k - 1))) ? k : 8; }();   // buckets per chunk lane
+    constexpr int c = 16, K = 8;                                           // 8 buckets per chunk lane: 2^13 chunks per window, 13 fold levels (the tail programs are generated for that)
     constexpr int nbw = W == 3 ? 8 : 4, sh = W == 3 ? 3 : 2, NS = 16 / nbw;
     constexpr size_t RAWW = W == 3 ? 48 : 244;
     const size_t B1 = (size_t)1 << c, nb = B1 * nbw, per_win_chunks = B1 / K, nct = per_win_chunks * nbw, per_win_items = (size_t)NS * n;
@@ -923,7 +922,7 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     HIPCHK(raw.alloc(sizeof(i32) * RAWW * n, s)); HIPCHK(rec.alloc(32 * n, s));
     HIPCHK(hist.alloc(sizeof(u32) * nb, s)); HIPCHK(offs.alloc(sizeof(u32) * nb, s)); HIPCHK(cursor.alloc(sizeof(u32) * nb, s)); HIPCHK(dmax.alloc(sizeof(u32), s));
     HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s)); HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
-    HIPCHK(ch0.alloc(sizeof(i32) * jw * nct, s)); HIPCHK(ch1.alloc(sizeof(i32) * jw * ((per_win_chunks + 1) / 2) * nbw, s));
+    HIPCHK(ch0.alloc(sizeof(i32) * jw * 2 * nct, s)); HIPCHK(ch1.alloc(sizeof(i32) * jw * 2 * nct, s));   // the fold's arrays: at most 2 nct records on either side
     HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(dmax.p, 0, sizeof(u32), s));
@@ -960,26 +959,30 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     prof_mark(W == 3 ? "k_g1_msm_bucket_raw" : "k_g2_msm_bucket_raw_pair");
     if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
     else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
-    const bool pairk = W == 6 && g_pair_layout;                            // G2: a lane pair per chunk / per pair of chunk sums, two waves per SIMD
-    prof_mark(W == 6 ? (pairk ? "k_g2_msm_chunk_pair" : "k_g2_msm_chunk") : "k_g1_msm_chunk");
-    if (pairk) hipLaunchKernelGGL(k_g2_msm_chunk_pair, dim3((unsigned)((nct + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
-    else hipLaunchKernelGGL(k.chunk, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
-    prof_mark(W == 6 ? (pairk ? "k_g2_msm_fold_pair" : "k_g2_msm_fold") : "k_g1_msm_fold");
+    // running sums per chunk WITHOUT the per-lane multiplication, then the fold that carries the odd-element sums along (msm.inc):
+    // one addition deep per level; out come, per window, X, L and O_0 .. O_{m-1}
+    const bool pairk = W == 6 && g_pair_layout;                            // G2: a lane pair per chunk / per sum, two waves per SIMD
+    prof_mark(W == 6 ? (pairk ? "k_g2_msm_chunk2_pair" : "k_g2_msm_chunk2") : "k_g1_msm_chunk2");
+    if (pairk) hipLaunchKernelGGL(k_g2_msm_chunk2_pair, dim3((unsigned)((nct + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    else if (W == 6) hipLaunchKernelGGL(k_g2_msm_chunk2, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    else hipLaunchKernelGGL(k_g1_msm_chunk2, dim3(nblocks(nct)), dim3(WG), 0, s, (const i32*)buckets.as<i32>(), ch0.as<i32>(), c, K, nb, nct);
+    prof_mark(W == 6 ? (pairk ? "k_g2_msm_fold2_pair" : "k_g2_msm_fold2") : "k_g1_msm_fold2");
     i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
-    size_t seg = per_win_chunks;
-    while (seg > 1) {
-        const size_t half = (seg + 1) / 2;
-        if (pairk) hipLaunchKernelGGL(k_g2_msm_fold_pair, dim3((unsigned)((half * nbw + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nbw);
-        else hipLaunchKernelGGL(k.fold, dim3(nblocks(half * nbw)), dim3(WG), 0, s, (const i32*)src, dst, seg, half, nbw);
+    int narr = 2, m = 0;
+    for (size_t len = per_win_chunks; len > 1; len /= 2, narr++, m++) {
+        const size_t lanes = (size_t)(narr + 1) * nbw * (len / 2);
+        if (pairk) hipLaunchKernelGGL(k_g2_msm_fold2_pair, dim3((unsigned)((lanes + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len);
+        else if (W == 6) hipLaunchKernelGGL(k_g2_msm_fold2, dim3(nblocks(lanes)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len);
+        else hipLaunchKernelGGL(k_g1_msm_fold2, dim3(nblocks(lanes)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len);
         std::swap(src, dst);
-        seg = half;
     }
-    if (g_lat_max > 0) {                                                   // Horner over the 8 / 4 windows + ToAffine: one wave (k_lat.hip: msmfin1 / msmfin2)
+    const size_t nrec = (size_t)(m + 2) * nbw;                             // X, L, O_0 .. O_{m-1} per window
+    if (g_lat_max > 0 && m == 13 && K == 8) {                              // Horner over the O's and over the 8 / 4 windows + ToAffine: one wave (k_lat.hip: msmfin1 / msmfin2)
         const size_t prog = W == 3 ? LAT_MSMFIN1_OFFSET : LAT_MSMFIN2_OFFSET;
         DBuf good; HIPCHK(good.alloc(1, s));
         prof_mark(W == 3 ? "k_lat:msmfin1" : "k_lat:msmfin2");
         hipLaunchKernelGGL(k_lat, dim3(1), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog, (const u8*)nullptr, (size_t)0,
-                           (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), (size_t)nbw,
+                           (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0, reinterpret_cast<const u8*>(src), nrec,
                            (const u8*)nullptr, good.as<u8>(), reinterpret_cast<u64*>(d_out), (size_t)1);
         hipLaunchKernelGGL(k_good_to_flag, dim3(1), dim3(WG), 0, s, (const u8*)good.as<u8>(), d_flag);
         prof_mark(nullptr);
@@ -987,8 +990,9 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
         HIPCHK(hipStreamSynchronize(s));
         return BLSMI_OK;
     }
-    prof_mark(W == 6 ? "k_g2_msm_final" : "k_g1_msm_final");
-    hipLaunchKernelGGL(k.final, dim3(1), dim3(WG), 0, s, (const i32*)src, nbw, c, d_out, d_flag);
+    prof_mark(W == 6 ? "k_g2_msm_final2" : "k_g1_msm_final2");
+    if (W == 6) hipLaunchKernelGGL(k_g2_msm_final2, dim3(1), dim3(WG), 0, s, (const i32*)src, nbw, m, 3, c, d_out, d_flag);
+    else hipLaunchKernelGGL(k_g1_msm_final2, dim3(1), dim3(WG), 0, s, (const i32*)src, nbw, m, 3, c, d_out, d_flag);
     prof_mark(nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));

@@ -832,7 +832,7 @@ def flat12(f):
 BUF_RAW3 = 8       # LOAD: element e of the raw device representation (15 int32 limbs, structure-of-arrays with n = 1) at buffer 3
 BUF_M384_0 = 9     # LOAD: element e of the Fq wire format (6 little-endian uint64, Montgomery 2^384) at buffer 0
 BUF_SOA3 = 10      # LOAD: coordinate e of Jacobian record w of a structure-of-arrays buffer of `stride` records (buffer 3, stride = its
-                   # stride argument): element = e | w << 3 | (1 << 8 for 6-coordinate records); a record flagged infinite reads as (0, 1, 0)
+                   # stride argument): element = e | w << 3 | (1 << 11 for 6-coordinate records), w < 256; a record flagged infinite reads as (0, 1, 0)
 
 
 BUF_SOA12 = 11     # LOAD: Fq element e of Fq12 record (tuple index + which * arg2) of a structure-of-arrays buffer of `stride` records (buffer 3,
@@ -847,7 +847,8 @@ BUF_SOAPT = 13     # LOAD: coordinate e of projective SoA record (tuple index + 
 
 
 def soa_el(e, w, six):
-    return e | (w << 3) | ((1 << 8) if six else 0)
+    assert 0 <= w < 256
+    return e | (w << 3) | ((1 << 11) if six else 0)
 
 
 def unflat12(v):
@@ -969,23 +970,37 @@ def build_subgroup_program(b, T, kind):
     return b
 
 
-def build_msm_final_program(b, T, kind, nwin=16, c=16):
-    """the tail of the bucket-method MSM (msm.inc step 4): join the nwin window sums by Horner in 2^c -- c doublings and one
-    addition per window, 240 dependent doublings -- and convert to affine.  Inputs: the window sums as the kernels leave them
-    (Jacobian, raw limbs, structure of arrays); (X, Y, Z) Jacobian = (X Z : Y : Z^3) homogeneous.  Output: the affine sum and
-    its Z (zero for the point at infinity)."""
+def build_msm_final_program(b, T, kind, nwin, c=16, m=13, logk=3):
+    """the tail of the bucket-method MSM over decomposed scalars (msm.inc): per window w the fold leaves 2 + m sums -- X (all chunk
+    sums), L (the chunks' local weighted sums) and the odd-element sums O_0 .. O_{m-1} of the successively halved chunk-sum arrays --
+    at records a nwin + w of a Jacobian structure-of-arrays buffer (a = 0: X, 1: L, 2 + l: O_l).  The window total is
+        L - X + 2^logk (O_0 + 2 O_1 + 4 O_2 + ...)                     (Horner from O_{m-1} down, all windows side by side)
+    and the windows are joined by Horner in 2^c -- c doublings and one addition per window -- then converted to affine.
+    (X, Y, Z) Jacobian = (X Z : Y : Z^3) homogeneous.  Output: the affine sum and its Z (zero for the point at infinity)."""
     six = kind == "msmfin2"
     F = Fld2(b, T) if six else Fld1(b)
     C = Curve(F)
-    def coord(w, j):
-        if six:
-            return (b.lin(b.inp(BUF_SOA3, soa_el(2 * j, w, True)), True), b.lin(b.inp(BUF_SOA3, soa_el(2 * j + 1, w, True)), True))
-        return b.lin(b.inp(BUF_SOA3, soa_el(j, w, False)), True)
-    W = []
-    for w in range(nwin):
-        X, Y, Z = coord(w, 0), coord(w, 1), coord(w, 2)
-        z2 = F.lin(F.sqr(Z))
-        W.append((F.lin(F.mul(X, Z)), Y, F.lin(F.mul(z2, Z))))
+    # every input is loaded -- and converted -- BEFORE the first chain is written down: the scheduler places a job at the earliest
+    # level of its kind with room and opens new levels only at the end, so a load that no longer fits an early LOAD level would land
+    # behind everything created so far and serialise the windows
+    nrec = (m + 2) * nwin
+    if six:
+        raw = [[(b.inp(BUF_SOA3, soa_el(2 * j, rec, True)), b.inp(BUF_SOA3, soa_el(2 * j + 1, rec, True))) for j in range(3)] for rec in range(nrec)]
+        red = [[(b.lin(c[0], True), b.lin(c[1], True)) for c in r] for r in raw]
+    else:
+        raw = [[b.inp(BUF_SOA3, soa_el(j, rec, False)) for j in range(3)] for rec in range(nrec)]
+        red = [[b.lin(c, True) for c in r] for r in raw]
+    z2s = [F.lin(F.sqr(r[2])) for r in red]
+    pts = [(F.lin(F.mul(r[0], r[2])), r[1], F.lin(F.mul(z2, r[2]))) for r, z2 in zip(red, z2s)]
+    def point(rec):
+        return pts[rec]
+    W = [point((m + 1) * nwin + w) for w in range(nwin)]
+    for l in range(m - 2, -1, -1):                                          # all windows step by step: their chains share levels
+        W = [C.add(C.dbl(W[w]), point((l + 2) * nwin + w)) for w in range(nwin)]
+    for _ in range(logk):
+        W = [C.dbl(t) for t in W]
+    W = [C.add(W[w], point(nwin + w)) for w in range(nwin)]
+    W = [C.add(W[w], C.neg(point(w))) for w in range(nwin)]
     R = W[nwin - 1]
     for w in range(nwin - 2, -1, -1):
         for _ in range(c):

@@ -384,3 +384,36 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_fold_pair(const i32* src, i32*
     if (j + half < seg) r = jac_add(r, pair_soa_load(src, seg * nwin, w * seg + j + half, par));
     if (t0 < total) pair_soa_store(dst, half * nwin, t, par, r);
 }
+// lane-pair forms of the multiplication-free running-sum pass and of its fold (msm.inc)
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_chunk2_pair(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct) {
+    const int par = threadIdx.x & 1;
+    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t t = t0 < nct ? t0 : nct - 1;
+    const size_t per_win = ((size_t)1 << c) / K;
+    const size_t w = t / per_win, j = t % per_win;
+    const size_t lo = j * K;
+    P2::G2JacP running = jac_zero<P2::Fp2S>(), local = jac_zero<P2::Fp2S>();
+#pragma unroll 1
+    for (int k = K - 1; k >= 0; k--) {
+        running = jac_add_i(running, pair_soa_load(buckets, nb, (w << c) + lo + k, par));
+        local = jac_add_i(local, running);
+    }
+    if (t0 < nct) { pair_soa_store(out, 2 * nct, t, par, running); pair_soa_store(out, 2 * nct, nct + t, par, local); }
+}
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_fold2_pair(const i32* src, i32* dst, int narr, int nwin, size_t len) {
+    const int par = threadIdx.x & 1;
+    const size_t half = len / 2, per_arr = (size_t)nwin * half, total = (size_t)(narr + 1) * per_arr;
+    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t t = t0 < total ? t0 : total - 1;
+    const size_t a = t / per_arr, r = t % per_arr, w = r / half, j = r % half;
+    const size_t nsrc = (size_t)narr * nwin * len;
+    // (uniform per pair; a wave mixes both kinds only at an array boundary)
+    P2::G2JacP v;
+    if (a < (size_t)narr) {
+        const size_t base = (a * nwin + w) * len + 2 * j;
+        v = jac_add(pair_soa_load(src, nsrc, base, par), pair_soa_load(src, nsrc, base + 1, par));
+    } else {
+        v = pair_soa_load(src, nsrc, (size_t)w * len + 2 * j + 1, par);
+    }
+    if (t0 < total) pair_soa_store(dst, total, t, par, v);
+}

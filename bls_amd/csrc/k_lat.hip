@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
                         for (int i = 0; i < NL; i++) y.v[i] = raw[((size_t)e * NL + i) * cnt + idx];
                     } else if (e == 0) y = C_ONE;
                 } else if (bsel == 10) {                                           // coordinate of a Jacobian SoA record (msm.inc, curve.cuh jac_soa_store) at buffer 3
-                    const u32 e = el & 7u, w = (el >> 3) & 31u, ncoord = (el >> 8) & 1u ? 6u : 3u;
+                    const u32 e = el & 7u, w = (el >> 3) & 255u, ncoord = (el >> 11) & 1u ? 6u : 3u;
                     const i32* raw = reinterpret_cast<const i32*>(b3);
                     const size_t cnt = s3;                                         // records in the buffer = word stride
 #pragma unroll

@@ -142,31 +142,37 @@ def test_subgroup_programs(progs):
 
 
 def test_msm_final_programs():
-    """Horner over the window sums of the endomorphism MSM (8 windows of 16 bits for G1, 4 for G2) given in Jacobian
-    coordinates: sum_w 2^(16 w) W_w, affine"""
+    """the tail of the MSM over decomposed scalars: per window the fold's 2 + m sums (X, L, O_0 .. O_{m-1}) in Jacobian coordinates ->
+    sum_w 2^(16 w) (L_w - X_w + 8 sum_l 2^l O_{w,l}), affine"""
     xs = P.XORShift(31)
+    m, logk = 13, 3
     for kind, Fd, gen, six in (("msmfin1", P.F1, P.G1_GEN, False), ("msmfin2", P.F2, P.G2_GEN, True)):
         p = G.schedule(G.build_program(kind))
-        ks = [P.rand_fr(xs) for _ in range(4 if six else 8)]
-        ks[3] = 0                                                              # an empty window: the point at infinity
+        nwin = 4 if six else 8
         inputs, total = {}, 0
-        for w, k in enumerate(ks):
-            total += k << (16 * w)
-            if k == 0:
-                coords = (0, 1, 0) if not six else ((0, 0), (1, 0), (0, 0))   # what the loader produces for a flagged record
-            else:
-                a = P.jac_to_affine(Fd, P.affine_mul(Fd, gen, k))
-                z = P.rand_int(xs, P.Q - 1) + 1                                # a random Jacobian representative (x z^2, y z^3, z)
-                if six:
-                    zz = (z, 0); z2 = P.fq2_sqr(zz); z3 = P.fq2_mul(z2, zz)
-                    coords = (P.fq2_mul(a[0], z2), P.fq2_mul(a[1], z3), zz)
+        for w in range(nwin):
+            ks = [P.rand_fr(xs) for _ in range(m + 2)]                          # X, L, O_0 .. O_{m-1} as multiples of the generator
+            if w == 1:
+                ks[0] = 0; ks[5] = 0                                            # empty sums: the point at infinity
+            wt = (ks[1] - ks[0] + (1 << logk) * sum(ks[2 + l] << l for l in range(m))) % P.R_ORDER
+            total = (total + (wt << (16 * w))) % P.R_ORDER
+            for a, k in enumerate(ks):
+                rec = a * nwin + w
+                if k == 0:
+                    coords = (0, 1, 0) if not six else ((0, 0), (1, 0), (0, 0))   # what the loader produces for a flagged record
                 else:
-                    coords = (a[0] * z * z % P.Q, a[1] * z * z * z % P.Q, z)
-            for j, cj in enumerate(coords):
-                if six:
-                    inputs[G.soa_el(2 * j, w, True)] = cj[0]; inputs[G.soa_el(2 * j + 1, w, True)] = cj[1]
-                else:
-                    inputs[G.soa_el(j, w, False)] = cj
+                    pt = P.jac_to_affine(Fd, P.affine_mul(Fd, gen, k))
+                    z = P.rand_int(xs, P.Q - 1) + 1                                # a random Jacobian representative (x z^2, y z^3, z)
+                    if six:
+                        zz = (z, 0); z2 = P.fq2_sqr(zz); z3 = P.fq2_mul(z2, zz)
+                        coords = (P.fq2_mul(pt[0], z2), P.fq2_mul(pt[1], z3), zz)
+                    else:
+                        coords = (pt[0] * z * z % P.Q, pt[1] * z * z * z % P.Q, z)
+                for j, cj in enumerate(coords):
+                    if six:
+                        inputs[G.soa_el(2 * j, rec, True)] = cj[0]; inputs[G.soa_el(2 * j + 1, rec, True)] = cj[1]
+                    else:
+                        inputs[G.soa_el(j, rec, False)] = cj
         out = G.simulate(p, {G.BUF_SOA3: inputs})
         want = P.jac_to_affine(Fd, P.affine_mul(Fd, gen, total % P.R_ORDER))
         if six:
