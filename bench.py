@@ -350,6 +350,34 @@ def verify_bench(E, steps=5, warmup=1, n=65536):
             out[group + "_roofline"] = roofline_of(prof, n, BYTES["verify"], E.ctr, lambda k: 2 * n if k.endswith("_pair") else n)
             if world == 1 and E.cpu:
                 out[group + "_cpu_baseline"] = cpu_verify(group, packed, pks, sigs)
+        if group == "g2pubs":
+            # the same tuples with the public keys PREPARED (blsmi 0.4): one 24 KB table per tuple -- every key distinct as far as the
+            # memory system is concerned (n tables = 1.6 GB read per step); the timed step has the same collective as above
+            tab = torch.empty(n * engine.G2_PREPARED_BYTES, dtype=torch.uint8, device=dev)
+            t0 = time.perf_counter()
+            engine.g2_prepare_batch_dev(d[2].data_ptr(), n, tab.data_ptr())
+            t_prep = time.perf_counter() - t0
+
+            def local_step_prepared():
+                engine.g2pubs_verify_batch_prepared_dev(d[0].data_ptr(), d[1].data_ptr(), tab.data_ptr(), 0, d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+
+            def step_prepared():
+                d_ok.zero_()
+                local_step_prepared()
+                if E.use_dist:
+                    full.zero_()
+                    full[rank * n // 8:(rank + 1) * n // 8] = (d_ok.view(-1, 8).to(torch.int32) * weights).sum(dim=1, dtype=torch.int32)
+                    dist.all_reduce(full, op=dist.ReduceOp.SUM)
+            dtp = timed_steps(E, step_prepared, steps, warmup)
+            assert bool(d_ok.all().item()), "synthetic tuples must all verify with prepared keys"
+            pk = {"verifies_per_s": round(world * n * steps / dtp, 1), "ms_per_step": round(dtp / steps * 1e3, 3),
+                  "prepare_ms_once": round(t_prep * 1e3, 3), "table_bytes_per_key": engine.G2_PREPARED_BYTES,
+                  "note": "G2AffineToPrepared once per key into HBM (blsmi_g2_prepare_batch_dev), then Miller loops that read a key's 68 line triples instead of "
+                          "recomputing them; here every tuple has its own table (no reuse in cache); verdicts identical to the unprepared path (tests/test_gpu_prepared.py)"}
+            if rank == 0:
+                pk["roofline"] = roofline_of(profiled(E.lib, local_step_prepared), n, BYTES["verify"], E.ctr, lambda k: 2 * n if k.endswith("_pair") else n)
+            out["g2pubs_prepared_keys"] = pk
+            del tab
     out["note"] = "all tuples valid; inputs resident in HBM; hash-to-curve on the GPU included; 1 Verify = 2 Miller-loop pairs + 1 final exponentiation + 1 hash"
     return out
 
@@ -419,6 +447,23 @@ def aggregate_dev_bench(E, group, n, reps=3):
            "roofline": roofline_of(prof, n, BYTES[group + "_aggregate"], E.ctr),
            "note": "messages (32 bytes each), offsets and keys resident in HBM; duplicate-message rejection on the device (keyed open-addressing table, exact comparisons) included; "
                    "n Miller loops (two tuples per loop) + Fq12 product tree + ONE final exponentiation; verdict True, and False with one key replaced"}
+    if group == "g2pubs":
+        # the same aggregate over PREPARED keys, one table per signer: n x 24 704 bytes resident (25.9 GB at n = 2^20 -- what 288 GB of HBM are for)
+        del bad
+        tab = torch.empty(n * engine.G2_PREPARED_BYTES, dtype=torch.uint8, device=dev)
+        engine.g2_prepare_batch_dev(d_k.data_ptr(), n, tab.data_ptr())
+
+        def step_prepared():
+            res["okp"] = engine.g2pubs_verify_aggregate_prepared_dev(d_m.data_ptr(), d_o.data_ptr(), tab.data_ptr(), 0, agg, n)
+        dtp = timed_steps(E, step_prepared, reps, 1)
+        assert res["okp"] is True, "the synthetic aggregate must verify with prepared keys"
+        profp = profiled(E.lib, step_prepared)
+        idx = torch.arange(n, dtype=torch.int32, device=dev); idx[n // 3] = n // 3 + 1
+        assert engine.g2pubs_verify_aggregate_prepared_dev(d_m.data_ptr(), d_o.data_ptr(), tab.data_ptr(), idx.data_ptr(), agg, n) is False, "one wrong key must fail the aggregate"
+        out["prepared_keys"] = {"ms": round(dtp / reps * 1e3, 2), "signatures_per_s": round(n * reps / dtp, 1), "tables_GB": round(n * engine.G2_PREPARED_BYTES / 1e9, 2),
+                                "roofline": roofline_of(profp, n, BYTES[group + "_aggregate"], E.ctr),
+                                "note": "one prepared table per signer resident in HBM; the Miller loops read the lines (k_miller1x2_prep_pair)"}
+        del tab
     return out, (packed, allpk, agg)
 
 
@@ -655,6 +700,26 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an extra must never cost the headline line
             extras[name] = {"error": repr(e)[:400]}
     agg_dev_inputs = {}
+
+    def pairing_prepared_leg():
+        """the headline workload with the G2 arguments PREPARED (bls.MillerLoop's own calling convention: MillerLoopItem{P, *G2Prepared}): one
+        table per tuple resident in HBM; output must equal the headline run's bit for bit"""
+        a, b, o = bufs[0]
+        tab = torch.empty(n * engine.G2_PREPARED_BYTES, dtype=torch.uint8, device=E.dev)
+        t0 = time.perf_counter()
+        engine.g2_prepare_batch_dev(b.data_ptr(), n, tab.data_ptr())
+        t_prep = time.perf_counter() - t0
+        o2 = torch.zeros_like(o)
+
+        def stp():
+            engine.pairing_batch_prepared_dev(a.data_ptr(), tab.data_ptr(), 0, o2.data_ptr(), n)
+        dtp = timed_steps(E, stp, args.steps, 1)
+        assert torch.equal(o, o2), "pairings over prepared keys differ from the headline run"
+        return {"pairings_per_s": round(n * args.steps / dtp, 1), "ms_per_step": round(dtp / args.steps * 1e3, 3), "prepare_ms_once": round(t_prep * 1e3, 3),
+                "prepare_points_per_s": round(n / t_prep, 1), "roofline": roofline_of(profiled(lib, stp), n, BYTES["pairing"], E.ctr, lambda k: 2 * n),
+                "note": "G2AffineToPrepared once (blsmi_g2_prepare_batch_dev, the reference's BenchmarkG2Prepare shape), then Pairing over the resident tables; same Fq12 bits as the headline"}
+    if rank == 0 and ndev == 1 and world == 1 and not args.no_verify_extra:
+        leg("pairing_prepared", pairing_prepared_leg)
     if not args.no_verify_extra:
         if ndev == 1:                                                      # rank style (or one device): all ranks take part in the collectives
             leg("verify_bench", lambda: verify_bench(E))
@@ -744,6 +809,8 @@ def main():
             cfg["0"] = line["config0"]
         cfg["1"] = {"workload": line["config"]["workload"], "value": line["value"], "unit": "pairings/s", "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "frac", "traffic")} if roof else None,
                     "cpu_baseline": {k: line["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in line else None}
+        if "pairing_prepared" in line and "error" not in line["pairing_prepared"]:
+            cfg["1"]["prepared_g2"] = {k: line["pairing_prepared"][k] for k in ("pairings_per_s", "ms_per_step", "prepare_points_per_s")}
         if "msm_bench" in line and "error" not in line["msm_bench"]:
             cfg["2"] = {"workload": "2^20-point G1 and G2 scalar multiplication + MSM, resident", **{k: line["msm_bench"][k] for k in ("g1_mul", "g1_msm", "g2_mul", "g2_msm") if k in line["msm_bench"]}}
         if "aggregate_bench" in line and "error" not in line["aggregate_bench"]:

@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "lat_programs.h"
 #include "util_dev.h"
+#include "prepared.h"
 #include <functional>
 #include <mutex>
 #include <condition_variable>
@@ -57,7 +58,7 @@ std::mutex g_mu;
 std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
-char g_version[200] = "blsmi 0.3 (uninitialised)";
+char g_version[200] = "blsmi 0.4 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
@@ -271,7 +272,7 @@ int ensure_init_list(const int* devs, int ndev) {
     HIPCHK(hipSetDevice(g_dev[0].id));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g_dev[0].id));
-    snprintf(g_version, sizeof g_version, "blsmi 0.3 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_have_comm ? " rccl" : "");
+    snprintf(g_version, sizeof g_version, "blsmi 0.4 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_have_comm ? " rccl" : "");
     g_ready = true;
     return BLSMI_OK;
 }

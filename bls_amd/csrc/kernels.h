@@ -31,6 +31,14 @@ __global__ void k_final_exp_pair(const i32* fbuf, u64* out, size_t n, int mode);
 __global__ void k_miller1x2_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n, size_t m);
 __global__ void k_miller2_pair(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
 __global__ void k_final_exp_is_one_pair(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+// k_prepared_pair.hip
+__global__ void k_g2_prepare_pair(const u8* g2, i32* tables, size_t n);
+__global__ void k_prepared_export(const i32* tables, u64* out, size_t n);
+__global__ void k_flag_prepared(const i32* tables, const u32* key_idx, const u8* sigs, int sig_words, const u8* in_flags, u8* flags, int* any_flag, size_t n);
+__global__ void k_prepared_gather_keys(const i32* tables, const u32* key_idx, u32* pks, size_t n);
+__global__ void k_miller1_prep_pair(const u8* g1, const i32* tables, const u32* key_idx, i32* fbuf, size_t n);
+__global__ void k_miller2_prep_pair(const u8* sigs, const u8* h, const i32* tables, const u32* key_idx, i32* fbuf, size_t n, const i32* pre_gen);
+__global__ void k_miller1x2_prep_pair(const u8* g1, const i32* tables, const u32* key_idx, i32* fbuf, size_t n, size_t m);
 // k_lat.hip
 __global__ void k_lat(const u8* prog, const u8* b0, size_t s0, const u8* b1, size_t s1, const u8* b2, size_t s2,
                                                 const u8* b3, size_t s3, const u8* flags, u8* ok, u64* out, size_t n);

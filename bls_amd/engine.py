@@ -169,6 +169,81 @@ def verify_aggregate_with_domain_dev(d_msgs32, d_domain, d_pks, sig, n, stream=0
     return bool(ok.value)
 
 
+# ---- prepared public keys (g2pubs): G2AffineToPrepared once, Miller loops that read the lines (blsmi 0.4) ----
+G2_PREPARED_BYTES = 24704
+
+
+def g2_prepare_batch_dev(d_g2_aff, n, d_prepared, stream=0):
+    """n resident G2 points -> n tables of G2_PREPARED_BYTES at d_prepared (device)."""
+    _check(_lib().blsmi_g2_prepare_batch_dev(C.c_void_p(d_g2_aff), C.c_size_t(n), C.c_void_p(d_prepared), C.c_void_p(stream)), "blsmi_g2_prepare_batch_dev")
+
+
+def g2_prepared_export_dev(d_prepared, n, d_out, stream=0):
+    """the reference's G2Prepared.coeffs of n tables: n x 68 x 3 x 12 uint64 at d_out (device)."""
+    _check(_lib().blsmi_g2_prepared_export_dev(C.c_void_p(d_prepared), C.c_size_t(n), C.c_void_p(d_out), C.c_void_p(stream)), "blsmi_g2_prepared_export_dev")
+
+
+def g2_prepare_batch(g2_aff, n):
+    """G2AffineToPrepared (g2.go:639-801) of n host points: (n, 68, 3, 12) uint64 -- coefficient triples of FQ2 as c0 | c1 limbs."""
+    q = _u8(g2_aff, 192 * n)
+    out = np.empty((n, 68, 3, 12), dtype=np.uint64)
+    _check(_lib().blsmi_g2_prepare_batch(_p8(q), C.c_size_t(n), out.ctypes.data_as(_u64p)), "blsmi_g2_prepare_batch")
+    return out
+
+
+class PreparedKeys:
+    """n g2pubs public keys prepared into tables the library owns (blsmi_g2_prepared_create); .ptr is the device pointer."""
+
+    def __init__(self, g2_aff, n):
+        q = _u8(g2_aff, 192 * n)
+        h = C.c_void_p(0)
+        _check(_lib().blsmi_g2_prepared_create(_p8(q), C.c_size_t(n), C.byref(h)), "blsmi_g2_prepared_create")
+        self.ptr, self.n = h.value, n
+
+    def close(self):
+        if self.ptr:
+            _check(_lib().blsmi_g2_prepared_destroy(C.c_void_p(self.ptr)), "blsmi_g2_prepared_destroy")
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def g2pubs_verify_batch_prepared(msgs, prepared, key_idx, sigs, inf_flags=None):
+    """g2pubs.Verify x n, host buffers, keys prepared (a PreparedKeys or a device pointer): (ok bool array, packed bitmap)."""
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    ptr = prepared.ptr if isinstance(prepared, PreparedKeys) else prepared
+    idx = None if key_idx is None else np.ascontiguousarray(key_idx, dtype=np.uint32)
+    s = _u8(sigs, 96 * n)
+    fl = None if inf_flags is None else _u8(inf_flags, n)
+    ok = np.empty(n, dtype=np.uint8)
+    bm = np.empty((n + 7) // 8, dtype=np.uint8)
+    _check(_lib().blsmi_g2pubs_verify_batch_prepared(_p8(buf), off.ctypes.data_as(_u64p), C.c_void_p(ptr), None if idx is None else idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    _p8(s), _p8(fl), _p8(ok), _p8(bm), C.c_size_t(n)), "blsmi_g2pubs_verify_batch_prepared")
+    return ok.astype(bool), bm
+
+
+def pairing_batch_prepared_dev(d_g1, d_prepared, d_key_idx, d_out, n, stream=0):
+    _check(_lib().blsmi_pairing_batch_prepared_dev(C.c_void_p(d_g1), C.c_void_p(d_prepared), C.c_void_p(d_key_idx or 0), C.c_void_p(d_out), C.c_size_t(n), C.c_void_p(stream)), "blsmi_pairing_batch_prepared_dev")
+
+
+def g2pubs_verify_batch_prepared_dev(d_msgs, d_off, d_prepared, d_key_idx, d_sigs, d_inf, d_ok, n, stream=0):
+    _check(_lib().blsmi_g2pubs_verify_batch_prepared_dev(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_prepared), C.c_void_p(d_key_idx or 0), C.c_void_p(d_sigs),
+                                                        C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "blsmi_g2pubs_verify_batch_prepared_dev")
+
+
+def g2pubs_verify_aggregate_prepared_dev(d_msgs, d_off, d_prepared, d_key_idx, sig, n, stream=0):
+    s = _u8(sig, 96)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g2pubs_verify_aggregate_prepared_dev(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_prepared), C.c_void_p(d_key_idx or 0), _p8(s), C.c_size_t(n),
+                                                            C.byref(ok), C.c_void_p(stream)), "blsmi_g2pubs_verify_aggregate_prepared_dev")
+    return bool(ok.value)
+
+
 # ---- groups ----------------------------------------------------------------------------------------
 def _mul(fn, pb, pts, scalars, n):
     p, s = _u8(pts, pb * n), _u8(scalars, 32 * n)

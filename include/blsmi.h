@@ -55,7 +55,8 @@ int blsmi_shard_count(void);
 void blsmi_shutdown(void);
 /* "blsmi <ABI version> gfx950 CUs=.. devices=.. shards=..".  ABI history: 0.2 gave blsmi_g{1,2}pubs_aggregate_partial its trailing
  * `int *bad` argument (a caller built against the 5-argument prototype of 0.1 must be rebuilt); 0.3 adds the *_dev forms of
- * mul / sum / msm / verify_aggregate and changes no existing prototype.  Check the prefix before binding by hand. */
+ * mul / sum / msm / verify_aggregate and changes no existing prototype; 0.4 adds the prepared-key entry points.  Check the prefix
+ * before binding by hand. */
 const char *blsmi_version(void);
 
 /* ---- pairing (replaces bls.Pairing, pairing.go:132-136; BASELINE config 2) -------------------
@@ -153,6 +154,38 @@ int blsmi_g1pubs_verify_with_domain_batch(const uint8_t *msgs32, const uint8_t d
                                           const uint8_t *inf_flags, uint8_t *ok, uint8_t *ok_bitmap, size_t n);
 int blsmi_g1pubs_verify_aggregate_with_domain(const uint8_t *msgs32, const uint8_t domain[8], const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
 int blsmi_g1pubs_verify_aggregate_common_with_domain(const uint8_t msg32[32], const uint8_t domain[8], const uint8_t *pks, const uint8_t sig[192], size_t n, int *ok);
+
+/* ---- prepared public keys (g2pubs; added in blsmi 0.4) ---------------------------------------------------------------
+ * bls.MillerLoop takes its G2 arguments PREPARED (MillerLoopItem{P *G1Affine, Q *G2Prepared}, pairing.go:4-14;
+ * G2AffineToPrepared, g2.go:639-801: the 68 line-coefficient triples that depend on Q alone), and g2pubs.Verify prepares the
+ * same public key again on every call (CompareTwoPairings, pairing.go:140-147).  A verifier that meets the same keys again and
+ * again prepares them ONCE into device memory -- BLSMI_G2_PREPARED_BYTES per key, one table after the other -- and hands the
+ * tables to the *_prepared_dev entry points, whose Miller loops read a key's lines instead of recomputing them.
+ * d_key_idx: n x uint32, tuple t uses table d_key_idx[t]; NULL: tuple t uses table t.  A key given as the all-zero record
+ * (the point at infinity) keeps that mark in its table: verdict 0, as in the unprepared forms.  Every result is identical to the
+ * unprepared entry point on the same keys.  All buffers on ONE of the library's devices; `stream` as in blsmi_pairing_batch_dev. */
+#define BLSMI_G2_PREPARED_BYTES 24704
+int blsmi_g2_prepare_batch_dev(const void *d_g2_aff /* n*192 */, size_t n, void *d_prepared /* n*BLSMI_G2_PREPARED_BYTES */, void *stream);
+/* the reference's G2Prepared.coeffs of n prepared keys: per key 68 x [3]FQ2, each FQ2 as c0 | c1, 6 x uint64 Montgomery limbs each */
+int blsmi_g2_prepared_export_dev(const void *d_prepared, size_t n, void *d_out /* n*68*3*12 uint64 */, void *stream);
+/* G2AffineToPrepared of n host points straight into that representation (BenchmarkG2Prepare, pairing_test.go:60-81) */
+int blsmi_g2_prepare_batch(const uint8_t *g2_aff /* n*192 */, size_t n, uint64_t *out_coeffs /* n*68*3*12 */);
+/* For callers without a HIP runtime of their own (the cgo shim): prepare n HOST keys into tables the library allocates on one of
+ * its devices; *handle is the device pointer to pass as d_prepared.  _destroy waits for that device to go idle, then frees. */
+int blsmi_g2_prepared_create(const uint8_t *g2_aff /* n*192 */, size_t n, void **handle);
+int blsmi_g2_prepared_destroy(void *handle);
+/* n independent g2pubs.Verify()s with messages, signatures, key indices and results in HOST memory and the keys prepared;
+ * arguments as blsmi_g2pubs_verify_batch with (d_prepared, key_idx) in the place of pks.  Runs on the device that holds the
+ * tables (not split over devices). */
+int blsmi_g2pubs_verify_batch_prepared(const uint8_t *msgs, const uint64_t *msg_off, const void *d_prepared, const uint32_t *key_idx /* n, may be NULL */,
+                                       const uint8_t *sigs, const uint8_t *inf_flags, uint8_t *ok, uint8_t *ok_bitmap, size_t n);
+/* Pairing(P_t, Q_t) with Q_t prepared; output as blsmi_pairing_batch_dev */
+int blsmi_pairing_batch_prepared_dev(const void *d_g1_aff, const void *d_prepared, const void *d_key_idx, void *d_out_fq12, size_t n, void *stream);
+/* g2pubs.Verify x n / Signature.VerifyAggregate with prepared public keys; otherwise as the *_dev forms below */
+int blsmi_g2pubs_verify_batch_prepared_dev(const void *d_msgs, const void *d_off, const void *d_prepared, const void *d_key_idx,
+                                           const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
+int blsmi_g2pubs_verify_aggregate_prepared_dev(const void *d_msgs, const void *d_off, const void *d_prepared, const void *d_key_idx,
+                                               const uint8_t sig[96], size_t n, int *ok, void *stream);
 
 /* Multi-GPU VerifyAggregate: each rank computes the product of its shard's Miller loops
  * prod_i ML(H(m_i), pk_i) (no final exponentiation) as one Fq12 in the wire format; the ranks all-gather
