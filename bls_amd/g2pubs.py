@@ -7,7 +7,8 @@ pairing and hash operation runs in the HIP kernels of libblsmi.so (no CPU fallba
     sig.VerifyAggregateCommon(pubKeys, msg)     g2pubs/bls.go:275-278
     AggregateSignatures / AggregatePublicKeys   g2pubs/bls.go:165-192
     DeserializeSignature / DeserializePublicKey g2pubs/bls.go:33-40, 89-96
-plus VerifyBatch, the batch form the one-tuple-per-call Go API lacks.
+plus VerifyBatch, the batch form the one-tuple-per-call Go API lacks, and PrepareKeys / VerifyBatchPrepared: public keys run
+through G2AffineToPrepared (g2.go:639-801) ONCE into tables resident on the device instead of on every Verify (pairing.go:140-147).
 """
 from . import engine
 from ._groups import DeserializeError, Point, point_sum  # noqa: F401
@@ -97,6 +98,35 @@ def VerifyBatch(msgs, pubs, sigs):
         return []
     flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
     ok, _ = engine.g2pubs_verify_batch(msgs, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
+    return [bool(x) for x in ok]
+
+
+class PreparedKeys:
+    """The reference's G2Prepared of n public keys, kept in device memory the library owns."""
+
+    def __init__(self, pubs):
+        self.n = len(pubs)
+        self._h = engine.PreparedKeys(b"".join(p.p.bytes_or_zero() for p in pubs), self.n)   # all-zero record = infinity: verdict False
+
+    def Close(self):
+        self._h.close()
+
+
+def PrepareKeys(pubs):
+    return PreparedKeys(pubs)
+
+
+def VerifyBatchPrepared(msgs, keys, key_idx, sigs):
+    """[Verify(msgs[i], pubs[key_idx[i]], sigs[i]) for i] with pubs = the keys given to PrepareKeys; same verdicts as VerifyBatch."""
+    n = len(msgs)
+    if not (len(key_idx) == len(sigs) == n):
+        raise ValueError("length mismatch")
+    if n == 0:
+        return []
+    if any(not 0 <= int(k) < keys.n for k in key_idx):
+        raise IndexError("key index out of range")
+    flags = [2 if s.s.infinity else 0 for s in sigs]
+    ok, _ = engine.g2pubs_verify_batch_prepared(msgs, keys._h, key_idx, b"".join(s.s.bytes_or_zero() for s in sigs), flags)
     return [bool(x) for x in ok]
 
 

@@ -208,3 +208,24 @@ def test_library_owned_tables_and_the_host_form(eng):
     assert np.array_equal(ok2, ref2)
     pk.close()
     pk.close()                                                             # idempotent
+
+
+def test_host_mirror_prepare_keys(eng):
+    """bls_amd.g2pubs.PrepareKeys / VerifyBatchPrepared against VerifyBatch and the oracle, a key at infinity among them"""
+    from bls_amd import g2pubs as G
+    xs = P.XORShift(9500)
+    sks = [sk_bytes(xs) for _ in range(4)]
+    pubs = [G.PrivToPub(s) for s in sks] + [G.NewAggregatePubkey()]       # the last one: the zero point
+    msgs = [b"mirror %d" % i for i in range(10)]
+    idx = [i % 4 for i in range(10)]
+    sigs = [G.Sign(m, sks[j]) for m, j in zip(msgs, idx)]
+    keys = G.PrepareKeys(pubs)
+    assert G.VerifyBatchPrepared(msgs, keys, idx, sigs) == [True] * 10 == G.VerifyBatch(msgs, [pubs[j] for j in idx], sigs)
+    idx2 = list(idx); idx2[3] = (idx2[3] + 1) % 4; idx2[6] = 4
+    got = G.VerifyBatchPrepared(msgs, keys, idx2, sigs)
+    assert got == [i not in (3, 6) for i in range(10)] == G.VerifyBatch(msgs, [pubs[j] for j in idx2], sigs)
+    assert RC.g2pubs.verify(msgs[3], pubs[idx2[3]].p.bytes_or_zero(), sigs[3].s.bytes_or_zero()) is False
+    with pytest.raises(IndexError):
+        G.VerifyBatchPrepared(msgs, keys, [5] * 10, sigs)
+    keys.Close()
+
