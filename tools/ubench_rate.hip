@@ -3,6 +3,7 @@
 // hipcc --offload-arch=gfx950 -O2 -w -o ubench_rate ubench_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef unsigned u32;
 typedef unsigned long long u64;
 #define STR2(x) #x
@@ -41,9 +42,10 @@ template <int OP, int WIDE> __global__ void __launch_bounds__(64) k_rate(u32* ou
     }
     out[blockIdx.x * 64 + threadIdx.x] = a + b + c + d + (u32)(A + B + C + D);
 }
+static int g_scale = 1;
 template <int OP, int WIDE> void run(const char* name, u32* out, int ncu, int waves_per_simd) {
     const int per_rept = WIDE ? 4 : (OP == 12 ? 2 : 1);
-    const int iters = 512 / per_rept;
+    const int iters = g_scale * 512 / per_rept;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
@@ -56,10 +58,15 @@ template <int OP, int WIDE> void run(const char* name, u32* out, int ncu, int wa
     printf("%-34s %s waves/SIMD=%d  %7.3f ms  %5.2f cycles per instruction per wave, %5.2f per SIMD issue slot (2.4 GHz)\n", name, WIDE ? "4 chains" : "1 chain ", waves_per_simd, best,
            best * 1e-3 * 2.4e9 / instr_per_wave, best * 1e-3 * 2.4e9 / instr_per_wave / waves_per_simd);
 }
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     u32* out; hipMalloc(&out, sizeof(u32) * p.multiProcessorCount * 64 * 64);
     const int n = p.multiProcessorCount;
+    if (argc > 1) {                                                        // sustained: ubench_rate <scale>  (scale x 1 ms per line)
+        g_scale = atoi(argv[1]);
+        for (int rep = 0; rep < 3; rep++) { run<7, 1>("v_mad_i64_i32 sustained", out, n, 2); run<1, 1>("v_add_u32 sustained", out, n, 2); }
+        return 0;
+    }
     for (int w : {1, 2, 4}) {
         run<0, 0>("v_add_u32 literal", out, n, w); run<1, 0>("v_add_u32", out, n, w); run<2, 0>("v_and_b32", out, n, w); run<3, 0>("v_lshrrev_b32", out, n, w);
         run<4, 0>("v_add3_u32", out, n, w); run<5, 0>("v_mul_lo_u32", out, n, w); run<6, 0>("v_mad_u64_u32", out, n, w); run<7, 0>("v_mad_i64_i32", out, n, w);
