@@ -5,6 +5,35 @@
 #include "device_io.cuh"
 #include <cstdio>
 namespace P2 = blsmi::pairl;
+#define AS5 __attribute__((address_space(5)))
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T fetch5(const AS5 T* src) {
+    T dst; const AS5 v4i* p = (const AS5 v4i*)src; v4i* q = (v4i*)&dst;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = p[i];
+    return dst;
+}
+template <class T> __device__ __forceinline__ void store5(AS5 T* dst, const T& src) {
+    const v4i* p = (const v4i*)&src; AS5 v4i* q = (AS5 v4i*)dst;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = p[i];
+}
+__device__ long long g_ts[8];
+__device__ __noinline__ void dbl_step_p(AS5 P2::G2Proj* r, AS5 P2::Fp2S* o) {
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    P2::G2Proj rr = fetch5(r);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    P2::Fp2S a0, a1, a2;
+    P2::doubling_step_h_i(rr, a0, a1, a2);
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t2 = __builtin_amdgcn_s_memtime();
+    store5(r, rr); store5(o, a0); store5(o + 1, a1); store5(o + 2, a2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t3 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 7 && threadIdx.x == 0) { g_ts[0] = t0; g_ts[1] = t1; g_ts[2] = t2; g_ts[3] = t3; }
+}
 template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, int iters, int seed) {
     P2::Fp2S a, b;
     for (int i = 0; i < NL; i++) { a.c.v[i] = (seed * 7 + i * 131 + threadIdx.x * 17) & MASK; b.c.v[i] = (seed * 3 + i * 71 + threadIdx.x) & MASK; }
@@ -23,7 +52,7 @@ template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, in
             a = P2::fp2_store(P2::fp2_mul(a, b));
         }
     }
-    if (MODE == 3 || MODE == 4 || MODE == 5) {
+    if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 9 || MODE == 10) {
         P2::Fp12S f = P2::fp12_one();
         f.c0.c1 = a; f.c1.c2 = b; f.c1.c0 = a;
         P2::G2Proj r; r.x = a; r.y = b; r.z = P2::fp2_one();
@@ -32,6 +61,8 @@ template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, in
         for (int it = 0; it < iters; it++) {
             if (MODE == 3) P2::ell_sqr(f, o0, o1, o2, px, py);
             if (MODE == 4) P2::doubling_step_h(r, o0, o1, o2);
+            if (MODE == 9) P2::doubling_step_h_i(r, o0, o1, o2);
+            if (MODE == 10) { P2::Fp2S oo[3]; dbl_step_p((AS5 P2::G2Proj*)&r, (AS5 P2::Fp2S*)oo); o0 = oo[0]; o1 = oo[1]; o2 = oo[2]; }
             if (MODE == 5) { P2::doubling_step_h(r, o0, o1, o2); P2::ell_sqr(f, o0, o1, o2, px, py); }
         }
         a = P2::fp2_store(P2::fp2_add(P2::fp2_add(f.c0.c0, f.c1.c1), P2::fp2_add(r.x, o1)));
@@ -60,6 +91,10 @@ int main() {
     // cores alone (measured above): fp2 mul 3931, fp2 sqr 2905, fp mul ~2560 cycles per SIMD slot
     run<3>("ell_sqr (25 mul + 2 fp mul)", out, p.multiProcessorCount, 3547 + 25 * 874 + 2 * 596);
     run<4>("doubling_step_h (4 mul + 5 sqr)", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
+    run<9>("doubling_step_h inlined (registers)", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
+    run<10>("doubling_step_h, scratch pointers", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
+    { long long ts[8]; hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_ts), sizeof ts);
+      printf("   timeline of one call (s_memtime ticks, 100 MHz): loads %lld, compute %lld, stores+drain %lld\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]); }
     run<6>("45 scratch stores + fp2 mul", out, p.multiProcessorCount, 924 + 90);
     run<7>("45 scratch loads + fp2 mul", out, p.multiProcessorCount, 924 + 90);
     run<8>("stores + loads + fp2 mul", out, p.multiProcessorCount, 924 + 180);
