@@ -8,15 +8,15 @@ namespace P2 = blsmi::pairl;
 #define AS5 __attribute__((address_space(5)))
 typedef int v4i __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ T fetch5(const AS5 T* src) {
-    T dst; const AS5 v4i* p = (const AS5 v4i*)src; v4i* q = (v4i*)&dst;
+    T dst; const AS5 int* p = (const AS5 int*)src; int* q = (int*)&dst;
 #pragma unroll
-    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = p[i];
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) q[i] = p[i];
     return dst;
 }
 template <class T> __device__ __forceinline__ void store5(AS5 T* dst, const T& src) {
-    const v4i* p = (const v4i*)&src; AS5 v4i* q = (AS5 v4i*)dst;
+    const int* p = (const int*)&src; AS5 int* q = (AS5 int*)dst;
 #pragma unroll
-    for (unsigned i = 0; i < sizeof(T) / 16; i++) q[i] = p[i];
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) q[i] = p[i];
 }
 __device__ long long g_ts[8];
 __device__ __noinline__ void dbl_step_p(AS5 P2::G2Proj* r, AS5 P2::Fp2S* o) {
@@ -34,6 +34,59 @@ __device__ __noinline__ void dbl_step_p(AS5 P2::G2Proj* r, AS5 P2::Fp2S* o) {
     const long long t3 = __builtin_amdgcn_s_memtime();
     if (blockIdx.x == 7 && threadIdx.x == 0) { g_ts[0] = t0; g_ts[1] = t1; g_ts[2] = t2; g_ts[3] = t3; }
 }
+// ell_sqr (f <- (f * line)^2, pairing_body.inc) as PHASES: every value that must wait in memory is stored, and everything the next
+// multiplications need is fetched, at a few points where ONE memory round trip covers both; between those points the live set stays
+// below what survives an out-of-line core call (256 registers - the cores' 107), so the compiler has nothing to spill.
+namespace blsmi { namespace pairl {
+struct Pad { Fp6S bb, t, ab, x, y; };
+__device__ __noinline__ void ell_sqr_phased(AS5 Fp12S* fp, const AS5 Fp2S* o, const AS5 FpS* pxy, AS5 Pad* pad) {
+    // round trip 1: the line, the point, f.c1
+    const Fp2S o0 = fetch5(o), o1 = fetch5(o + 1), l0 = fetch5(o + 2);
+    const FpS px = fetch5(pxy), py = fetch5(pxy + 1);
+    const Fp6S fc1 = fetch5(&fp->c1);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp2S l4 = fp2_store(fp2_mul_fp(o0, py)), l1 = fp2_store(fp2_mul_fp(o1, px));
+    const Fp6S bb = fp6_store(fp6_mul_by_1(fc1, l4));
+    __builtin_amdgcn_sched_barrier(0);
+    // 2: bb out, f.c0 in
+    store5(&pad->bb, bb);
+    const Fp6S fc0 = fetch5(&fp->c0);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S s = fp6_store(fp6_add(fc0, fc1));
+    const Fp6S t = fp6_store(fp6_mul_by_01(s, l0, fp2_add(l1, l4)));
+    __builtin_amdgcn_sched_barrier(0);
+    // 3: t out, f.c0 in again
+    store5(&pad->t, t);
+    const Fp6S fc0b = fetch5(&fp->c0);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S aa = fp6_store(fp6_mul_by_01(fc0b, l0, l1));
+    __builtin_amdgcn_sched_barrier(0);
+    // 4: bb, t in
+    const Fp6S bb2 = fetch5(&pad->bb), t2 = fetch5(&pad->t);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S g0 = fp6_store(fp6_add(fp6_mul_nr(bb2), aa)), g1 = fp6_store(fp6_sub(fp6_sub(t2, aa), bb2));
+    const Fp6S x = fp6_store(fp6_add(fp6_mul_nr(g1), g0)), y = fp6_store(fp6_add(g0, g1));
+    // 5: x, y out (drained at the next core call)
+    store5(&pad->x, x); store5(&pad->y, y);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S ab = fp6_store(fp6_mul(g0, g1));
+    __builtin_amdgcn_sched_barrier(0);
+    // 6: ab out; x, y in
+    store5(&pad->ab, ab);
+    const Fp6S x2 = fetch5(&pad->x), y2 = fetch5(&pad->y);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S tt = fp6_store(fp6_mul(x2, y2));
+    __builtin_amdgcn_sched_barrier(0);
+    // 7: ab in
+    const Fp6S ab2 = fetch5(&pad->ab);
+    __builtin_amdgcn_sched_barrier(0);
+    Fp12S r;
+    r.c0 = fp6_store(fp6_sub(fp6_sub(tt, ab2), fp6_mul_nr(ab2)));
+    r.c1 = fp6_store(fp6_add(ab2, ab2));
+    store5(fp, r);
+}
+} }
+using P2::Pad; using P2::ell_sqr_phased;
 template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, int iters, int seed) {
     P2::Fp2S a, b;
     for (int i = 0; i < NL; i++) { a.c.v[i] = (seed * 7 + i * 131 + threadIdx.x * 17) & MASK; b.c.v[i] = (seed * 3 + i * 71 + threadIdx.x) & MASK; }
@@ -52,7 +105,7 @@ template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, in
             a = P2::fp2_store(P2::fp2_mul(a, b));
         }
     }
-    if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 9 || MODE == 10) {
+    if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 9 || MODE == 10 || MODE == 11) {
         P2::Fp12S f = P2::fp12_one();
         f.c0.c1 = a; f.c1.c2 = b; f.c1.c0 = a;
         P2::G2Proj r; r.x = a; r.y = b; r.z = P2::fp2_one();
@@ -60,6 +113,7 @@ template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, in
         const FpS px = a.c, py = b.c;
         for (int it = 0; it < iters; it++) {
             if (MODE == 3) P2::ell_sqr(f, o0, o1, o2, px, py);
+            if (MODE == 11) { P2::Fp2S oo[3] = {o0, o1, o2}; FpS pp[2] = {px, py}; Pad pad; ell_sqr_phased((AS5 P2::Fp12S*)&f, (const AS5 P2::Fp2S*)oo, (const AS5 FpS*)pp, (AS5 Pad*)&pad); }
             if (MODE == 4) P2::doubling_step_h(r, o0, o1, o2);
             if (MODE == 9) P2::doubling_step_h_i(r, o0, o1, o2);
             if (MODE == 10) { P2::Fp2S oo[3]; dbl_step_p((AS5 P2::G2Proj*)&r, (AS5 P2::Fp2S*)oo); o0 = oo[0]; o1 = oo[1]; o2 = oo[2]; }
@@ -90,6 +144,7 @@ int main() {
     run<2>("mul + sqr + add + sub", out, p.multiProcessorCount, 874 + 680 + 130);
     // cores alone (measured above): fp2 mul 3931, fp2 sqr 2905, fp mul ~2560 cycles per SIMD slot
     run<3>("ell_sqr (25 mul + 2 fp mul)", out, p.multiProcessorCount, 3547 + 25 * 874 + 2 * 596);
+    run<11>("ell_sqr in phases", out, p.multiProcessorCount, 3547 + 25 * 874 + 2 * 596);
     run<4>("doubling_step_h (4 mul + 5 sqr)", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
     run<9>("doubling_step_h inlined (registers)", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
     run<10>("doubling_step_h, scratch pointers", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
