@@ -161,7 +161,8 @@ int blsmi_g1pubs_verify_aggregate_common_with_domain(const uint8_t msg32[32], co
  * same public key again on every call (CompareTwoPairings, pairing.go:140-147).  A verifier that meets the same keys again and
  * again prepares them ONCE into device memory -- BLSMI_G2_PREPARED_BYTES per key, one table after the other -- and hands the
  * tables to the *_prepared_dev entry points, whose Miller loops read a key's lines instead of recomputing them.
- * d_key_idx: n x uint32, tuple t uses table d_key_idx[t]; NULL: tuple t uses table t.  A key given as the all-zero record
+ * d_key_idx: n x uint32, tuple t uses table d_key_idx[t]; NULL: tuple t uses table t.  Indices are NOT range-checked (the tables
+ * are plain memory the caller sized): an index beyond the prepared keys reads past them.  A key given as the all-zero record
  * (the point at infinity) keeps that mark in its table: verdict 0, as in the unprepared forms.  Every result is identical to the
  * unprepared entry point on the same keys.  All buffers on ONE of the library's devices; `stream` as in blsmi_pairing_batch_dev. */
 #define BLSMI_G2_PREPARED_BYTES 24704
