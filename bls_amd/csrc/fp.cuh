@@ -433,10 +433,13 @@ BLSMI_DEV FpS fp_inv(const Fp<L, V>& a) {
 }
 
 // Square root (fq.go:203-217): a1 = a^((q-3)/4); a0 = a1^2 a; ok iff a0 != -1; root = a1*a.
-template <int L, int V>
+template <int L, int V> BLSMI_DEV FpS fp_pow_wave(const Fp<L, V>& x, const u32* ebits, int nbits);   // fp_row.cuh: one limb per lane, wave-uniform x
+template <bool WAVE = false, int L, int V>
 BLSMI_DEV FpS fp_sqrt(const Fp<L, V>& a, bool& ok) {
     const FpS as = fp_store(a);
-    const FpS a1 = fp_pow_const(as, C_QM3O4, BLSMI_QM3O4_BITS);
+    FpS a1;
+    if constexpr (WAVE) a1 = fp_pow_wave(as, C_QM3O4, BLSMI_QM3O4_BITS);
+    else a1 = fp_pow_const(as, C_QM3O4, BLSMI_QM3O4_BITS);
     const auto a0 = fp_mul(fp_sqr(a1), as);
     ok = !fp_eq(a0, C_NEGONE);
     return fp_store(fp_mul(a1, as));

@@ -158,7 +158,9 @@ __device__ __noinline__ void swu_g1_helper_ref(G1Aff& out, const FpS& t) {
 //   y0 = U V e        has  y0^2 = chi * U/V   (the square root of g(x0), or of -g(x0) for a non-residue)
 //   1/V = chi U V^2 e^2,   x0 = num den^2 / V
 // and for a non-residue g(x0), g(x1) = -t^6 g(x0) = (t^3 y0)^2.  Outputs are the same field elements.
-__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
+// WAVE: the whole wave works on ONE t (every lane the same values); the exponentiation then runs with one limb per lane (fp_row.cuh)
+template <bool WAVE>
+BLSMI_DEV void swu_g1_helper_t(G1Aff& out, const FpS& t) {
     const FpS tsq = fp_store(fp_sqr(t));
     const FpS ndc = fp_store(fp_sub(fp_sqr(tsq), tsq));                   // (-1)^2 t^4 + (-1) t^2
     const i32 ndc0 = fp_is_zero(ndc) ? -1 : 0;
@@ -169,7 +171,9 @@ __device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
     const FpS U = fp_store(fp_add(fp_add(fp_mul(fp_sqr(num), num), fp_mul(C_ELLPA, nd2)), fp_mul(C_ELLPB, V)));
     const FpS V2 = fp_store(fp_sqr(V));
     const FpS UV = fp_store(fp_mul(U, V));
-    const FpS e = fp_pow_const(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
+    FpS e;
+    if constexpr (WAVE) e = fp_pow_wave(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
+    else e = fp_pow_const(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
     const FpS y0 = fp_store(fp_mul(UV, e));
     const i32 m0 = fp_eq(fp_mul(fp_sqr(y0), V), U) ? -1 : 0;              // g(x0) is a square
     const FpS vinv = fp_store(fp_mul(fp_mul(UV, V), fp_sqr(e)));           // chi / V
@@ -188,6 +192,8 @@ __device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) {
         out.x = fp_select(special, r.x, out.x); out.y = fp_select(special, r.y, out.y);
     }
 }
+__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) { swu_g1_helper_t<false>(out, t); }
+__device__ __noinline__ void swu_g1_helper_wave(G1Aff& out, const FpS& t) { swu_g1_helper_t<true>(out, t); }
 template <int N>
 BLSMI_DEV FpS horner_fp(const FpS (&c)[N], const FpS& x) {
     FpS v = c[N - 1];
@@ -289,7 +295,8 @@ __device__ __noinline__ void swu_g2_helper_ref(G2Aff& out, const Fp2S& t) {
 // Same map with TWO exponentiations: g(x0) = U/V as above (over Fq2); its norm is a/b with a = N(U), b = N(V).
 // With w = a b^3, e = w^((q-3)/4):  s0 = a b e has s0^2 = chi * a/b (the norm root fp2_sqrt_from_norm_root needs) and
 // 1/b = chi a b^2 e^2, which yields both x0 = num conj(den) N(den)^2 / b and g(x0) = U conj(V) / b without an inversion.
-__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
+template <bool WAVE>
+BLSMI_DEV void swu_g2_helper_t(G2Aff& out, const Fp2S& t) {
     Fp2S nqr; nqr.c0 = C_ONE; nqr.c1 = C_ONE;
     const Fp2S tsq = fp2_store(fp2_sqr(t));
     const Fp2S nqr_tsq = fp2_store(fp2_mul_nr(tsq));
@@ -305,7 +312,9 @@ __device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
     const FpS bb = fp_store(fp_mul(nden2, nden));                           // b = N(V) = N(den)^3
     const FpS aa = fp_store(fp_add(fp_sqr(U.c0), fp_sqr(U.c1)));           // a = N(U)
     const FpS ab = fp_store(fp_mul(aa, bb)), b2 = fp_store(fp_sqr(bb));
-    const FpS e = fp_pow_const(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
+    FpS e;
+    if constexpr (WAVE) e = fp_pow_wave(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
+    else e = fp_pow_const(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
     const FpS s0 = fp_store(fp_mul(ab, e));
     const i32 m0 = fp_eq(fp_mul(fp_sqr(s0), bb), aa) ? -1 : 0;             // N(g(x0)) is a square <=> g(x0) is a square
     const FpS binv_p = fp_store(fp_mul(fp_mul(ab, bb), fp_sqr(e)));        // chi / b
@@ -320,7 +329,7 @@ __device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
     const FpS s1 = fp_store(fp_mul(fp_mul(fp_mul(fp_sqr(nt), nt), s0), C_SQRT_M8));   // N(gx1) = 8 N(t)^6 N(gx0) = s1^2
     const Fp2S x = fp2_select(m0, x0, x1);
     const Fp2S g = fp2_select(m0, gx0, gx1);
-    Fp2S y = fp2_sqrt_from_norm_root(g, fp_select(m0, s0, s1));
+    Fp2S y = fp2_sqrt_from_norm_root<WAVE>(g, fp_select(m0, s0, s1));
     const i32 flip = fp2_sign_is_neg(t) ^ fp2_sign_is_neg(y);             // signT != signY (g2.go:983-988, 1021-1026)
     y = fp2_select(flip, fp2_store(fp2_neg(y)), y);
     out.x = x; out.y = y; out.inf = 0;
@@ -330,6 +339,8 @@ __device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) {
         out.x = fp2_select(special, r.x, out.x); out.y = fp2_select(special, r.y, out.y);
     }
 }
+__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<false>(out, t); }
+__device__ __noinline__ void swu_g2_helper_wave(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<true>(out, t); }
 template <int N>
 BLSMI_DEV Fp2S horner_fp2(const Fp2S (&c)[N], const Fp2S& x) {
     Fp2S v = c[N - 1];
@@ -524,6 +535,55 @@ __device__ __noinline__ void tai_g2_group8(Fp2S& xo, Fp2S& yo, const u8* msg32, 
         xc = fp2_store(fp2_add(xc, step));
     }
     Fp2S y = fp2_sqrt_from_norm_root(gsel, ssel);                          // either root: the choice follows
+    const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() (g2.go:1074-1077)
+    y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
+    xo = xsel; yo = y;
+}
+// The same search for the smallest calls: one workgroup of EIGHT WAVES per message, wave g tests candidate x0 + 8 r + g with every
+// lane computing the same values and the norm's exponentiation running one limb per lane (fp_row.cuh); the verdicts and the winner's
+// (x, g(x), norm root) meet in LDS, wave 0 finishes the square root (a second wave-wide exponentiation) and stores.
+// lds: 8 verdict words + 75 words of the winner.
+__device__ __noinline__ void tai_g2_waves8(Fp2S& xo, Fp2S& yo, const u8* msg32, const u8* domain8, i32* lds) {
+    u32 w[16], dre[8], dim[8];
+    for (int tag = 1; tag <= 2; tag++) {                                   // SHA-256 of the 41-byte string m || domain || tag
+        for (int i = 0; i < 8; i++) w[i] = ((u32)msg32[4 * i] << 24) | ((u32)msg32[4 * i + 1] << 16) | ((u32)msg32[4 * i + 2] << 8) | msg32[4 * i + 3];
+        for (int i = 0; i < 2; i++) w[8 + i] = ((u32)domain8[4 * i] << 24) | ((u32)domain8[4 * i + 1] << 16) | ((u32)domain8[4 * i + 2] << 8) | domain8[4 * i + 3];
+        w[10] = ((u32)tag << 24) | 0x800000;
+        w[11] = w[12] = w[13] = w[14] = 0;
+        w[15] = 41 * 8;
+        u32* d = tag == 1 ? dre : dim;
+        sha256_init(d);
+        sha256_block(d, w);
+    }
+    u32 wre[12], wim[12];
+    for (int j = 0; j < 8; j++) { wre[j] = dre[7 - j]; wim[j] = dim[7 - j]; }
+    for (int j = 8; j < 12; j++) { wre[j] = 0; wim[j] = 0; }
+    Fp2S xc; xc.c0 = fp_from_words(wre); xc.c1 = fp_from_words(wim);
+    const int g = (int)(threadIdx.x >> 6);                                 // this wave's candidate within a round
+    Fp2S one = fp2_one(), step = fp2_zero();
+    for (int k = 0; k < 8; k++) {
+        if (k < g) xc = fp2_store(fp2_add(xc, one));
+        step = fp2_store(fp2_add(step, one));
+    }
+    while (true) {
+        const Fp2S gx = fp2_store(fp2_add(fp2_mul(fp2_sqr(xc), xc), C_B2));
+        bool ok; FpS nrm;
+        const FpS s = fp2_norm_root<true>(gx, nrm, ok);
+        __syncthreads();                                                   // the previous round's verdicts have been read
+        if ((threadIdx.x & 63) == 0) lds[g] = ok ? 1 : 0;
+        __syncthreads();
+        int win = -1;
+        for (int k = 7; k >= 0; k--) if (lds[k]) win = k;                  // smallest passing counter of the round
+        if (win == g && (threadIdx.x & 63) == 0) {
+            for (int i = 0; i < NL; i++) { lds[8 + i] = xc.c0.v[i]; lds[8 + NL + i] = xc.c1.v[i]; lds[8 + 2 * NL + i] = gx.c0.v[i]; lds[8 + 3 * NL + i] = gx.c1.v[i]; lds[8 + 4 * NL + i] = s.v[i]; }
+        }
+        if (win >= 0) break;                                               // uniform over the workgroup
+        xc = fp2_store(fp2_add(xc, step));
+    }
+    __syncthreads();
+    Fp2S xsel, gsel; FpS ssel;
+    for (int i = 0; i < NL; i++) { xsel.c0.v[i] = lds[8 + i]; xsel.c1.v[i] = lds[8 + NL + i]; gsel.c0.v[i] = lds[8 + 2 * NL + i]; gsel.c1.v[i] = lds[8 + 3 * NL + i]; ssel.v[i] = lds[8 + 4 * NL + i]; }
+    Fp2S y = fp2_sqrt_from_norm_root<true>(gsel, ssel);                    // every wave the same (only wave 0's result is stored)
     const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() (g2.go:1074-1077)
     y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
     xo = xsel; yo = y;

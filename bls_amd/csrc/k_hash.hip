@@ -47,12 +47,39 @@ KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
     swu_g2_helper(p, hp2_from_digest(d, (u32)(idx & 1)));
     if (t < n) store_g2(pts + 192 * idx, p);
 }
+// The same two kernels with one WAVE per map, for the smallest calls: every lane computes the same values and the map's square-root
+// exponentiation -- a chain of 379 dependent squarings with nothing to run beside it -- runs with one limb per lane
+// (fp_row.cuh: 219 us against 517 us for the chain).  Grid: 2 n workgroups of one wave; lane 0 stores.
+__global__ void __launch_bounds__(64) k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    const size_t idx = blockIdx.x, t = idx >> 1;
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msgs + off[t], (size_t)(off[t + 1] - off[t]));
+    G1Aff p;
+    swu_g1_helper_wave(p, hp_from_digest(d, (u32)(idx & 1)));
+    if (threadIdx.x == 0) store_g1(pts + 96 * idx, p);
+}
+__global__ void __launch_bounds__(64) k_swu_g2_waves(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    const size_t idx = blockIdx.x, t = idx >> 1;
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msgs + off[t], (size_t)(off[t + 1] - off[t]));
+    G2Aff p;
+    swu_g2_helper_wave(p, hp2_from_digest(d, (u32)(idx & 1)));
+    if (threadIdx.x == 0) store_g2(pts + 192 * idx, p);
+}
 // the try-and-increment search of HashG2WithDomain with eight lanes per message (eight candidates per round)
 KERNEL k_tai_g2_lanes8(const u8* msgs32, const u8* domain, u8* pts, size_t n) {
     const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 3, tt = t < n ? t : n - 1;
     G2Aff p; p.inf = 0;
     tai_g2_group8(p.x, p.y, msgs32 + 32 * tt, domain, (int)(idx & 7));
     if (t < n && !(idx & 7)) store_g2(pts + 192 * t, p);
+}
+// ... and with eight WAVES per message for the smallest calls (hash.cuh: tai_g2_waves8): one 512-thread workgroup per message
+__global__ void __launch_bounds__(512) k_tai_g2_waves8(const u8* msgs32, const u8* domain, u8* pts, size_t n) {
+    __shared__ i32 lds[8 + 5 * NL];
+    const size_t t = blockIdx.x;
+    G2Aff p; p.inf = 0;
+    tai_g2_waves8(p.x, p.y, msgs32 + 32 * t, domain, lds);
+    if (threadIdx.x == 0) store_g2(pts + 192 * t, p);
 }
 // Messages whose level program met an exceptional step (good[t] == 0: equal / opposite mapped points, an isogeny pole, a
 // result at infinity) are hashed again by the one-lane routines, which follow the reference's steps literally.  A wave
@@ -125,8 +152,11 @@ BLSMI_DEV FpS load_be48_masked(const u8* p) {                            // clea
     w[11] &= 0x1fffffffu;
     return fp_from_words(w);
 }
-KERNEL2 k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+// WAVE: one point per 64-lane workgroup (t = blockIdx.x, every lane the same values, lane 0 stores), the square root's exponentiation
+// with one limb per lane (fp_row.cuh) -- the smallest calls; no subgroup test in that form (the caller runs it as a level program)
+template <bool WAVE>
+BLSMI_DEV void g1_decompress_body(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) {
+    const size_t t = WAVE ? (size_t)blockIdx.x : (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
     const u8* c = in + 48 * tt;
     const u8 b0 = c[0];
@@ -134,7 +164,7 @@ KERNEL2 k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, 
     for (int i = 1; i < 48; i++) rest |= c[i];
     const FpS x = load_be48_masked(c);
     bool ok;
-    const FpS y = fp_sqrt(fp_add(fp_mul(fp_sqr(x), x), C_B), ok);        // g1.go:111-132
+    const FpS y = fp_sqrt<WAVE>(fp_add(fp_mul(fp_sqr(x), x), C_B), ok);  // g1.go:111-132
     const i32 lt = ~fp_gt_half(y);                                         // y < -y
     const i32 greatest = (b0 & 0x20) ? -1 : 0;
     G1Aff a; a.x = x; a.y = fp_select(lt ^ greatest, y, fp_store(fp_neg(y))); a.inf = 0;
@@ -144,14 +174,17 @@ KERNEL2 k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, 
     else if (b0 & 0x40) { if (rest) e = 2; else inf = 1; }
     else if (!ok) e = 3;
     else if (!sub) e = 4;
-    if (t < n) {
+    if (t < n && (!WAVE || threadIdx.x == 0)) {
         a.inf = (inf || e) ? -1 : 0;
         store_g1(out + 96 * t, a);
         out_inf[t] = inf; err[t] = e;
     }
 }
-KERNEL k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) {
-    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+KERNEL2 k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) { g1_decompress_body<false>(in, check, out, out_inf, err, n); }
+__global__ void __launch_bounds__(64) k_g1_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n) { g1_decompress_body<true>(in, 0, out, out_inf, err, n); }
+template <bool WAVE>
+BLSMI_DEV void g2_decompress_body(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) {
+    const size_t t = WAVE ? (size_t)blockIdx.x : (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
     const u8* c = in + 96 * tt;
     const u8 b0 = c[0];
@@ -159,7 +192,7 @@ KERNEL k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, s
     for (int i = 1; i < 96; i++) rest |= c[i];
     Fp2S x; x.c1 = load_be48_masked(c); x.c0 = load_be48(c + 48);          // x.c1 || x.c0 on the wire (g2.go:254-255)
     bool ok;
-    const Fp2S y = fp2_sqrt_any(fp2_add(fp2_mul(fp2_sqr(x), x), C_B2), ok);   // g2.go:149-169; y or -y is chosen below
+    const Fp2S y = fp2_sqrt_any<WAVE>(fp2_add(fp2_mul(fp2_sqr(x), x), C_B2), ok);   // g2.go:149-169; y or -y is chosen below
     const i32 lt = ~fp2_sign_is_neg(y);
     const i32 greatest = (b0 & 0x20) ? -1 : 0;
     G2Aff a; a.x = x; a.y = fp2_select(lt ^ greatest, y, fp2_store(fp2_neg(y))); a.inf = 0;
@@ -169,12 +202,14 @@ KERNEL k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, s
     else if (b0 & 0x40) { if (rest) e = 2; else inf = 1; }
     else if (!ok) e = 3;
     else if (!sub) e = 4;
-    if (t < n) {
+    if (t < n && (!WAVE || threadIdx.x == 0)) {
         a.inf = (inf || e) ? -1 : 0;
         store_g2(out + 192 * t, a);
         out_inf[t] = inf; err[t] = e;
     }
 }
+KERNEL k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) { g2_decompress_body<false>(in, check, out, out_inf, err, n); }
+__global__ void __launch_bounds__(64) k_g2_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n) { g2_decompress_body<true>(in, 0, out, out_inf, err, n); }
 // Small batches: the decompression kernels run without their subgroup test, the test runs as a level program of the latency
 // path (k_lat.hip: subgrp1 / subgrp2, one point per wave) and this kernel applies its verdict -- what the kernels above do
 // for e = 4: the record becomes the all-zero (infinity) record and the error code is set.

@@ -48,13 +48,18 @@ __global__ void k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n);
 __global__ void k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_swu_g2_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_tai_g2_lanes8(const u8* msgs32, const u8* domain, u8* pts, size_t n);
+__global__ void k_tai_g2_waves8(const u8* msgs32, const u8* domain, u8* pts, size_t n);
 __global__ void k_hash_g1_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);
 __global__ void k_hash_g2_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);
 __global__ void k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const u8* good, u8* out, size_t n);
 __global__ void k_write_generators(u8* g1, u8* g2);
 __global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
+__global__ void k_g1_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n);
 __global__ void k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
+__global__ void k_g2_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n);
 __global__ void k_apply_subgroup(const u8* in_subgroup, u8* out, int rec_words, const u8* out_inf, u8* err, size_t n);
 __global__ void k_merge_flags(const u8* inf_pk, const u8* err_pk, const u8* inf_sig, const u8* err_sig, u8* flags, size_t n);
 __global__ void k_flag_zero_records(const u8* pks, int pk_words, const u8* sigs, int sig_words, const u8* in_flags, u8* flags, int* any, size_t n);

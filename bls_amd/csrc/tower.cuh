@@ -5,6 +5,7 @@
 // to the storage types (Fp2S/Fp6S/Fp12S) with *_store() where a value is kept across a loop.
 #pragma once
 #include "fp.cuh"
+#include "fp_row.cuh"
 
 namespace blsmi {
 
