@@ -922,7 +922,12 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     DBuf raw, rec, hist, offs, cursor, idx, buckets, ch0, ch1, dmax, cls, perm;
     HIPCHK(raw.alloc(sizeof(i32) * RAWW * n, s)); HIPCHK(rec.alloc(32 * n, s));
     HIPCHK(hist.alloc(sizeof(u32) * nb, s)); HIPCHK(offs.alloc(sizeof(u32) * nb, s)); HIPCHK(cursor.alloc(sizeof(u32) * nb, s)); HIPCHK(dmax.alloc(sizeof(u32), s));
-    HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s)); HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
+    // one-pass scatter into fixed-capacity buckets (msm.inc: k_msm_scatter_cap); BLSMI_MSM_CAP=0 keeps the exact histogram + scan + scatter
+    static const bool cap_mode = []{ const char* v = getenv("BLSMI_MSM_CAP"); return !(v && v[0] == '0'); }();
+    const size_t mean = (per_win_items + B1 - 1) / B1;
+    // three times the mean: the top window of a 127-bit sub-scalar has only 2^15 digit values, i.e. twice the mean in half of its buckets
+    const u32 cap = cap_mode && nb * (3 * mean + 32) < ((size_t)1 << 32) ? (u32)(3 * mean + 32) : 0;
+    HIPCHK(idx.alloc(sizeof(u32) * std::max(per_win_items * nbw, nb * (size_t)cap), s)); HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
     HIPCHK(ch0.alloc(sizeof(i32) * jw * 2 * nct, s)); HIPCHK(ch1.alloc(sizeof(i32) * jw * 2 * nct, s));   // the fold's arrays: at most 2 nct records on either side
     HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
@@ -931,16 +936,31 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     prof_mark(W == 3 ? "k_msm_recode_g1" : "k_msm_recode_g2");
     if (W == 3) hipLaunchKernelGGL(k_msm_recode_g1, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, rec.as<u8>(), n);
     else hipLaunchKernelGGL(k_msm_recode_g2, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, rec.as<u8>(), n);
-    prof_mark("k_msm_hist_glv");
-    hipLaunchKernelGGL(k_msm_hist_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, hist.as<u32>());
-    prof_mark("k_msm_max");
-    hipLaunchKernelGGL(k_msm_max, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, dmax.as<u32>());
     u32 biggest = 0;
-    HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
-    prof_mark("k_msm_scan");
-    hipLaunchKernelGGL(k_msm_scan, dim3(nbw), dim3(256), 0, s, (const u32*)hist.as<u32>(), offs.as<u32>(), cursor.as<u32>(), c);
-    prof_mark("k_msm_scatter_glv");
-    hipLaunchKernelGGL(k_msm_scatter_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, sh, cursor.as<u32>(), idx.as<u32>());
+    size_t slice_stride = per_win_items;                                   // a bucket's items: idx + (bucket >> 16) * slice_stride + offs[bucket]
+    auto exact_passes = [&](bool with_hist) -> int {
+        if (with_hist) {
+            prof_mark("k_msm_hist_glv");
+            hipLaunchKernelGGL(k_msm_hist_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, hist.as<u32>());
+            prof_mark("k_msm_max");
+            hipLaunchKernelGGL(k_msm_max, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, dmax.as<u32>());
+            HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
+        }
+        prof_mark("k_msm_scan");
+        hipLaunchKernelGGL(k_msm_scan, dim3(nbw), dim3(256), 0, s, (const u32*)hist.as<u32>(), offs.as<u32>(), cursor.as<u32>(), c);
+        prof_mark("k_msm_scatter_glv");
+        hipLaunchKernelGGL(k_msm_scatter_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, sh, cursor.as<u32>(), idx.as<u32>());
+        slice_stride = per_win_items;
+        return BLSMI_OK;
+    };
+    if (cap) {
+        prof_mark("k_msm_scatter_cap");
+        hipLaunchKernelGGL(k_msm_scatter_cap, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, sh, cap, hist.as<u32>(), idx.as<u32>());
+        prof_mark("k_msm_max");
+        hipLaunchKernelGGL(k_msm_max_cap, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, cap, offs.as<u32>(), dmax.as<u32>());
+        HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
+        slice_stride = 0;
+    } else { const int rc = exact_passes(true); if (rc) return rc; }
     prof_mark("k_msm_class_*");
     const unsigned cb = (unsigned)((nb + 255) / 256);
     hipLaunchKernelGGL(k_msm_class_hist, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, cls.as<u32>());
@@ -957,9 +977,10 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     prof_mark(nullptr);
     HIPCHK(hipStreamSynchronize(s));
     if (biggest > 2048) return BLSMI_E_SKEW;
+    if (cap && biggest > cap) { const int rc = exact_passes(false); if (rc) return rc; }   // a bucket outgrew its slots (the counts are exact all the same): the two exact passes
     prof_mark(W == 3 ? "k_g1_msm_bucket_raw" : "k_g2_msm_bucket_raw_pair");
-    if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
-    else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), per_win_items, nb);
+    if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), slice_stride, nb);
+    else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), slice_stride, nb);
     // running sums per chunk WITHOUT the per-lane multiplication, then the fold that carries the odd-element sums along (msm.inc):
     // one addition deep per level; out come, per window, X, L and O_0 .. O_{m-1}
     const bool pairk = W == 6 && g_pair_layout;                            // G2: a lane pair per chunk / per sum, two waves per SIMD

@@ -490,3 +490,35 @@ def test_device_duplicate_table_and_its_fallback(force):
     assert r.returncode == 0 and line, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
     res = json.loads(line[-1][len("DUP_RESULT "):])
     assert res["forced"] == bool(force) and res["ok"], res
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_bucket_overflowing_its_slots_takes_the_exact_passes(group):
+    """The one-pass scatter gives every bucket three times the mean population + 32 slots (n = 2^17: 44 for G1, 56 for G2); 300 EQUAL scalars put 300
+    items into the same bucket of every window -- beyond its slots, below the skew limit of 2 048 -- so the call must go through the exact
+    histogram + scan + scatter.  Same point as the oracle gives through the scalar identity."""
+    from bls_amd import engine as eng
+    eng.init(0)
+    n = 1 << 17
+    rng = np.random.default_rng(56)
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); k[:, 0] &= 0x3f
+    k[1000:1300] = k[999]                                                  # 301 equal scalars
+    base = 64
+    bk = rng.integers(0, 256, size=(base, 32), dtype=np.uint8); bk[:, 0] &= 0x3f
+    gen = RC.g1_generator() if group == "g1" else RC.g2_generator()
+    bpts, _ = (eng.g1_mul_batch if group == "g1" else eng.g2_mul_batch)(gen * base, bk.reshape(-1), base)
+    pts = np.tile(bpts, (n // base, 1))
+    lib = eng._lib()
+    lib.blsmi_set_profiling(1)
+    got = (eng.g1_msm if group == "g1" else eng.g2_msm)(pts.reshape(-1), k.reshape(-1), n)
+    import ctypes
+    buf = ctypes.create_string_buffer(8192)
+    lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
+    names = buf.value.decode()
+    assert "k_msm_scatter_cap" in names and "k_msm_scatter_glv" in names and "k_msm_scan" in names, names   # the one-pass scatter ran, then the exact passes
+    acc = 0
+    kk = k.reshape(n // base, base, 32)
+    for j in range(base):
+        col = sum(int.from_bytes(kk[i, j].tobytes(), "big") for i in range(n // base))
+        acc = (acc + int.from_bytes(bk[j].tobytes(), "big") * col) % P.R_ORDER
+    assert got == (RC.g1_mul if group == "g1" else RC.g2_mul)(gen, acc.to_bytes(32, "big"))
