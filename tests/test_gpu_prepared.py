@@ -54,6 +54,8 @@ def test_tables_are_the_references_g2prepared(eng):
     keys = [RC.g2_generator()] + [rand_g2(xs) for _ in range(4)]
     # a record that is no curve point at all: G2AffineToPrepared is formulas only, the table must follow them all the same
     keys.append(RC.g2_mul(RC.g2_generator(), (5).to_bytes(32, "big"))[:96] + bytes(95) + b"\x07")
+    # ... and a coordinate encoded as a value >= q (FQReprToFQ turns it into 0 upstream, fq.go:49-56): same lines as the oracle's
+    keys.append((P.Q + 5).to_bytes(48, "big") + keys[1][48:])
     want = np.stack([RC.g2_prepare(k) for k in keys])
     got = eng.g2_prepare_batch(b"".join(keys), len(keys))
     assert got.shape == want.shape and np.array_equal(got, want)
