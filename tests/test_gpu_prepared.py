@@ -231,3 +231,39 @@ def test_host_mirror_prepare_keys(eng):
         G.VerifyBatchPrepared(msgs, keys, [5] * 10, sigs)
     keys.Close()
 
+
+
+def test_concurrent_callers_share_one_set_of_prepared_keys(eng):
+    """Six threads verify against the same library-owned tables at once (each call leases its own stream context; the tables are only
+    read), two more run unprepared batches beside them; every caller gets the verdicts of its own tuples."""
+    import threading
+    sks, keys, msgs, idx, sigs = _verify_case(eng, 96, 9600)
+    pk = eng.PreparedKeys(b"".join(keys), len(keys))
+    expect = np.ones(96, dtype=bool)
+    bad = idx.copy()
+    for i in range(2, 96, 9):
+        bad[i] = (bad[i] + 1) % 6; expect[i] = False
+    plain_keys = b"".join(keys[j] for j in bad)
+    results = {}
+
+    def run(t):
+        try:
+            for _ in range(4):
+                if t < 6:
+                    lo = 16 * t
+                    ok, _ = eng.g2pubs_verify_batch_prepared(msgs[lo:lo + 16], pk, bad[lo:lo + 16], sigs[lo:lo + 16].reshape(-1))
+                    assert np.array_equal(ok, expect[lo:lo + 16])
+                else:
+                    ok, _ = eng.g2pubs_verify_batch(msgs, plain_keys, sigs.reshape(-1))
+                    assert np.array_equal(ok, expect)
+            results[t] = True
+        except Exception as e:  # noqa: BLE001
+            results[t] = e
+
+    th = [threading.Thread(target=run, args=(t,)) for t in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    pk.close()
+    assert all(results.get(t) is True for t in range(8)), results
