@@ -236,6 +236,19 @@ def g2pubs_verify_batch_prepared_dev(d_msgs, d_off, d_prepared, d_key_idx, d_sig
                                                         C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "blsmi_g2pubs_verify_batch_prepared_dev")
 
 
+def g2pubs_verify_aggregate_prepared(msgs, prepared, key_idx, sig):
+    """Signature.VerifyAggregate over prepared keys, host buffers (a PreparedKeys or a device pointer)."""
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    ptr = prepared.ptr if isinstance(prepared, PreparedKeys) else prepared
+    idx = None if key_idx is None else np.ascontiguousarray(key_idx, dtype=np.uint32)
+    s = _u8(sig, 96)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g2pubs_verify_aggregate_prepared(_p8(buf), off.ctypes.data_as(_u64p), C.c_void_p(ptr), None if idx is None else idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                        _p8(s), C.c_size_t(n), C.byref(ok)), "blsmi_g2pubs_verify_aggregate_prepared")
+    return bool(ok.value)
+
+
 def g2pubs_verify_aggregate_prepared_dev(d_msgs, d_off, d_prepared, d_key_idx, sig, n, stream=0):
     s = _u8(sig, 96)
     ok = C.c_int(0)

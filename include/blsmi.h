@@ -185,6 +185,8 @@ int blsmi_pairing_batch_prepared_dev(const void *d_g1_aff, const void *d_prepare
 /* g2pubs.Verify x n / Signature.VerifyAggregate with prepared public keys; otherwise as the *_dev forms below */
 int blsmi_g2pubs_verify_batch_prepared_dev(const void *d_msgs, const void *d_off, const void *d_prepared, const void *d_key_idx,
                                            const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
+int blsmi_g2pubs_verify_aggregate_prepared(const uint8_t *msgs, const uint64_t *msg_off, const void *d_prepared, const uint32_t *key_idx /* n, may be NULL */,
+                                           const uint8_t sig[96], size_t n, int *ok);   /* messages, indices and signature in HOST memory */
 int blsmi_g2pubs_verify_aggregate_prepared_dev(const void *d_msgs, const void *d_off, const void *d_prepared, const void *d_key_idx,
                                                const uint8_t sig[96], size_t n, int *ok, void *stream);
 

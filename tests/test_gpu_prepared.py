@@ -208,6 +208,13 @@ def test_library_owned_tables_and_the_host_form(eng):
     ok2, _ = eng.g2pubs_verify_batch_prepared(msgs[:6], pk, None, sigs[:6].reshape(-1))
     ref2, _ = eng.g2pubs_verify_batch(msgs[:6], b"".join(keys), sigs[:6].reshape(-1))
     assert np.array_equal(ok2, ref2)
+    # VerifyAggregate over the same tables, host buffers
+    agg = eng.g1_sum(sigs.reshape(-1), n)
+    assert eng.g2pubs_verify_aggregate_prepared(msgs, pk, idx, agg) is True
+    assert eng.g2pubs_verify_aggregate_prepared(msgs, pk, bad, agg) is False
+    dup = list(msgs); dup[5] = dup[6]
+    assert eng.g2pubs_verify_aggregate_prepared(dup, pk, idx, agg) is False
+    assert eng.g2pubs_verify_aggregate_prepared(msgs[:6], pk, None, eng.g1_sum(sigs[:6].reshape(-1), 6)) is (list(idx[:6]) == list(range(6)))
     pk.close()
     pk.close()                                                             # idempotent
 
