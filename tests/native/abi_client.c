@@ -40,6 +40,17 @@ int main(int argc, char **argv) {
     printf("\nbatch");
     for (uint64_t i = 0; i < n; i++) printf(" %d", ok[i]);
     printf("\n");
+    /* the same tuples over PREPARED keys (blsmi 0.4): the tables live in device memory the library owns; tuple i uses table i */
+    void *prepared = NULL;
+    uint8_t *okp = malloc(n);
+    rc = blsmi_g2_prepared_create(pks, (size_t)n, &prepared);
+    if (rc != BLSMI_OK || !prepared) { fprintf(stderr, "prepared_create: %d\n", rc); return 1; }
+    rc = blsmi_g2pubs_verify_batch_prepared(msgs, off, prepared, NULL, sigs, NULL, okp, NULL, (size_t)n);
+    if (rc != BLSMI_OK) { fprintf(stderr, "verify prepared: %d\n", rc); return 1; }
+    printf("prepared");
+    for (uint64_t i = 0; i < n; i++) printf(" %d", okp[i]);
+    printf("\n");
+    if ((rc = blsmi_g2_prepared_destroy(prepared)) != BLSMI_OK) { fprintf(stderr, "prepared_destroy: %d\n", rc); return 1; }
     uint64_t e[72];
     rc = blsmi_pairing_batch(sigs, pks, e, 1);               /* e(sig_0, pk_0) */
     if (rc != BLSMI_OK) { fprintf(stderr, "pairing: %d\n", rc); return 1; }
