@@ -87,6 +87,51 @@ __device__ __noinline__ void ell_sqr_phased(AS5 Fp12S* fp, const AS5 Fp2S* o, co
 }
 } }
 using P2::Pad; using P2::ell_sqr_phased;
+// An Fq12 multiplication on references as FOUR memory events (what waits is stored and what the next six products need is fetched at
+// the same points), nothing for the compiler to spill in between: the out-of-line version the library used spends more cycles on
+// scattered spills -- each drained at the next core call -- than on its 18 products.
+namespace blsmi { namespace pairl {
+template <class T> __device__ __forceinline__ T fetch_g(const T* src) {
+    T dst; const int* p = (const int*)src; int* q = (int*)&dst;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) q[i] = p[i];
+    return dst;
+}
+template <class T> __device__ __forceinline__ void store_g(T* dst, const T& src) {
+    const int* p = (const int*)&src; int* q = (int*)dst;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) q[i] = p[i];
+}
+__device__ __noinline__ void fp12_mul_phased(Fp12S* r, const Fp12S* a, const Fp12S* b) {
+    Fp6S pad_[2];
+    Fp6S* pad = pad_;
+    asm volatile("" : "+v"(pad));                                         // the two waiting products stay in memory
+    // 1: a.c0, b.c0
+    Fp6S x = fetch_g(&a->c0), y = fetch_g(&b->c0);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S t0 = fp6_store(fp6_mul(x, y));
+    __builtin_amdgcn_sched_barrier(0);
+    // 2: t0 out; a.c1, b.c1 in
+    store_g(&pad[0], t0);
+    x = fetch_g(&a->c1); y = fetch_g(&b->c1);
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S t1 = fp6_store(fp6_mul(x, y));
+    __builtin_amdgcn_sched_barrier(0);
+    // 3: t1 out; a.c0, b.c0 in again for the sums
+    store_g(&pad[1], t1);
+    const Fp6S sa = fp6_store(fp6_add(fetch_g(&a->c0), x)), sb = fp6_store(fp6_add(fetch_g(&b->c0), y));
+    __builtin_amdgcn_sched_barrier(0);
+    const Fp6S t2 = fp6_store(fp6_mul(sa, sb));
+    __builtin_amdgcn_sched_barrier(0);
+    // 4: t0, t1 in; the result out
+    const Fp6S u0 = fetch_g(&pad[0]), u1 = fetch_g(&pad[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    Fp12S res;
+    res.c0 = fp6_store(fp6_add(fp6_mul_nr(u1), u0));
+    res.c1 = fp6_store(fp6_sub(fp6_sub(t2, u0), u1));
+    store_g(r, res);
+}
+} }
 template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, int iters, int seed) {
     P2::Fp2S a, b;
     for (int i = 0; i < NL; i++) { a.c.v[i] = (seed * 7 + i * 131 + threadIdx.x * 17) & MASK; b.c.v[i] = (seed * 3 + i * 71 + threadIdx.x) & MASK; }
@@ -104,6 +149,20 @@ template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, in
             if (MODE == 7 || MODE == 8) { i32 acc = 0; for (int i = 0; i < 45; i++) acc += priv[i]; b.c.v[0] = (b.c.v[0] + acc) & MASK; }   // loads, then the call
             a = P2::fp2_store(P2::fp2_mul(a, b));
         }
+    }
+    if (MODE >= 12 && MODE <= 17) {
+        // the final exponentiation's squarings: plain Granger-Scott (9 square cores), compressed (6), and one exp_by_x
+        P2::Fp12S f = P2::fp12_one();
+        f.c0.c1 = a; f.c1.c2 = b; f.c1.c0 = a; f.c0.c2 = b; f.c1.c1 = a;
+        for (int it = 0; it < iters; it++) {
+            if (MODE == 12) for (int k = 0; k < 16; k++) f = P2::fp12_cyclotomic_sqr(f);
+            if (MODE == 13) { P2::CycCompressed c = P2::cyc_compress(f); for (int k = 0; k < 16; k++) c = P2::cyc_compressed_sqr(c); f.c0.c1 = c.z4; f.c0.c2 = c.z3; f.c1.c0 = c.z2; f.c1.c2 = c.z5; }
+            if (MODE == 14) { P2::Fp12S o; P2::exp_by_x(o, f, BLSMI_X_ABS); f = o; }
+            if (MODE == 15) { P2::Fp12S g = f; for (int k = 0; k < 4; k++) { P2::Fp12S t = f; P2::nf_fp12_mul(t, t, g); f = t; } }
+            if (MODE == 16) f = P2::cyc_sqr_run(f, 16);
+            if (MODE == 17) { P2::Fp12S g = f; for (int k = 0; k < 4; k++) { P2::Fp12S t = f; P2::fp12_mul_phased(&t, &t, &g); f = t; } }
+        }
+        a = P2::fp2_store(P2::fp2_add(P2::fp2_add(f.c0.c0, f.c1.c1), P2::fp2_add(f.c0.c1, f.c1.c2)));
     }
     if (MODE == 3 || MODE == 4 || MODE == 5 || MODE == 9 || MODE == 10 || MODE == 11) {
         P2::Fp12S f = P2::fp12_one();
@@ -124,7 +183,7 @@ template <int MODE> __global__ void __launch_bounds__(64, 2) k_core(i32* out, in
     for (int i = 0; i < NL; i++) out[(blockIdx.x * 64 + threadIdx.x) * NL + i] = a.c.v[i] + b.c.v[i];
 }
 template <int MODE> void run(const char* name, i32* out, int ncu, double instr_per_iter) {
-    const int iters = MODE >= 3 ? 200 : 2000;
+    const int iters = MODE == 14 ? 8 : MODE >= 12 ? 40 : MODE >= 3 ? 200 : 2000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e30f;
     for (int rep = 0; rep < 4; rep++) {
@@ -150,6 +209,12 @@ int main() {
     run<10>("doubling_step_h, scratch pointers", out, p.multiProcessorCount, 1013 + 4 * 874 + 5 * 680);
     { long long ts[8]; hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_ts), sizeof ts);
       printf("   timeline of one call (s_memtime ticks, 100 MHz): loads %lld, compute %lld, stores+drain %lld\n", ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]); }
+    run<12>("16 plain cyclotomic squarings", out, p.multiProcessorCount, 16 * (9 * 680 + 550));
+    run<13>("16 compressed squarings", out, p.multiProcessorCount, 16 * (6 * 680 + 360));
+    run<14>("exp_by_x", out, p.multiProcessorCount, 15 * 6660 + 48 * 4440 + 2 * 28000 + 5 * 18600);
+    run<15>("4 nf_fp12_mul (18 mul cores each)", out, p.multiProcessorCount, 4 * 18600);
+    run<17>("4 Fq12 multiplications in four memory events", out, p.multiProcessorCount, 4 * 18600);
+    run<16>("cyc_sqr_run(16): 16 compressed + decompression", out, p.multiProcessorCount, 16 * 4440 + 28000);
     run<6>("45 scratch stores + fp2 mul", out, p.multiProcessorCount, 924 + 90);
     run<7>("45 scratch loads + fp2 mul", out, p.multiProcessorCount, 924 + 90);
     run<8>("stores + loads + fp2 mul", out, p.multiProcessorCount, 924 + 180);
