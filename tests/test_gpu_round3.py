@@ -515,7 +515,8 @@ def test_msm_bucket_overflowing_its_slots_takes_the_exact_passes(group):
     buf = ctypes.create_string_buffer(8192)
     lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
     names = buf.value.decode()
-    assert "k_msm_scatter_cap" in names and "k_msm_scatter_glv" in names and "k_msm_scan" in names, names   # the one-pass scatter ran, then the exact passes
+    if os.environ.get("BLSMI_MSM_CAP", "1") != "0":
+        assert "k_msm_scatter_cap" in names and "k_msm_scatter_glv" in names and "k_msm_scan" in names, names   # the one-pass scatter ran, then the exact passes
     acc = 0
     kk = k.reshape(n // base, base, 32)
     for j in range(base):
