@@ -2,6 +2,7 @@
 #include "pairing.cuh"
 #include "device_io.cuh"
 
+#define BLSMI_PAIR_MILLER_ONLY          // the final-exponentiation kernels of pair_kernels.inc are compiled in k_fe_pair.hip
 #include "pair_kernels.inc"
 
 // The same Fq2 / Fq6 / Fq12 operations in the LANE-PAIR layout (fp2_pair.inc): lanes 2k, 2k+1 hold the c0 / c1 halves of

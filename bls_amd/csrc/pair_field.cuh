@@ -5,6 +5,9 @@
 #pragma once
 #include "glv.cuh"        // (curve.cuh + the one-element-per-lane endomorphisms, which must see BLSMI_FP2_K before it is re-pointed)
 
+#ifdef BLSMI_ASM_CORES
+#include "core_asm.inc"
+#endif
 namespace blsmi {
 namespace pairl {
 #include "fp2_pair.inc"

@@ -273,3 +273,19 @@ def test_sum_tree_programs():
         fin = G.simulate(G.schedule(G.build_program("sumfin_" + g)), {G.BUF_SOAPT: {e | bit: v for e, v in enumerate(s1)}})
         flat = [want[0][0], want[0][1], want[1][0], want[1][1]] if six else [want[0], want[1]]
         assert fin[:len(flat)] == flat and fin[len(flat)]
+
+
+def test_core_asm_blobs_are_current(tmp_path):
+    """bls_amd/csrc/core_asm.inc (the multiply cores of the final-exponentiation kernels as assembly blobs) is generated from the
+    compiler's own output for fp2p_mul_body / fp2p_sqr_body: regenerate it and compare, so that a change to the field arithmetic cannot
+    leave a stale blob behind."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls_amd", "csrc")
+    out = tmp_path / "core_asm.inc"
+    subprocess.check_call([sys.executable, os.path.join(csrc, "gen_core_asm.py"), str(out)], timeout=600)
+    assert out.read_text() == open(os.path.join(csrc, "core_asm.inc")).read(), "core_asm.inc is stale: run python bls_amd/csrc/gen_core_asm.py"
