@@ -166,9 +166,8 @@ BLSMI_DEV vlimbs fp_mul_body(vlimbs a, vlimbs b) {
     r[NL - 1] = (i32)acc;
     return r;
 }
-__device__ __noinline__ vlimbs fp_mul_core(vlimbs a, vlimbs b) { return fp_mul_body(a, b); }
 // Squaring (fq.go:151-198): off-diagonal products once, against the doubled operand.
-__device__ __noinline__ vlimbs fp_sqr_core(vlimbs a) {
+BLSMI_DEV vlimbs fp_sqr_body(vlimbs a) {
     i32 m[NL], a2[NL];
     vlimbs r;
 #pragma unroll
@@ -198,6 +197,8 @@ __device__ __noinline__ vlimbs fp_sqr_core(vlimbs a) {
     r[NL - 1] = (i32)acc;
     return r;
 }
+__device__ __noinline__ vlimbs fp_mul_core(vlimbs a, vlimbs b) { return fp_mul_body(a, b); }
+__device__ __noinline__ vlimbs fp_sqr_core(vlimbs a) { return fp_sqr_body(a); }
 
 template <int La, int Va, int Lb, int Vb>
 BLSMI_DEV auto fp_mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {

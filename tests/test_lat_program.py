@@ -287,5 +287,5 @@ def test_core_asm_blobs_are_current(tmp_path):
         pytest.skip("no hipcc")
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls_amd", "csrc")
     out = tmp_path / "core_asm.inc"
-    subprocess.check_call([sys.executable, os.path.join(csrc, "gen_core_asm.py"), str(out)], timeout=600)
+    subprocess.check_call([sys.executable, os.path.join(csrc, "gen_core_asm.py"), str(tmp_path)], timeout=600)
     assert out.read_text() == open(os.path.join(csrc, "core_asm.inc")).read(), "core_asm.inc is stale: run python bls_amd/csrc/gen_core_asm.py"
