@@ -50,7 +50,7 @@ KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
 // The same two kernels with one WAVE per map, for the smallest calls: every lane computes the same values and the map's square-root
 // exponentiation -- a chain of 379 dependent squarings with nothing to run beside it -- runs with one limb per lane
 // (fp_row.cuh: 219 us against 517 us for the chain).  Grid: 2 n workgroups of one wave; lane 0 stores.
-__global__ void __launch_bounds__(64) k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n) {
+__global__ void __launch_bounds__(64, 2) k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n) {
     const size_t idx = blockIdx.x, t = idx >> 1;
     u32 d[8];
     sha256_msg(d, 1, 0x01, msgs + off[t], (size_t)(off[t + 1] - off[t]));
@@ -181,7 +181,7 @@ BLSMI_DEV void g1_decompress_body(const u8* in, int check, u8* out, u8* out_inf,
     }
 }
 KERNEL2 k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) { g1_decompress_body<false>(in, check, out, out_inf, err, n); }
-__global__ void __launch_bounds__(64) k_g1_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n) { g1_decompress_body<true>(in, 0, out, out_inf, err, n); }
+__global__ void __launch_bounds__(64, 2) k_g1_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n) { g1_decompress_body<true>(in, 0, out, out_inf, err, n); }
 template <bool WAVE>
 BLSMI_DEV void g2_decompress_body(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n) {
     const size_t t = WAVE ? (size_t)blockIdx.x : (size_t)blockIdx.x * WG + threadIdx.x;
