@@ -15,7 +15,9 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 _UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_hash.hip", "k_curve.hip", "k_lat.hip", "k_util.hip"]
 LAT_BIN = os.path.join(CSRC, "lat_programs.z")            # level programs of the latency path (gen_lat.py), zlib-compressed, embedded into blsmi.hip.o
 BUILD_DIR = os.path.join(CSRC, "build")
-_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"]
+# -Werror=pass-failed: a kernel that misses its declared waves-per-SIMD (a shared device function that outgrew the register budget)
+# stops the build instead of running at half occupancy
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Werror=pass-failed"]
 
 
 def _deps(unit):
