@@ -70,6 +70,8 @@ __global__ void k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* fla
 __global__ void k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
 __global__ void k_debug_swu_g1(const u64* a, u64* out, size_t n);
 __global__ void k_debug_swu_g2(const u64* a, u64* out, size_t n);
+// k_hash_pair.hip
+__global__ void k_hash_g2_pair(const u8* msgs, const u64* off, u8* good, u8* out, size_t n, unsigned redo_every);
 // k_curve.hip
 __global__ void k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n);
