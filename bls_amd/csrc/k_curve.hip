@@ -2,6 +2,7 @@
 #include "tower.cuh"
 #include "device_io.cuh"
 #include "glv.cuh"
+#include "msm_raw.cuh"
 
 KERNEL k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
@@ -142,7 +143,6 @@ KERNEL k_g2_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out,
 // with E = 2 (G1) / 4 (G2) field elements of 15 words.  980 KB for G1, 1.9 MB for G2: resident in L2.
 constexpr int FIXED_WINDOWS = 32, FIXED_ENTRIES = 255;
 template <class F> BLSMI_DEV Aff<F> fixed_entry(const i32* table, int w, u32 d);
-BLSMI_DEV FpS raw_load(const i32* p) { FpS x; for (int j = 0; j < NL; j++) x.v[j] = p[j]; return x; }
 template <> BLSMI_DEV G1Aff fixed_entry<FpS>(const i32* table, int w, u32 d) {
     const i32* e = table + ((size_t)w * FIXED_ENTRIES + (d ? d - 1 : 0)) * 2 * NL;
     G1Aff a; a.x = raw_load(e); a.y = raw_load(e + NL); a.inf = d ? 0 : -1; return a;
@@ -265,34 +265,7 @@ KERNEL k_g2_sum_final(const i32* src, u8* out, i32* out_inf) { sum_final_body<Fp
 // ------------------------------------------------------------------------------------------------------------------
 #include "pair_field.cuh"
 namespace P2 = blsmi::pairl;
-BLSMI_DEV P2::G2AffP pair_load_g2(const u8* p, int par) {                  // wire order x.c0 || x.c1 || y.c0 || y.c1
-    u32 any = 0;
-    P2::G2AffP a;
-    a.x = P2::wrap(load_be48(p + 48 * par, &any)); a.y = P2::wrap(load_be48(p + 96 + 48 * par, &any));
-    any |= (u32)__shfl_xor((int)any, 1);
-    a.inf = any ? 0 : -1;                                                  // the all-zero record is the point at infinity
-    return a;
-}
-BLSMI_DEV void pair_store_g2(u8* p, int par, const P2::G2AffP& a) {
-    if (a.inf) { u32* w = reinterpret_cast<u32*>(p + 48 * par); for (int i = 0; i < 12; i++) { w[i] = 0; w[24 + i] = 0; } return; }
-    store_be48(p + 48 * par, a.x.c); store_be48(p + 96 + 48 * par, a.y.c);
-}
-// G2 bucket accumulation of the MSM (msm.inc step 2) with a lane PAIR per bucket: half the point state per lane, two waves per
-// SIMD instead of one.  The record a pair leaves is the one-lane kernel's (jac_soa_store): coordinate c_par by lane par.
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_pair(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb) {
-    const int par = threadIdx.x & 1;
-    const size_t j = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t jj = j < nb ? j : nb - 1;
-    const size_t t = perm[jj];
-    const u32 cnt = j < nb ? hist[t] : 0;
-    const u32* slice = idx + (t >> c) * n + offs[t];
-    P2::G2JacP acc = jac_zero<P2::Fp2S>();
-    for (u32 k = 0; k < cnt; k++) acc = jac_add_affine(acc, pair_load_g2(pts + (size_t)192 * slice[k], par));
-    if (j < nb) {
-        soa_store(buckets, nb, t, 0 + par, acc.x.c); soa_store(buckets, nb, t, 2 + par, acc.y.c); soa_store(buckets, nb, t, 4 + par, acc.z.c);
-        if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
-    }
-}
+#include "pair_point_io.inc"
 __global__ void __launch_bounds__(WG, 2) k_g2_mul_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
     const int par = threadIdx.x & 1;
     const size_t t = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
@@ -321,99 +294,4 @@ __global__ void __launch_bounds__(WG, 2) k_g2_mul_glv_pair(const u8* pts, size_t
     const P2::G2AffP p = pair_load_g2(pts + pt_stride * tt, par);
     const P2::G2AffP a = jac_to_affine(glv_mul<P2::Fp2S>(p, scalars + 32 * tt));
     if (t < n) { pair_store_g2(out + (size_t)192 * t, par, a); if (!par) out_inf[t] = a.inf ? 1 : 0; }
-}
-// G2 bucket accumulation over the raw-limb items of the endomorphism MSM (msm.inc): a lane pair per bucket, lane `par` loads its
-// own coefficient of the item's variant (P, -psi P, psi^2 P, -psi^3 P).
-BLSMI_DEV P2::G2AffP raw_item_g2_pair(const i32* raw, u32 item, int par) {
-    const i32* o = raw + (size_t)RAW2_WORDS * (item & 0x3fffffffu) + (size_t)(item >> 30) * 4 * NL + par * NL;
-    P2::G2AffP a;
-    a.x = P2::wrap(raw_load(o)); a.y = P2::wrap(raw_load(o + 2 * NL));
-    a.inf = raw[(size_t)RAW2_WORDS * (item & 0x3fffffffu) + 240];
-    return a;
-}
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_raw_pair(const i32* raw, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t per_win, size_t nb) {
-    const int par = threadIdx.x & 1;
-    const size_t j = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t jj = j < nb ? j : nb - 1;
-    const size_t t = perm[jj];
-    const u32 cnt = j < nb ? hist[t] : 0;
-    const u32* slice = idx + (t >> 16) * per_win + offs[t];
-    P2::G2JacP acc = jac_zero<P2::Fp2S>();
-    for (u32 k = 0; k < cnt; k++) acc = jac_add_affine_i(acc, raw_item_g2_pair(raw, slice[k], par));   // inlined: the accumulator stays in registers
-    if (j < nb) {
-        soa_store(buckets, nb, t, 0 + par, acc.x.c); soa_store(buckets, nb, t, 2 + par, acc.y.c); soa_store(buckets, nb, t, 4 + par, acc.z.c);
-        if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
-    }
-}
-// The running-sum pass and the fold of the MSM for G2 in the lane-pair layout (the one-lane k_g2_msm_chunk runs one wave per SIMD with
-// 494 spilled registers, one VALU instruction per 13.7 cycles: profiles/r03a): a lane pair per chunk / per pair of chunk sums.
-BLSMI_DEV P2::G2JacP pair_soa_load(const i32* buf, size_t n, size_t t, int par) {
-    P2::G2JacP p;
-    p.x = P2::wrap(soa_load(buf, n, t, 0 + par)); p.y = P2::wrap(soa_load(buf, n, t, 2 + par)); p.z = P2::wrap(soa_load(buf, n, t, 4 + par));
-    p.inf = buf[(size_t)6 * NL * n + t];
-    return p;
-}
-BLSMI_DEV void pair_soa_store(i32* buf, size_t n, size_t t, int par, const P2::G2JacP& p) {
-    soa_store(buf, n, t, 0 + par, p.x.c); soa_store(buf, n, t, 2 + par, p.y.c); soa_store(buf, n, t, 4 + par, p.z.c);
-    if (!par) buf[(size_t)6 * NL * n + t] = p.inf;
-}
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_chunk_pair(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nchunks_total) {
-    const int par = threadIdx.x & 1;
-    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t t = t0 < nchunks_total ? t0 : nchunks_total - 1;         // both lanes of a pair stay active
-    const size_t per_win = ((size_t)1 << c) / K;
-    const size_t w = t / per_win, j = t % per_win;
-    const size_t lo = j * K;
-    P2::G2JacP running = jac_zero<P2::Fp2S>(), local = jac_zero<P2::Fp2S>();
-#pragma unroll 1
-    for (int k = K - 1; k >= 0; k--) {
-        running = jac_add_i(running, pair_soa_load(buckets, nb, (w << c) + lo + k, par));
-        local = jac_add_i(local, running);
-    }
-    if (j == 0) local = jac_add(local, jac_neg(running));                  // lo - 1 = -1
-    else local = jac_add(local, jac_mul_u64_public(running, (u64)(lo - 1)));
-    if (t0 < nchunks_total) pair_soa_store(chunks, nchunks_total, t, par, local);
-}
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_fold_pair(const i32* src, i32* dst, size_t seg, size_t half, int nwin) {
-    const int par = threadIdx.x & 1;
-    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t total = half * nwin;
-    const size_t t = t0 < total ? t0 : total - 1;
-    const size_t w = t / half, j = t % half;
-    P2::G2JacP r = pair_soa_load(src, seg * nwin, w * seg + j, par);
-    if (j + half < seg) r = jac_add(r, pair_soa_load(src, seg * nwin, w * seg + j + half, par));
-    if (t0 < total) pair_soa_store(dst, half * nwin, t, par, r);
-}
-// lane-pair forms of the multiplication-free running-sum pass and of its fold (msm.inc)
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_chunk2_pair(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct) {
-    const int par = threadIdx.x & 1;
-    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t t = t0 < nct ? t0 : nct - 1;
-    const size_t per_win = ((size_t)1 << c) / K;
-    const size_t w = t / per_win, j = t % per_win;
-    const size_t lo = j * K;
-    P2::G2JacP running = jac_zero<P2::Fp2S>(), local = jac_zero<P2::Fp2S>();
-#pragma unroll 1
-    for (int k = K - 1; k >= 0; k--) {
-        running = jac_add_i(running, pair_soa_load(buckets, nb, (w << c) + lo + k, par));
-        local = jac_add_i(local, running);
-    }
-    if (t0 < nct) { pair_soa_store(out, 2 * nct, t, par, running); pair_soa_store(out, 2 * nct, nct + t, par, local); }
-}
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_fold2_pair(const i32* src, i32* dst, int narr, int nwin, size_t len) {
-    const int par = threadIdx.x & 1;
-    const size_t half = len / 2, per_arr = (size_t)nwin * half, total = (size_t)(narr + 1) * per_arr;
-    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t t = t0 < total ? t0 : total - 1;
-    const size_t a = t / per_arr, r = t % per_arr, w = r / half, j = r % half;
-    const size_t nsrc = (size_t)narr * nwin * len;
-    // (uniform per pair; a wave mixes both kinds only at an array boundary)
-    P2::G2JacP v;
-    if (a < (size_t)narr) {
-        const size_t base = (a * nwin + w) * len + 2 * j;
-        v = jac_add(pair_soa_load(src, nsrc, base, par), pair_soa_load(src, nsrc, base + 1, par));
-    } else {
-        v = pair_soa_load(src, nsrc, (size_t)w * len + 2 * j + 1, par);
-    }
-    if (t0 < total) pair_soa_store(dst, total, t, par, v);
 }

@@ -93,9 +93,10 @@ __global__ void k_g1_sum(const i32* src, i32* dst, size_t n, size_t half);
 __global__ void k_g2_sum(const i32* src, i32* dst, size_t n, size_t half);
 __global__ void k_g1_sum_final(const i32* src, u8* out, i32* out_inf);
 __global__ void k_g2_sum_final(const i32* src, u8* out, i32* out_inf);
-__global__ void k_g2_msm_bucket_pair(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb);
 __global__ void k_g2_mul_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g2_mul_glv_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n);
+// k_msm_pair.hip
+__global__ void k_g2_msm_bucket_pair(const u8* pts, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t n, int c, size_t nb);
 __global__ void k_g2_msm_bucket_raw_pair(const i32* raw, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t per_win, size_t nb);
 __global__ void k_g2_msm_chunk_pair(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nchunks_total);
 __global__ void k_g2_msm_fold_pair(const i32* src, i32* dst, size_t seg, size_t half, int nwin);
