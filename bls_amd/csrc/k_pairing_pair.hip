@@ -11,7 +11,7 @@ template <int W2>
 __device__ void pair_rec_load(FpS* c, const u64* p, size_t t, int par) { for (int j = 0; j < W2; j++) c[j] = load_m384(p + (size_t)6 * (2 * W2 * t + 2 * j + par)); }
 template <int W2>
 __device__ void pair_rec_store(u64* p, size_t t, int par, const FpS* c) { for (int j = 0; j < W2; j++) store_m384(p + (size_t)6 * (2 * W2 * t + 2 * j + par), c[j]); }
-__global__ void __launch_bounds__(WG, 2) k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size_t n) {
+__global__ void __launch_bounds__(WG, BLSMI_PAIR_WAVES) k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size_t n) {
     namespace P2 = blsmi::pairl;
     const int par = threadIdx.x & 1;
     const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);

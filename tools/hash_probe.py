@@ -15,3 +15,9 @@ for name in ("hash_g1_batch", "hash_g2_batch"):
     for _ in range(3):
         t = time.perf_counter(); f(msgs); best = min(best, time.perf_counter() - t)
     print(f"{name}: n={n} {best*1e3:.2f} ms (host buffers, wall) {n/best/1e6:.3f} M/s")
+dom = bytes(range(8))
+E.hash_g2_with_domain_batch(msgs[:1024], dom)
+best = 1e9
+for _ in range(3):
+    t = time.perf_counter(); E.hash_g2_with_domain_batch(msgs, dom); best = min(best, time.perf_counter() - t)
+print(f"hash_g2_with_domain_batch: n={n} {best*1e3:.2f} ms (host buffers, wall) {n/best/1e6:.3f} M/s")
