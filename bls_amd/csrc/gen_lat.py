@@ -802,26 +802,17 @@ def h2_gls_digits():
 
 
 def scale_by_cofactor_proj(C, P):
+    """[h2] P = [c] Q, Q = clearH2(P), c = sum d_i |x|^i over the psi images Q_i = (-1)^i psi^i(Q); the digits are one:
+    d_1 = 2 d_0 - 1, d_2 = 2 d_0 - 2, d_3 = d_0 - 1, so [h2] P = [d_0](Q_0 + 2 Q_1 + 2 Q_2 + Q_3) - (Q_1 + 2 Q_2 + Q_3) (hash.cuh: scale_by_cofactor_g2)"""
     F = C.F
     q0 = clear_h2_proj(C, P)
-    q1 = psi_proj(F, q0); q2 = psi_proj(F, q1); q3 = psi_proj(F, q2)
-    q = [q0, C.neg(q1), q2, C.neg(q3)]
-    # subset sums of the four points: at most one addition per ladder step
-    table = {0: None}
-    for m in range(1, 16):
-        low = m & -m
-        i = low.bit_length() - 1
-        rest = m ^ low
-        table[m] = q[i] if rest == 0 else C.add(table[rest], q[i])
+    p1 = psi_proj(F, q0); q2 = psi_proj(F, p1); q1 = C.neg(p1); q3 = C.neg(psi_proj(F, q2))
     d = h2_gls_digits()
-    res = None
-    for bit in range(63, -1, -1):
-        if res is not None:
-            res = C.dbl(res)
-        m = sum(((d[i] >> bit) & 1) << i for i in range(4))
-        if m:
-            res = table[m] if res is None else C.add(res, table[m])
-    return res
+    assert d[1] == 2 * d[0] - 1 and d[2] == 2 * d[0] - 2 and d[3] == d[0] - 1
+    a = C.add(q1, q2)
+    t = C.add(C.add(q0, q3), C.dbl(a))
+    s = C.add(C.add(a, q2), q3)
+    return C.add(C.mul_u64(t, d[0]), C.neg(s))
 
 
 def flat12(f):

@@ -393,7 +393,7 @@ BLSMI_DEV G2Jac psi_jac(const G2Jac& g) {
     return r;
 }
 // clearH2 (hash.go:368-389) on a Jacobian input: the same chain with general additions, no intermediate ToAffine
-__device__ __noinline__ void clear_h2_jac(G2Aff& out, const G2Jac& p) {
+BLSMI_DEV G2Jac clear_h2_jac_j(const G2Jac& p) {
     G2Jac work = jac_mul_u64_public(p, BLSMI_X_ABS);
     work = jac_add(work, p);
     const G2Jac mpsi = jac_neg(psi_jac(p));
@@ -401,8 +401,23 @@ __device__ __noinline__ void clear_h2_jac(G2Aff& out, const G2Jac& p) {
     work = jac_mul_u64_public(work, BLSMI_X_ABS);
     work = jac_add(work, mpsi);
     work = jac_add(work, jac_neg(p));
-    work = jac_add(work, psi_jac(psi_jac(jac_double(p))));
-    out = jac_to_affine(work);
+    return jac_add(work, psi_jac(psi_jac(jac_double(p))));
+}
+__device__ __noinline__ void clear_h2_jac(G2Aff& out, const G2Jac& p) { out = jac_to_affine(clear_h2_jac_j(p)); }
+// ScaleByCofactor (g2.go:104-115, 130-138: a bit-serial multiplication by the 507-bit cofactor h2).  Same point, shorter road:
+// clearH2(P) = [3 (x^2 - 1) h2] P on all of E'(Fq2) and lands in G2, where psi acts as x, so [h2] P = [c] Q with Q = clearH2(P) and
+// c = (3 (x^2 - 1))^-1 mod r = sum d_i |x|^i, i.e. sum d_i Q_i with Q_i = (-1)^i psi^i(Q).  The four digits are one:
+// d_0 = (|x| + 1) / 3, d_1 = 2 d_0 - 1, d_2 = 2 d_0 - 2, d_3 = d_0 - 1 (gen_consts.py asserts it), hence
+//     [h2] P = [d_0] (Q_0 + 2 Q_1 + 2 Q_2 + Q_3) - (Q_1 + 2 Q_2 + Q_3):
+// ONE 64-bit multiplication (63 doublings, 27 additions) and seven additions after clearH2's two, nothing leaves Jacobian
+// coordinates before the end (one inversion).  [Until round 3 the four digits ran as a joint ladder: 64 doublings + 110 mixed additions, and clearH2 ended in an inversion of its own.]
+__device__ __noinline__ void scale_by_cofactor_g2(G2Aff& out, const G2Aff& pt) {
+    const G2Jac q0 = clear_h2_jac_j(to_jac(pt));
+    const G2Jac p1 = psi_jac(q0), q2 = psi_jac(p1), q1 = jac_neg(p1), q3 = jac_neg(psi_jac(q2));
+    const G2Jac a = jac_add(q1, q2);
+    const G2Jac t = jac_add(jac_add(q0, q3), jac_double(a));
+    const G2Jac s = jac_add(jac_add(a, q2), q3);
+    out = jac_to_affine(jac_add(jac_mul_u64_public(t, C_H2_D0), jac_neg(s)));
 }
 __device__ __noinline__ void swu_finish_g2(G2Aff& out, G2Aff p1, const G2Aff& p2);
 // hash.go:391-411
@@ -472,21 +487,7 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
         const i32 y_gt = fp2_sign_is_neg(y);                               // y > (q-1)/2 lexicographically (c1 first) <=> y > -y
         pt.y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
     }
-    // ScaleByCofactor multiplies by the 507-bit cofactor h2 with a bit-serial double-and-add (g2.go:104-115, 130-138).
-    // Same point, shorter road: clearH2(P) = [3 (x^2 - 1) h2] P on all of E'(Fq2), it lands in G2 where psi acts as x,
-    // so [h2] P = [c] clearH2(P) with c = (3 (x^2 - 1))^-1 mod r = sum d_i |x|^i, i.e. sum (-1)^i d_i psi^i(clearH2(P)):
-    // two 64-bit multiplications inside clearH2 plus one 64-step joint ladder instead of 506 doublings + ~250 additions.
-    G2Aff q[4];
-    clear_h2_jac(q[0], to_jac(pt));                                       // same point as clearH2(pt), one inversion instead of two
-    psi(q[1], q[0]); psi(q[2], q[1]); psi(q[3], q[2]);
-    q[1] = aff_neg(q[1]); q[3] = aff_neg(q[3]);
-    G2Jac res = jac_zero<Fp2S>();
-    for (int bit = 63; bit >= 0; bit--) {
-        res = jac_double(res);
-        for (int i = 0; i < 4; i++)
-            if ((C_H2_GLS[i] >> bit) & 1) res = jac_add_affine(res, q[i]);
-    }
-    out = jac_to_affine(res);
+    scale_by_cofactor_g2(out, pt);
 }
 
 // The try-and-increment search of HashG2WithDomain (g2.go:1049-1077) with EIGHT lanes per message: lane g of an aligned group of eight tests the candidate x0 + 8 r + g in round r,
