@@ -447,7 +447,8 @@ __device__ __noinline__ void swu_finish_g2(G2Aff& out, G2Aff p1, const G2Aff& p2
 // g2.go:1041-1085: try-and-increment on x0 = (H(m||d||01), H(m||d||02)); favour the y with Parity(),
 // then scale by the 507-bit G2 cofactor (g2.go:130-138).  The loop runs until every lane of the wave
 // has found a square (uniform trip count; finished lanes keep their result).
-__device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, const u8* domain8) {
+// x0 = (H(m || domain || 01), H(m || domain || 02)) as an element of Fq2 (g2.go:1041-1048)
+__device__ __noinline__ void tai_g2_x0(Fp2S& x0, const u8* msg32, const u8* domain8) {
     u32 w[16], dre[8], dim[8];
     for (int tag = 1; tag <= 2; tag++) {                                   // SHA-256 of the 41-byte string m || domain || tag
         for (int i = 0; i < 8; i++) w[i] = ((u32)msg32[4 * i] << 24) | ((u32)msg32[4 * i + 1] << 16) | ((u32)msg32[4 * i + 2] << 8) | msg32[4 * i + 3];
@@ -462,7 +463,10 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
     u32 wre[12], wim[12];
     for (int j = 0; j < 8; j++) { wre[j] = dre[7 - j]; wim[j] = dim[7 - j]; }
     for (int j = 8; j < 12; j++) { wre[j] = 0; wim[j] = 0; }
-    Fp2S x0; x0.c0 = fp_from_words(wre); x0.c1 = fp_from_words(wim);
+    x0.c0 = fp_from_words(wre); x0.c1 = fp_from_words(wim);
+}
+__device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, const u8* domain8) {
+    Fp2S x0; tai_g2_x0(x0, msg32, domain8);
     // The loop only has to DECIDE whether x0^3 + b is a square -- one Fq exponentiation on its norm; the root itself
     // (a second exponentiation) is taken once, after the loop, for the x0 each lane settled on.  The wave iterates until
     // its slowest lane is done (about log2(64) + 1 rounds), so halving the cost of a round matters.
@@ -487,6 +491,65 @@ __device__ __noinline__ void hash_g2_with_domain(G2Aff& out, const u8* msg32, co
         const i32 y_gt = fp2_sign_is_neg(y);                               // y > (q-1)/2 lexicographically (c1 first) <=> y > -y
         pt.y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
     }
+    scale_by_cofactor_g2(out, pt);
+}
+
+// HashG2WithDomain for large batches: the 64 lanes of a wave SHARE the try-and-increment search of their 64 messages.  In the
+// loop above every lane walks its own counter and the wave waits for its unluckiest message (about seven rounds of one Fq
+// exponentiation each); here a round hands the wave's lanes to the messages that are still open -- round 0: candidate 0 of every
+// message; then 64 / (open messages) consecutive candidates of each open message -- so about half, then a quarter ... of the
+// messages close per round and three rounds nearly always do.  The smallest passing counter wins (atomicMin within a round, rounds
+// in increasing order): the x the reference's loop stops at.  A helper lane recomputes the message's x0 (two SHA-256 blocks)
+// and the winner leaves the norm root for the owner in LDS.  lds: TAI_WAVE_LDS_WORDS words per wave; the caller's workgroup is one wave.
+constexpr int TAI_WAVE_LDS_WORDS = 3 * 64 + 64 * NL;
+BLSMI_DEV FpS fp_small_mont(u32 c) {                                       // c * 1 in Montgomery form
+    FpS acc = fp_zero(), pw = C_ONE;
+    for (int i = 0; i < 32; i++) {
+        acc = fp_select(-(i32)((c >> i) & 1), fp_store(fp_add(acc, pw)), acc);
+        pw = fp_store(fp_add(pw, pw));
+    }
+    return acc;
+}
+__device__ __noinline__ void hash_g2_with_domain_wave(G2Aff& out, const u8* msgs32, size_t first, size_t n, const u8* domain8, u32* lds) {
+    u32* win = lds; u32* nextc = lds + 64; u32* list = lds + 128; i32* sbuf = reinterpret_cast<i32*>(lds + 192);
+    const int lane = (int)(threadIdx.x & 63);
+    const bool valid = first + lane < n;
+    const size_t own = valid ? first + lane : n - 1;
+    Fp2S x0; tai_g2_x0(x0, msgs32 + 32 * own, domain8);
+    win[lane] = 0xffffffffu; nextc[lane] = 0;
+    bool open = valid;
+    __syncthreads();
+    while (true) {
+        const unsigned long long U = __ballot(open ? 1 : 0);
+        if (U == 0) break;
+        const int cnt = __popcll(U), k = 64 / cnt;
+        if (open) list[__popcll(U & ((1ull << lane) - 1))] = (u32)lane;
+        __syncthreads();
+        const int slot = lane / k;
+        const bool active = slot < cnt;
+        const int m = (int)list[active ? slot : 0];                        // the wave-local message this lane works for
+        const u32 cand = nextc[m] + (u32)(lane % k);
+        Fp2S xm = x0;
+        if (U != ~0ull) tai_g2_x0(xm, msgs32 + 32 * (first + m), domain8);  // (all 64 open -- round 0 of a full wave: every lane has its own message)
+        xm.c0 = fp_store(fp_add(xm.c0, fp_small_mont(cand)));
+        const Fp2S gx = fp2_store(fp2_add(fp2_mul(fp2_sqr(xm), xm), C_B2));
+        bool ok; FpS nrm;
+        const FpS s = fp2_norm_root(gx, nrm, ok);
+        if (active && ok) atomicMin(&win[m], cand);
+        __syncthreads();
+        if (active && ok && win[m] == cand)
+            for (int i = 0; i < NL; i++) sbuf[m * NL + i] = s.v[i];
+        if (open) { if (win[lane] != 0xffffffffu) open = false; else nextc[lane] += (u32)k; }
+        __syncthreads();
+    }
+    // every owner: the x its search stopped at, g(x), the norm root its winner left
+    G2Aff pt; pt.x = x0; pt.x.c0 = fp_store(fp_add(x0.c0, fp_small_mont(valid ? win[lane] : 0u))); pt.y = fp2_one(); pt.inf = 0;
+    const Fp2S gsel = fp2_store(fp2_add(fp2_mul(fp2_sqr(pt.x), pt.x), C_B2));
+    FpS ssel;
+    for (int i = 0; i < NL; i++) ssel.v[i] = valid ? sbuf[lane * NL + i] : 0;
+    Fp2S y = fp2_sqrt_from_norm_root(gsel, ssel);                          // either root: the choice follows
+    const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() == true (g2.go:1074-1077)
+    pt.y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
     scale_by_cofactor_g2(out, pt);
 }
 

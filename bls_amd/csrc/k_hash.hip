@@ -21,10 +21,11 @@ KERNEL k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n) {
     if (t < n) store_g2(out + 192 * t, h);
 }
 KERNEL k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n) {
+    static_assert(WG == 64, "hash_g2_with_domain_wave: one wave per workgroup");
+    __shared__ u32 lds[TAI_WAVE_LDS_WORDS];
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
-    const size_t tt = t < n ? t : n - 1;
     G2Aff h;
-    hash_g2_with_domain(h, msgs32 + 32 * tt, domain);
+    hash_g2_with_domain_wave(h, msgs32, (size_t)blockIdx.x * WG, n, domain, lds);   // the wave shares its messages' search
     if (t < n) store_g2(out + 192 * t, h);
 }
 // ---- small batches, the hash split in two: these kernels do SHA-256 and the SWU maps (or the try-and-increment search) --

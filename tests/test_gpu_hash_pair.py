@@ -62,5 +62,27 @@ def test_hash_g2_lane_pairs_redo_pass_and_one_lane_kernel_agree():
     assert a == b == c
 
 
+def test_hash_g2_with_domain_shared_search_against_the_latency_path_and_the_oracle():
+    """large batches: the 64 lanes of a wave share their messages' try-and-increment search (hash.cuh: hash_g2_with_domain_wave);
+    1 061 messages = 16 full waves and a tail of 37, judged in full by the latency path (eight lanes per message + level program)
+    and on a sample by the oracle (g2.go:1041-1085)"""
+    from bls_amd import engine
+    from gpu_common import RC
+    engine.init(0)
+    rng = np.random.default_rng(7)
+    msgs = [rng.bytes(32) for _ in range(1061)]
+    dom = bytes(range(1, 9))
+    try:
+        engine.set_latency_threshold(0); x = engine.hash_g2_with_domain_batch(msgs, dom)
+        engine.set_latency_threshold(8192); y = engine.hash_g2_with_domain_batch(msgs, dom)
+        engine.set_latency_threshold(0); few = engine.hash_g2_with_domain_batch(msgs[:3], dom)      # a wave with three messages
+    finally:
+        engine.set_latency_threshold(8192)
+    assert np.array_equal(x, y)
+    assert np.array_equal(few, x[:3])
+    for i in list(range(0, 1061, 97)) + [1024, 1060]:
+        assert x[i].tobytes() == RC.hash_g2_with_domain(msgs[i], dom), i
+
+
 if __name__ == "__main__":
     _worker()
