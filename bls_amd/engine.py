@@ -131,6 +131,11 @@ def verify_batch_dev(group, d_msgs, d_off, d_pks, d_sigs, d_inf, d_ok, n, stream
     _check(fn(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_pks), C.c_void_p(d_sigs), C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_batch_dev")
 
 
+def g1pubs_verify_with_domain_batch_dev(d_msgs32, d_domain, d_pks, d_sigs, d_inf, d_ok, n, stream=0):
+    """VerifyWithDomain (g1pubs/bls.go:171-174) with everything resident on the device (ints = device pointers)"""
+    _check(_lib().blsmi_g1pubs_verify_with_domain_batch_dev(C.c_void_p(d_msgs32), C.c_void_p(d_domain), C.c_void_p(d_pks), C.c_void_p(d_sigs), C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_with_domain_batch_dev")
+
+
 def mul_batch_dev(group, d_pts, d_scalars, d_out, d_out_inf, n, stream=0):
     """k_i * P_i with everything resident on the device (ints = device pointers; d_pts = 0: the group generator)."""
     fn = _lib().blsmi_g1_mul_batch_dev if group == "g1" else _lib().blsmi_g2_mul_batch_dev

@@ -200,6 +200,8 @@ int blsmi_fq12_product(const uint64_t *in_fq12 /* n*72 */, size_t n, uint64_t *o
 /* device-pointer forms of the verify batches (inputs resident in HBM; ok is n bytes on the device) */
 int blsmi_g2pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
 int blsmi_g1pubs_verify_batch_dev(const void *d_msgs, const void *d_off, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
+/* VerifyWithDomain (g1pubs/bls.go:171-174): n 32-byte messages and the 8-byte domain resident on the device */
+int blsmi_g1pubs_verify_with_domain_batch_dev(const void *d_msgs32, const void *d_domain8, const void *d_pks, const void *d_sigs, const void *d_inf_flags, void *d_ok, size_t n, void *stream);
 
 /* device-pointer forms of VerifyAggregate (g2pubs/bls.go:240-270, g1pubs/bls.go:252-282, :300-311): messages, offsets (or the
  * 8-byte domain) and keys resident on one of the library's devices, the aggregate signature in HOST memory (one point).  The

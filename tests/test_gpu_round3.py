@@ -209,6 +209,14 @@ def test_verify_aggregate_with_domain_large_and_dev(eng):
     assert eng.g1pubs_verify_aggregate_with_domain(msgs, dom, allpk, agg) is True
     d_m, d_d, d_k = _dev(b"".join(msgs)), _dev(dom), _dev(allpk)
     assert eng.verify_aggregate_with_domain_dev(d_m.data_ptr(), d_d.data_ptr(), d_k.data_ptr(), agg, n) is True
+    # VerifyWithDomain per tuple (g1pubs/bls.go:171-174), host form and device form: same verdict vector, wrong keys rejected
+    import torch
+    swapped = bytearray(allpk); swapped[96 * 17:96 * 18] = pks[(17 + 1) % nk]; swapped[96 * 8199:96 * 8200] = pks[(8199 + 1) % nk]
+    want = np.ones(n, dtype=bool); want[17] = want[8199] = False
+    assert np.array_equal(eng.g1pubs_verify_with_domain_batch(msgs, dom, bytes(swapped), sigs.reshape(-1)), want)
+    d_ok = torch.zeros(n, dtype=torch.uint8, device=d_m.device)
+    eng.g1pubs_verify_with_domain_batch_dev(d_m.data_ptr(), d_d.data_ptr(), _dev(bytes(swapped)).data_ptr(), _dev(sigs.reshape(-1)).data_ptr(), 0, d_ok.data_ptr(), n)
+    assert np.array_equal(d_ok.cpu().numpy().astype(bool), want)
     bad = bytearray(allpk); bad[96 * 4000:96 * 4001] = pks[(4000 + 1) % nk]
     assert eng.g1pubs_verify_aggregate_with_domain(msgs, dom, bytes(bad), agg) is False
     assert eng.verify_aggregate_with_domain_dev(d_m.data_ptr(), d_d.data_ptr(), _dev(bytes(bad)).data_ptr(), agg, n) is False
