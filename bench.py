@@ -307,6 +307,8 @@ def max_over_ranks(E, dt):
 
 
 def timed_steps(E, step, steps, warmup):
+    # two warm-up calls by default in the legs: the first grows the call context's arena of temporaries (overflow blocks), the
+    # second's lease merges them into one block (hipFree + hipMalloc, sporadically tens of ms) -- neither belongs in a timed step
     for _ in range(warmup):
         step()
     fence(E); t0 = time.perf_counter()
@@ -316,7 +318,7 @@ def timed_steps(E, step, steps, warmup):
     return max_over_ranks(E, time.perf_counter() - t0)
 
 
-def verify_bench(E, steps=5, warmup=1, n=65536):
+def verify_bench(E, steps=5, warmup=2, n=65536):
     """The batch-verify workload under bench.py's own timing discipline, both packages, inputs resident.  With a process
     group the bitmap all-reduce (SUM over disjoint bit ownership == OR, RCCL) runs inside every timed step."""
     import torch
@@ -411,7 +413,7 @@ def verify_bench(E, steps=5, warmup=1, n=65536):
     return out
 
 
-def msm_bench(E, n=1 << 20, steps=3, warmup=1):
+def msm_bench(E, n=1 << 20, steps=3, warmup=2):
     """BASELINE configs[2]: 2^20-point G1 and G2 scalar multiplication and MSM, inputs resident in HBM (rank 0 / device 0)."""
     import torch
     from oracle import refcpu as RC
@@ -466,7 +468,7 @@ def aggregate_dev_bench(E, group, n, reps=3):
 
     def step():
         res["ok"] = engine.verify_aggregate_dev(group, d_m.data_ptr(), d_o.data_ptr(), d_k.data_ptr(), agg, n)
-    dt = timed_steps(E, step, reps, 1)
+    dt = timed_steps(E, step, reps, 2)
     assert res["ok"] is True, "the synthetic aggregate must verify"
     prof = profiled(E.lib, step)
     pkb = 192 if group == "g2pubs" else 96
@@ -484,7 +486,7 @@ def aggregate_dev_bench(E, group, n, reps=3):
 
         def step_prepared():
             res["okp"] = engine.g2pubs_verify_aggregate_prepared_dev(d_m.data_ptr(), d_o.data_ptr(), tab.data_ptr(), 0, agg, n)
-        dtp = timed_steps(E, step_prepared, reps, 1)
+        dtp = timed_steps(E, step_prepared, reps, 2)
         assert res["okp"] is True, "the synthetic aggregate must verify with prepared keys"
         profp = profiled(E.lib, step_prepared)
         idx = torch.arange(n, dtype=torch.int32, device=dev); idx[n // 3] = n // 3 + 1
@@ -547,9 +549,11 @@ def config0(E):
         else:
             y = int.from_bytes(sigs[i, 48:].tobytes(), "big")
             sigs[i, 48:] = np.frombuffer(((RC_Q() - y) % RC_Q()).to_bytes(48, "big"), dtype=np.uint8)
-    t0 = time.perf_counter()
-    ok, _ = engine.g2pubs_verify_batch(msgs, pks.reshape(-1), sigs.reshape(-1))
-    gpu_s = time.perf_counter() - t0
+    gpu_s = 1e9
+    for _ in range(3):                                                     # the call is blocking; best of three (a context's first calls size its temporaries)
+        t0 = time.perf_counter()
+        ok, _ = engine.g2pubs_verify_batch(msgs, pks.reshape(-1), sigs.reshape(-1))
+        gpu_s = min(gpu_s, time.perf_counter() - t0)
     assert np.array_equal(ok, expect), "configs[0]: library verdicts differ from the corruption schedule"
     from concurrent.futures import ThreadPoolExecutor
     cores = usable_cores()
@@ -564,7 +568,7 @@ def config0(E):
     return {"workload": "1 000 (msg, G2 pubkey, G1 sig) tuples through g2pubs.Verify, every 16th corrupted (wrong message / wrong key / negated signature)",
             "cpu": {"value": round(n / cpu_s, 1), "unit": "verifies/s", "cores": cores, "kind": "port", "wall_s": round(cpu_s, 2),
                     "sample": "all 1 000 tuples on the C restatement of the reference (oracle/refcpu.c), %d threads" % cores},
-            "gpu": {"value": round(n / gpu_s, 1), "unit": "verifies/s", "ms_one_call": round(gpu_s * 1e3, 2), "path": "host buffers, one call of 1 000 tuples (latency path: one tuple per wave)"},
+            "gpu": {"value": round(n / gpu_s, 1), "unit": "verifies/s", "ms_one_call": round(gpu_s * 1e3, 2), "path": "host buffers, one call of 1 000 tuples (latency path: one tuple per wave), best of three calls"},
             "verdicts_identical": True, "rejected": int((~expect).sum())}
 
 
