@@ -595,6 +595,17 @@ def inlibrary_bench(E, ndev, n_per_dev=65536, steps=3):
         return b
     t = best(lambda: engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n))
     out["pairings_per_s"] = round(n / t, 1); out["pairing_ms_per_call"] = round(t * 1e3, 2)
+    # the same call from page-locked buffers (blsmi_host_alloc): inputs written there once, the 576-byte results land there
+    hb = [engine.HostBuffer(96 * n), engine.HostBuffer(192 * n), engine.HostBuffer(576 * n)]
+    hb[0].a[:] = g1.reshape(-1); hb[1].a[:] = g2.reshape(-1)
+    pin_out = hb[2].a.view(np.uint64).reshape(n, 72)
+    ref = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
+    t = best(lambda: engine.pairing_batch(hb[0].a, hb[1].a, n, out=pin_out))
+    assert np.array_equal(pin_out, ref), "page-locked buffers: different pairing values"
+    out["pairings_per_s_pinned_host"] = round(n / t, 1); out["pairing_ms_per_call_pinned_host"] = round(t * 1e3, 2)
+    del pin_out
+    for b in hb:
+        b.free()
     for group in ("g2pubs", "g1pubs"):
         packed, pks, sigs = _verify_tuples(engine, group, n, tag=5)
         fn = engine.g2pubs_verify_batch if group == "g2pubs" else engine.g1pubs_verify_batch

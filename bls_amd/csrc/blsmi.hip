@@ -471,6 +471,22 @@ BLSMI_API void blsmi_shutdown(void) {
 }
 BLSMI_API const char* blsmi_version(void) { return g_version; }
 
+// Page-locked host memory for the host entry points' buffers: hipMemcpyAsync from / to pageable memory is staged by the runtime
+// (~10 GB/s), from page-locked memory it is one DMA at PCIe rate.  Portable: every device of the process sees the same mapping.
+BLSMI_API int blsmi_host_alloc(size_t bytes, void** out) {
+    if (!out) return BLSMI_E_ARG;
+    *out = nullptr;
+    if (bytes == 0) return BLSMI_OK;
+    LOCK_AND_INIT();
+    if (hipHostMalloc(out, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return BLSMI_E_NOMEM; }
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_host_free(void* p) {
+    if (!p) return BLSMI_OK;
+    if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return BLSMI_E_ARG; }
+    return BLSMI_OK;
+}
+
 // ---- pairing ------------------------------------------------------------------------------------
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;

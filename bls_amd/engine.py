@@ -99,10 +99,36 @@ def _msgs(msgs):
 
 
 # ---- pairing ---------------------------------------------------------------------------------------
-def pairing_batch(g1_aff, g2_aff, n):
+class HostBuffer:
+    """Page-locked host memory from the library (blsmi_host_alloc) as a numpy uint8 array: `.a`.  Free with .free() (or let it go:
+    the finaliser frees it).  Arrays handed to the host entry points from such memory are copied by DMA instead of being staged."""
+
+    def __init__(self, nbytes):
+        self._p = C.c_void_p()
+        _lib().blsmi_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        _check(_lib().blsmi_host_alloc(C.c_size_t(int(nbytes)), C.byref(self._p)), "blsmi_host_alloc")
+        self.nbytes = int(nbytes)
+        self.a = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(self.nbytes,)) if nbytes else np.zeros(0, np.uint8)
+
+    def free(self):
+        if self._p and self._p.value:
+            _lib().blsmi_host_free.argtypes = [C.c_void_p]
+            _lib().blsmi_host_free(self._p)
+            self._p = C.c_void_p()
+            self.a = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def pairing_batch(g1_aff, g2_aff, n, out=None):
     """n x 96 B G1 affine, n x 192 B G2 affine -> (n, 72) uint64: the reference's in-memory FQ12."""
     a, b = _u8(g1_aff, 96 * n), _u8(g2_aff, 192 * n)
-    out = np.zeros((n, 72), dtype=np.uint64)
+    if out is None:
+        out = np.zeros((n, 72), dtype=np.uint64)
     _check(_lib().blsmi_pairing_batch(_p8(a), _p8(b), out.ctypes.data_as(_u64p), C.c_size_t(n)), "blsmi_pairing_batch")
     return out
 

@@ -59,6 +59,13 @@ void blsmi_shutdown(void);
  * before binding by hand. */
 const char *blsmi_version(void);
 
+/* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
+ * ordinary (pageable) memory, which the HIP runtime stages at ~10 GB/s; from blsmi_host_alloc memory the copies are single DMAs at
+ * PCIe rate (65 536 pairings from host buffers: 26 -> 22 ms).  A cgo caller serialises its points straight into such a buffer
+ * (INTEGRATION.md 2e).  The memory is visible to every device the library drives. */
+int blsmi_host_alloc(size_t bytes, void **out);
+int blsmi_host_free(void *p);
+
 /* ---- pairing (replaces bls.Pairing, pairing.go:132-136; BASELINE config 2) -------------------
  * out[i] = FinalExponentiation(MillerLoop(P_i, Q_i)) for n independent (P_i in G1, Q_i in G2)
  * affine pairs.  Inputs must be finite curve points (the reference panics on infinity). */

@@ -531,3 +531,20 @@ def test_msm_bucket_overflowing_its_slots_takes_the_exact_passes(group):
         col = sum(int.from_bytes(kk[i, j].tobytes(), "big") for i in range(n // base))
         acc = (acc + int.from_bytes(bk[j].tobytes(), "big") * col) % P.R_ORDER
     assert got == (RC.g1_mul if group == "g1" else RC.g2_mul)(gen, acc.to_bytes(32, "big"))
+
+
+def test_page_locked_host_buffers(eng):
+    """blsmi_host_alloc / blsmi_host_free: buffers the host entry points copy from and to by DMA; same values as from pageable memory"""
+    n = 300
+    g1, _ = eng.g1_mul_generator_batch(b"".join((i + 2).to_bytes(32, "big") for i in range(n)), n)
+    g2, _ = eng.g2_mul_generator_batch(b"".join((3 * i + 5).to_bytes(32, "big") for i in range(n)), n)
+    want = eng.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
+    a, b, o = eng.HostBuffer(96 * n), eng.HostBuffer(192 * n), eng.HostBuffer(576 * n)
+    a.a[:] = g1.reshape(-1); b.a[:] = g2.reshape(-1)
+    got = eng.pairing_batch(a.a, b.a, n, out=o.a.view(np.uint64).reshape(n, 72))
+    assert np.array_equal(got, want)
+    assert got[0].tobytes() == RC.pairing_batch(g1[0].tobytes(), g2[0].tobytes(), 1)[0].tobytes()
+    del got
+    for h in (a, b, o):
+        h.free(); h.free()                                                 # the second call is a no-op
+    empty = eng.HostBuffer(0); empty.free()
