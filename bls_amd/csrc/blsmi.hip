@@ -75,36 +75,45 @@ struct Workspace {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-// Temporaries of one call: a bump allocator over a grow-only block of device memory that belongs to the call context.  Every entry
+// Temporaries of one call: a bump allocator over grow-only blocks of device memory that belong to the call context.  Every entry
 // point used to take its temporaries from the stream-ordered pool (hipMallocAsync / hipFreeAsync); a dozen such pairs cost a
 // 2^20-point MSM 2.5 ms of its 14.6 and every small call ~0.1 ms.  A context serves one call at a time and the entry points are
-// blocking, so "free" is resetting the offset when the next call leases the context.  A request that does not fit is served by an
-// overflow block; the next reset merges everything into one block of the peak size (steady state: no allocation at all).
+// blocking, so "free" is resetting the offsets when the next call leases the context.  A request goes to the first block with room;
+// one that fits nowhere gets a block of its own (at least a quarter of what the arena already holds, so the block count stays
+// logarithmic in the peak).  A call that repeats an earlier call's requests finds every one of them in place: steady state makes
+// no runtime call at all -- in particular no hipFree, which synchronises the whole device (the first version merged the blocks
+// into one on the next lease: a sporadic 20-70 ms inside some later call, seen in bench.py legs).
 struct Arena {
-    struct Block { char* p; size_t cap; };
+    struct Block { char* p; size_t cap, used; };
     std::vector<Block> blocks;
-    size_t used = 0, overflow = 0;
+    static constexpr size_t MAX_BLOCKS = 64;
     void* alloc(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
-        if (!blocks.empty() && used + bytes <= blocks[0].cap) { void* r = blocks[0].p + used; used += bytes; return r; }
+        for (auto& b : blocks) if (b.used + bytes <= b.cap) { void* r = b.p + b.used; b.used += bytes; return r; }
+        size_t total = 0;
+        for (auto& b : blocks) total += b.cap;
+        const size_t want = std::max(std::max(bytes, (size_t)1 << 20), (total >> 2) & ~(size_t)255);
         void* q = nullptr;
-        const size_t want = blocks.empty() ? std::max(bytes, (size_t)1 << 20) : bytes;
-        if (hipMalloc(&q, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        blocks.push_back({(char*)q, want});
-        if (blocks.size() == 1) { used = bytes; return q; }
-        overflow += want;
+        if (hipMalloc(&q, want) != hipSuccess) {
+            (void)hipGetLastError();
+            if (want == bytes || hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            blocks.push_back({(char*)q, bytes, bytes});
+            return q;
+        }
+        blocks.push_back({(char*)q, want, bytes});
         return q;
     }
     void reset() {                                                         // caller: the context's previous call has completed
-        if (overflow) {
-            const size_t total = blocks[0].cap + overflow + (overflow >> 2);
+        if (blocks.size() > MAX_BLOCKS) {                                  // many differently-shaped calls: start over with one block of the total
+            size_t total = 0;
+            for (auto& b : blocks) total += b.cap;
             release();
             void* q = nullptr;
-            if (hipMalloc(&q, total) == hipSuccess) blocks.push_back({(char*)q, total}); else (void)hipGetLastError();
+            if (hipMalloc(&q, total) == hipSuccess) blocks.push_back({(char*)q, total, 0}); else (void)hipGetLastError();
         }
-        used = 0; overflow = 0;
+        for (auto& b : blocks) b.used = 0;
     }
-    void release() { for (auto& b : blocks) (void)hipFree(b.p); blocks.clear(); used = 0; overflow = 0; }
+    void release() { for (auto& b : blocks) (void)hipFree(b.p); blocks.clear(); }
 };
 struct Device;
 struct Ctx {
