@@ -510,7 +510,8 @@ BLSMI_DEV FpS fp_small_mont(u32 c) {                                       // c 
     }
     return acc;
 }
-__device__ __noinline__ void hash_g2_with_domain_wave(G2Aff& out, const u8* msgs32, size_t first, size_t n, const u8* domain8, u32* lds) {
+// tai_g2_wave: the search and the root -- the affine point before ScaleByCofactor; hash_g2_with_domain_wave: the whole hash
+__device__ __noinline__ void tai_g2_wave(G2Aff& pt, const u8* msgs32, size_t first, size_t n, const u8* domain8, u32* lds) {
     u32* win = lds; u32* nextc = lds + 64; u32* list = lds + 128; i32* sbuf = reinterpret_cast<i32*>(lds + 192);
     const int lane = (int)(threadIdx.x & 63);
     const bool valid = first + lane < n;
@@ -543,13 +544,17 @@ __device__ __noinline__ void hash_g2_with_domain_wave(G2Aff& out, const u8* msgs
         __syncthreads();
     }
     // every owner: the x its search stopped at, g(x), the norm root its winner left
-    G2Aff pt; pt.x = x0; pt.x.c0 = fp_store(fp_add(x0.c0, fp_small_mont(valid ? win[lane] : 0u))); pt.y = fp2_one(); pt.inf = 0;
+    pt.x = x0; pt.x.c0 = fp_store(fp_add(x0.c0, fp_small_mont(valid ? win[lane] : 0u))); pt.y = fp2_one(); pt.inf = 0;
     const Fp2S gsel = fp2_store(fp2_add(fp2_mul(fp2_sqr(pt.x), pt.x), C_B2));
     FpS ssel;
     for (int i = 0; i < NL; i++) ssel.v[i] = valid ? sbuf[lane * NL + i] : 0;
     Fp2S y = fp2_sqrt_from_norm_root(gsel, ssel);                          // either root: the choice follows
     const i32 y_gt = fp2_sign_is_neg(y);                                   // favour y with Parity() == true (g2.go:1074-1077)
     pt.y = fp2_select(y_gt, y, fp2_store(fp2_neg(y)));
+}
+__device__ __noinline__ void hash_g2_with_domain_wave(G2Aff& out, const u8* msgs32, size_t first, size_t n, const u8* domain8, u32* lds) {
+    G2Aff pt;
+    tai_g2_wave(pt, msgs32, first, n, domain8, lds);
     scale_by_cofactor_g2(out, pt);
 }
 

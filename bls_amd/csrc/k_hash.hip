@@ -101,6 +101,14 @@ KERNEL k_hash_g2_redo(const u8* msgs, const u64* off, const u8* good, u8* out, s
     hash_g2(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
     if (mine) store_g2(out + 192 * t, h);
 }
+// the search and the root alone (the point before ScaleByCofactor, wire format); k_cofac2_pair (k_hash_pair.hip) finishes
+KERNEL k_tai_g2_wave(const u8* msgs32, const u8* domain, u8* pts, size_t n) {
+    __shared__ u32 lds[TAI_WAVE_LDS_WORDS];
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    G2Aff p;
+    tai_g2_wave(p, msgs32, (size_t)blockIdx.x * WG, n, domain, lds);
+    if (t < n) store_g2(pts + 192 * t, p);
+}
 KERNEL k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const u8* good, u8* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x, tt = t < n ? t : n - 1;
     const bool mine = t < n && !good[t];

@@ -12,6 +12,7 @@
 #include "pair_field.cuh"
 using namespace blsmi;
 namespace P2 = blsmi::pairl;
+#include "pair_point_io.inc"
 
 namespace blsmi {
 namespace pairl {
@@ -111,7 +112,7 @@ __device__ __noinline__ void iso3_jac(G2JacP& out, const G2JacP& p) {
     out.inf = p.inf | (fp2_is_zero(out.z) ? -1 : 0);
 }
 // clearH2 (hash.go:368-389) on a Jacobian point: [x^2 - x - 1] P + [x - 1] psi(P) + psi^2(2 P), x = -|x|
-__device__ __noinline__ void clear_h2_jac(G2AffP& out, const G2JacP& p) {
+BLSMI_DEV G2JacP clear_h2_jac_j(const G2JacP& p) {
     G2JacP work = jac_mul_u64_public(p, BLSMI_X_ABS);
     work = jac_add(work, p);
     const G2JacP mpsi = glv_endo1(p);                                      // -psi(P)
@@ -119,8 +120,18 @@ __device__ __noinline__ void clear_h2_jac(G2AffP& out, const G2JacP& p) {
     work = jac_mul_u64_public(work, BLSMI_X_ABS);
     work = jac_add(work, mpsi);
     work = jac_add(work, jac_neg(p));
-    work = jac_add(work, glv_endo2(jac_double(p)));                        // psi^2(2 P)
-    out = jac_to_affine(work);
+    return jac_add(work, glv_endo2(jac_double(p)));                        // psi^2(2 P)
+}
+__device__ __noinline__ void clear_h2_jac(G2AffP& out, const G2JacP& p) { out = jac_to_affine(clear_h2_jac_j(p)); }
+// ScaleByCofactor (g2.go:104-115, 130-138) as hash.cuh's scale_by_cofactor_g2: [h2] P = [d_0](Q_0 + 2 Q_1 + 2 Q_2 + Q_3) - (Q_1 + 2 Q_2 + Q_3),
+// Q_i = (-1)^i psi^i(clearH2(P)), d_0 = (|x| + 1) / 3
+__device__ __noinline__ void scale_by_cofactor(G2AffP& out, const G2AffP& pt) {
+    const G2JacP q0 = clear_h2_jac_j(to_jac(pt));
+    const G2JacP q1 = glv_endo1(q0), q2 = glv_endo2(q0), q3 = glv_endo3(q0);
+    const G2JacP a = jac_add(q1, q2);
+    const G2JacP t = jac_add(jac_add(q0, q3), jac_double(a));
+    const G2JacP s = jac_add(jac_add(a, q2), q3);
+    out = jac_to_affine(jac_add(jac_mul_u64_public(t, C_H2_D0), jac_neg(s)));
 }
 }  // namespace pairl
 }  // namespace blsmi
@@ -168,4 +179,14 @@ __global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u6
             else { store_be48(o + 48 * par, r.x.c); store_be48(o + 96 + 48 * par, r.y.c); }
         }
     }
+}
+
+// HashG2WithDomain of a large batch, second half: ScaleByCofactor of the points k_tai_g2_wave (k_hash.hip) left, a lane pair per point
+__global__ void __launch_bounds__(WG, 2) k_cofac2_pair(const u8* pts, u8* out, size_t n) {
+    const int par = threadIdx.x & 1;
+    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    const size_t t = t0 < n ? t0 : n - 1;
+    P2::G2AffP r;
+    P2::scale_by_cofactor(r, pair_load_g2(pts + 192 * t, par));
+    if (t0 < n) pair_store_g2(out + 192 * t, par, r);
 }

@@ -54,6 +54,7 @@ __global__ void k_tai_g2_lanes8(const u8* msgs32, const u8* domain, u8* pts, siz
 __global__ void k_tai_g2_waves8(const u8* msgs32, const u8* domain, u8* pts, size_t n);
 __global__ void k_hash_g1_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);
 __global__ void k_hash_g2_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);
+__global__ void k_tai_g2_wave(const u8* msgs32, const u8* domain, u8* pts, size_t n);
 __global__ void k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const u8* good, u8* out, size_t n);
 __global__ void k_write_generators(u8* g1, u8* g2);
 __global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
@@ -72,6 +73,7 @@ __global__ void k_debug_swu_g1(const u64* a, u64* out, size_t n);
 __global__ void k_debug_swu_g2(const u64* a, u64* out, size_t n);
 // k_hash_pair.hip
 __global__ void k_hash_g2_pair(const u8* msgs, const u64* off, u8* good, u8* out, size_t n, unsigned redo_every);
+__global__ void k_cofac2_pair(const u8* pts, u8* out, size_t n);
 // k_curve.hip
 __global__ void k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n);

@@ -25,13 +25,15 @@ def _worker():
     engine.init(0)
     engine.set_latency_threshold(0)
     print("DIGEST " + hashlib.sha256(engine.hash_g2_batch(_msgs(2051)).tobytes()).hexdigest())
+    rng = np.random.default_rng(11)
+    print("DOMAIN " + hashlib.sha256(engine.hash_g2_with_domain_batch([rng.bytes(32) for _ in range(1061)], bytes(range(8))).tobytes()).hexdigest())
 
 
 def _run(env):
     e = dict(os.environ); e.update(env)
     out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=e, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    return [l for l in out.stdout.splitlines() if l.startswith("DIGEST ")][0]
+    return [l for l in out.stdout.splitlines() if l.startswith(("DIGEST ", "DOMAIN "))]
 
 
 def test_hash_g2_lane_pairs_against_the_latency_path_and_the_oracle():
@@ -59,7 +61,8 @@ def test_hash_g2_lane_pairs_redo_pass_and_one_lane_kernel_agree():
     a = _run({})                                                                # lane pairs
     b = _run({"BLSMI_HASH_G2_PAIR_REDO_EVERY": "3"})                            # every third message handed to the one-lane routine
     c = _run({"BLSMI_HASH_G2_PAIR": "0"})                                      # the one-lane kernel alone
-    assert a == b == c
+    assert a == b == c and len(a) == 2
+    assert _run({"BLSMI_COFAC2_PAIR": "0"}) == a                                # HashG2WithDomain: the fused one-lane kernel against search kernel + lane-pair ScaleByCofactor
 
 
 def test_hash_g2_with_domain_shared_search_against_the_latency_path_and_the_oracle():
