@@ -51,6 +51,16 @@ int main(int argc, char **argv) {
     for (uint64_t i = 0; i < n; i++) printf(" %d", okp[i]);
     printf("\n");
     if ((rc = blsmi_g2_prepared_destroy(prepared)) != BLSMI_OK) { fprintf(stderr, "prepared_destroy: %d\n", rc); return 1; }
+    /* and out of page-locked staging buffers (blsmi_host_alloc): what a shim that serialises straight into them hands over */
+    void *spk = NULL, *ssg = NULL, *sok = NULL;
+    if (blsmi_host_alloc(192 * n, &spk) != BLSMI_OK || blsmi_host_alloc(96 * n, &ssg) != BLSMI_OK || blsmi_host_alloc(n, &sok) != BLSMI_OK || !spk || !ssg || !sok) { fprintf(stderr, "host_alloc\n"); return 1; }
+    memcpy(spk, pks, 192 * n); memcpy(ssg, sigs, 96 * n);
+    rc = blsmi_g2pubs_verify_batch(msgs, off, (const uint8_t *)spk, (const uint8_t *)ssg, NULL, (uint8_t *)sok, NULL, (size_t)n);
+    if (rc != BLSMI_OK) { fprintf(stderr, "verify from page-locked buffers: %d\n", rc); return 1; }
+    printf("pinned");
+    for (uint64_t i = 0; i < n; i++) printf(" %d", ((uint8_t *)sok)[i]);
+    printf("\n");
+    if (blsmi_host_free(spk) != BLSMI_OK || blsmi_host_free(ssg) != BLSMI_OK || blsmi_host_free(sok) != BLSMI_OK || blsmi_host_free(NULL) != BLSMI_OK) { fprintf(stderr, "host_free\n"); return 1; }
     uint64_t e[72];
     rc = blsmi_pairing_batch(sigs, pks, e, 1);               /* e(sig_0, pk_0) */
     if (rc != BLSMI_OK) { fprintf(stderr, "pairing: %d\n", rc); return 1; }

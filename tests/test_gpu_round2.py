@@ -330,7 +330,7 @@ def test_hash_tail_programs_and_redo_kernels():
 # ---- the boundary from plain C: what cgo compiles from the shim, minus Go ------------------------------------------------------
 def test_c_abi_from_a_plain_c_client(tmp_path):
     """tests/native/abi_client.c (C99, only include/blsmi.h and -lblsmi) verifies tuples one per call -- the Go API's shape,
-    g2pubs/bls.go:159-162 -- as a batch and over prepared keys, and computes one pairing; verdicts and bytes are compared with the oracle."""
+    g2pubs/bls.go:159-162 -- as a batch, over prepared keys and out of page-locked buffers, and computes one pairing; verdicts and bytes are compared with the oracle."""
     import shutil
     import struct
     gcc = shutil.which("gcc")
@@ -352,7 +352,7 @@ def test_c_abi_from_a_plain_c_client(tmp_path):
     assert out.returncode == 0, out.stderr[-500:]
     lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l.strip()}
     want = ["1" if e else "0" for e in expect]
-    assert lines["single"] == want and lines["batch"] == want and lines["prepared"] == want
+    assert lines["single"] == want and lines["batch"] == want and lines["prepared"] == want and lines["pinned"] == want
     e = RC.pairing_batch(sigs[0], pks[0], 1).reshape(-1)
     assert [int(x, 16) for x in lines["pairing"]] == [int(v) for v in e]
 
