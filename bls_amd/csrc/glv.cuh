@@ -143,11 +143,25 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
     scalar_words(scalar, k);
     u32 sub[G::NS][G::KW];
     G::decompose(k, sub);
-    Jac<F> tab[17];
-    tab[0] = jac_zero<F>();
-    tab[1] = to_jac(p);
-    tab[2] = jac_double(tab[1]);
-    for (int j = 3; j <= 16; j++) tab[j] = jac_add_affine(tab[j - 1], p);
+    // the table [1..16] P in AFFINE coordinates -- one shared inversion (Montgomery's trick over the 15 z's) -- so that the 52
+    // additions of the ladder are mixed additions (7M + 4S instead of 11M + 5S); an infinite P makes every entry infinite
+    // (the products vanish, inverse(0) = 0, the flags say so)
+    Jac<F> tj[17];
+    tj[1] = to_jac(p);
+    tj[2] = jac_double(tj[1]);
+    for (int j = 3; j <= 16; j++) tj[j] = jac_add_affine(tj[j - 1], p);
+    F pre[17];
+    pre[2] = tj[2].z;
+    for (int j = 3; j <= 16; j++) pre[j] = f_store(f_mul(pre[j - 1], tj[j].z));
+    F inv = f_store(f_inv(pre[16]));                                        // 1 / (z_2 ... z_16)
+    tj[0] = tj[1]; tj[0].inf = -1;                                          // digit 0: nothing is added
+    for (int j = 16; j >= 2; j--) {                                         // in place: (x, y) become affine, z is not read again
+        const F zi = j > 2 ? f_store(f_mul(inv, pre[j - 1])) : inv;         // 1 / z_j
+        if (j > 2) inv = f_store(f_mul(inv, tj[j].z));
+        const F zi2 = f_store(f_sqr(zi));
+        tj[j].x = f_store(f_mul(tj[j].x, zi2));
+        tj[j].y = f_store(f_mul(f_mul(tj[j].y, zi2), zi));
+    }
     Jac<F> res = jac_zero<F>();
 #pragma unroll 1
     for (int w = G::NWIN - 1; w >= 0; w--) {
@@ -159,9 +173,11 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
         for (int s = 0; s < G::NS; s++) {
             const i32 d = booth5(sub[s], w);
             const i32 neg = d >> 31;                                        // all-ones for a negative digit
-            Jac<F> e = glv_endo_s(tab[(d ^ neg) - neg], s);
-            e.y = f_select(neg, f_store(f_neg(e.y)), e.y);
-            res = jac_add_i(res, e);
+            Jac<F> t = tj[(d ^ neg) - neg];
+            t.z = tj[1].z;                                                  // = 1, and stays 1 under every endomorphism
+            const Jac<F> e = glv_endo_s(t, s);
+            Aff<F> ea; ea.x = e.x; ea.y = f_select(neg, f_store(f_neg(e.y)), e.y); ea.inf = e.inf;
+            res = jac_add_affine_i(res, ea);
         }
     }
     return res;
