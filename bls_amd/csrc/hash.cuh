@@ -173,7 +173,7 @@ BLSMI_DEV void swu_g1_helper_t(G1Aff& out, const FpS& t) {
     const FpS UV = fp_store(fp_mul(U, V));
     FpS e;
     if constexpr (WAVE) e = fp_pow_wave(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
-    else e = fp_pow_const(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
+    else e = fp_pow_qm3o4(fp_mul(UV, V2));
     const FpS y0 = fp_store(fp_mul(UV, e));
     const i32 m0 = fp_eq(fp_mul(fp_sqr(y0), V), U) ? -1 : 0;              // g(x0) is a square
     const FpS vinv = fp_store(fp_mul(fp_mul(UV, V), fp_sqr(e)));           // chi / V
@@ -314,7 +314,7 @@ BLSMI_DEV void swu_g2_helper_t(G2Aff& out, const Fp2S& t) {
     const FpS ab = fp_store(fp_mul(aa, bb)), b2 = fp_store(fp_sqr(bb));
     FpS e;
     if constexpr (WAVE) e = fp_pow_wave(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
-    else e = fp_pow_const(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
+    else e = fp_pow_qm3o4(fp_mul(ab, b2));
     const FpS s0 = fp_store(fp_mul(ab, e));
     const i32 m0 = fp_eq(fp_mul(fp_sqr(s0), bb), aa) ? -1 : 0;             // N(g(x0)) is a square <=> g(x0) is a square
     const FpS binv_p = fp_store(fp_mul(fp_mul(ab, bb), fp_sqr(e)));        // chi / b

@@ -50,7 +50,7 @@ __device__ __noinline__ void swu2_lane_mid(SwuMid& o, const FpS& nden, const FpS
     const FpS nden2 = fp_store(fp_sqr(nden));
     const FpS bb = fp_store(fp_mul(nden2, nden));                           // b = N(V) = N(den)^3
     const FpS ab = fp_store(fp_mul(aa, bb)), b2 = fp_store(fp_sqr(bb));
-    const FpS e = fp_pow_const(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
+    const FpS e = fp_pow_qm3o4(fp_mul(ab, b2));
     o.s0 = fp_store(fp_mul(ab, e));
     o.m0 = fp_eq(fp_mul(fp_sqr(o.s0), bb), aa) ? -1 : 0;                   // N(g(x0)) is a square <=> g(x0) is a square
     const FpS binv_p = fp_store(fp_mul(fp_mul(ab, bb), fp_sqr(e)));        // chi / b
