@@ -158,4 +158,23 @@ template <class F> BLSMI_DEV Jac<F> jac_mul_u64_public(const Jac<F>& p, u64 k) {
     return res;
 }
 
+// [d_0] T for the one digit of ScaleByCofactor (hash.cuh: scale_by_cofactor_g2), d_0 = (|x| + 1) / 3 = 0x4600 5555 5555 aaab: its
+// sixteen nibbles are 0, 4, 5, 6, 10 or 11, so fixed 4-bit windows need five multiples of T (3 doublings + 3 additions to build) and
+// 13 additions in the ladder -- 63 doublings + 16 additions against 62 + 27 bit by bit.
+template <class F> BLSMI_DEV Jac<F> jac_mul_h2_d0(const Jac<F>& t) {
+    static_assert(C_H2_D0 == 0x460055555555aaabull, "the nibble table below is that of this constant");
+    const Jac<F> t2 = jac_double(t), t4 = jac_double(t2), t5 = jac_add(t4, t), t6 = jac_add(t5, t), t10 = jac_double(t5), t11 = jac_add(t10, t);
+    Jac<F> tab[5];
+    tab[0] = t4; tab[1] = t5; tab[2] = t6; tab[3] = t10; tab[4] = t11;
+    Jac<F> res = t4;                                                       // the top nibble
+#pragma unroll 1
+    for (int i = 14; i >= 0; i--) {
+#pragma unroll 1
+        for (int d = 0; d < 4; d++) res = jac_double_i(res);
+        const u32 nib = (u32)(C_H2_D0 >> (4 * i)) & 15u;
+        if (nib) res = jac_add_i(res, tab[nib == 4 ? 0 : nib == 5 ? 1 : nib == 6 ? 2 : nib == 10 ? 3 : 4]);
+    }
+    return res;
+}
+
 }  // namespace blsmi

@@ -812,7 +812,18 @@ def scale_by_cofactor_proj(C, P):
     a = C.add(q1, q2)
     t = C.add(C.add(q0, q3), C.dbl(a))
     s = C.add(C.add(a, q2), q3)
-    return C.add(C.mul_u64(t, d[0]), C.neg(s))
+    # [d_0] t by fixed 4-bit windows: the nibbles of d_0 = 0x4600 5555 5555 aaab are 0, 4, 5, 6, 10, 11 (curve.cuh: jac_mul_h2_d0)
+    assert d[0] == 0x460055555555aaab
+    t2 = C.dbl(t); t4 = C.dbl(t2); t5 = C.add(t4, t); t6 = C.add(t5, t); t10 = C.dbl(t5); t11 = C.add(t10, t)
+    tab = {4: t4, 5: t5, 6: t6, 10: t10, 11: t11}
+    res = t4
+    for i in range(14, -1, -1):
+        for _ in range(4):
+            res = C.dbl(res)
+        nib = (d[0] >> (4 * i)) & 15
+        if nib:
+            res = C.add(res, tab[nib])
+    return C.add(res, C.neg(s))
 
 
 def flat12(f):

@@ -131,7 +131,7 @@ __device__ __noinline__ void scale_by_cofactor(G2AffP& out, const G2AffP& pt) {
     const G2JacP a = jac_add(q1, q2);
     const G2JacP t = jac_add(jac_add(q0, q3), jac_double(a));
     const G2JacP s = jac_add(jac_add(a, q2), q3);
-    out = jac_to_affine(jac_add(jac_mul_u64_public(t, C_H2_D0), jac_neg(s)));
+    out = jac_to_affine(jac_add(jac_mul_h2_d0(t), jac_neg(s)));
 }
 }  // namespace pairl
 }  // namespace blsmi
