@@ -148,8 +148,7 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
     // (the products vanish, inverse(0) = 0, the flags say so)
     Jac<F> tj[17];
     tj[1] = to_jac(p);
-    tj[2] = jac_double(tj[1]);
-    for (int j = 3; j <= 16; j++) tj[j] = jac_add_affine(tj[j - 1], p);
+    for (int j = 2; j <= 16; j++) tj[j] = (j & 1) ? jac_add_affine(tj[j - 1], p) : jac_double(tj[j >> 1]);   // a doubling is cheaper than a mixed addition
     F pre[17];
     pre[2] = tj[2].z;
     for (int j = 3; j <= 16; j++) pre[j] = f_store(f_mul(pre[j - 1], tj[j].z));
