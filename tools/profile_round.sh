@@ -5,7 +5,7 @@
 # usage (on the GPU box, from the repo root): tools/profile_round.sh <tag> [commit]      e.g. r03a 3271d4e
 # outputs: gpurun_out/<tag>_rocprof_summary.txt, gpurun_out/<tag>_counters.json (copy both to profiles/), <tag>_bench.json
 set -u
-TAG=${1:-r03zg}
+TAG=${1:-r03zh}
 export BLSMI_COMMIT=${2:-unknown}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
