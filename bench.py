@@ -282,6 +282,147 @@ def cpu_verify(group, packed, pks, sigs, budget_s=3.0):
     return cpu_timed(work, 1024, "verifies/s", "reference-algorithm %s.Verify calls (hash-to-curve + CompareTwoPairings) of the same tuples" % group, budget_s)
 
 
+def cpu_aggregate(engine, group, m=1024):
+    """VerifyAggregate-shaped CPU baseline: every usable core runs ONE reference-algorithm VerifyAggregate of the same m distinct-message
+    signers (n + 1 full pairings + n hashes, g2pubs/bls.go:240-270), all cores concurrently; verdict True is asserted."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import refcpu as RC
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    pkb = 192 if group == "g2pubs" else 96
+    packed, allpk, agg, _ = _aggregate_inputs(engine, group, 0, m)
+    msgs = [bytes(packed.buf[int(packed.off[i]):int(packed.off[i + 1])]) for i in range(m)]
+    pks = [allpk[i * pkb:(i + 1) * pkb].tobytes() for i in range(m)]
+    sig = bytes(agg)
+    cores = usable_cores()
+    t0 = time.time(); ok1 = o.verify_aggregate(sig, pks[:16], msgs[:16]); per = (time.time() - t0) / 17
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        oks = list(ex.map(lambda k: o.verify_aggregate(sig, pks, msgs), range(cores)))
+    dt = time.time() - t0
+    assert all(oks) and not ok1, "CPU VerifyAggregate: the m-signer aggregate must verify (and its 16-signer prefix must not)"
+    return {"value": round(cores * m / dt, 2), "unit": "signatures/s", "cores": cores, "kind": "port", "single_core_per_s": round(1.0 / per, 2),
+            "sample": "%d concurrent reference-algorithm %s VerifyAggregate calls of %d signers each (%.1f s wall); oracle/refcpu.c" % (cores, group, m, dt)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the stdout line: ONE compact JSON object (< 4 KB) the driver can keep whole; everything else -> bench_detail.json + stderr
+# ---------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _roof_small(r, full=False):
+    """the roofline object of a leg, cut to what the contract names (bound, achieved, peak, unit, frac, traffic + the kernel it is about)"""
+    if not isinstance(r, dict):
+        return None
+    keys = ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch") if full else ("kernel", "kernel_ms", "frac", "traffic")
+    o = _pick(r, keys)
+    if isinstance(o.get("kernel_ms"), dict):                                # headline: both pairing kernels -> the dominant one's duration
+        o["kernel_ms"] = r["kernel_ms"].get(r.get("kernel"))
+    if isinstance(o.get("traffic"), float):
+        o["traffic"] = int(o["traffic"])
+    return o
+
+
+def _cpu_small(c, full=False):
+    if not isinstance(c, dict):
+        return None
+    o = _pick(c, ("value", "unit", "cores", "kind", "single_core_per_s") if full else ("value", "cores"))
+    if full and "sample" in c:
+        o["sample"] = c["sample"][:150]
+    return o
+
+
+def _entry(value, unit, ms, roof, cpu, **more):
+    e = {"value": value, "unit": unit, "ms": ms, "roofline": _roof_small(roof), "cpu_baseline": _cpu_small(cpu)}
+    e.update({k: v for k, v in more.items() if v is not None})
+    return e
+
+
+def compact_configs(d):
+    """five entries, one per BASELINE config, from the legs of the detail object `d` (absent legs -> absent entries)"""
+    def ok(name):
+        return isinstance(d.get(name), dict) and "error" not in d[name]
+    cfg = {}
+    if ok("config0"):
+        c0 = d["config0"]
+        cfg["0"] = _entry(c0["gpu"]["value"], "verifies/s", c0["gpu"]["ms_one_call"], None, c0["cpu"], verdicts_identical=c0.get("verdicts_identical"))
+    cfg["1"] = _entry(d["value"], d["unit"], d["ms_per_step"], d.get("roofline"), d.get("cpu_baseline"),
+                      prepared_g2_per_s=d["pairing_prepared"]["pairings_per_s"] if ok("pairing_prepared") else None)
+    if ok("msm_bench"):
+        cfg["2"] = {k: _entry(v["value"], v["unit"], v["ms_per_step"], v.get("roofline"), v.get("cpu_baseline"))
+                    for k, v in d["msm_bench"].items() if k in ("g1_mul", "g1_msm", "g2_mul", "g2_msm")}
+    a_dev, a_host = (d["g2pubs_aggregate_dev_bench"] if ok("g2pubs_aggregate_dev_bench") else None), (d["aggregate_bench"] if ok("aggregate_bench") else None)
+    if a_dev or a_host:
+        a = a_dev or a_host
+        cfg["3"] = _entry(a["signatures_per_s"], "signatures/s", a["ms"], a.get("roofline"), a.get("cpu_baseline"), n=a.get("signatures"),
+                          host_buffers_ms=a_host["ms"] if a_host and a_dev else None,
+                          prepared_keys_ms=a_dev["prepared_keys"]["ms"] if a_dev and "prepared_keys" in a_dev else None)
+    if ok("g1pubs_aggregate_bench"):
+        a = d["g1pubs_aggregate_bench"]
+        cfg["4"] = _entry(a["signatures_per_s"], "signatures/s", a["ms"], a.get("roofline"), a.get("cpu_baseline"), n=a.get("signatures"))
+    return cfg
+
+
+def compact_line(d, detail_file=None):
+    """The ONE stdout line: the contract's keys + headline roofline / cpu_baseline / valu.frac / counters + five config entries.
+    Guaranteed < LINE_LIMIT bytes: optional parts are dropped in a fixed order if a run ever produced more (they stay in the detail file)."""
+    line = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                     "launch", "devices", "rccl_ranks", "library"))
+    line["config"] = _pick(d.get("config", {}), ("workload", "pairings_per_gpu", "parallelism", "layout"))
+    if len(line["config"].get("workload", "")) > 200:
+        line["config"]["workload"] = line["config"]["workload"][:200]
+    line["roofline"] = _roof_small(d.get("roofline"), full=True)
+    if "cpu_baseline" in d:
+        line["cpu_baseline"] = _cpu_small(d["cpu_baseline"], full=True)
+    v = d.get("valu") or {}
+    line["valu"] = _pick(v, ("frac", "lane_instructions_per_pairing", "achieved", "peak", "unit"))
+    line["counters"] = _pick(d.get("counters", {}), ("file", "stale"))
+    line["self_check"] = _pick(d.get("self_check", {}), ("rows_per_device", "passed"))
+    line["configs"] = compact_configs(d)
+    vb = d.get("verify_bench")
+    if isinstance(vb, dict) and "error" not in vb:
+        line["verifies_per_s"] = {"g2pubs": vb.get("g2pubs_verifies_per_s"), "g1pubs": vb.get("g1pubs_verifies_per_s"),
+                                  "g1pubs_with_domain": (vb.get("g1pubs_with_domain") or {}).get("verifies_per_s"),
+                                  "g2pubs_prepared_keys": (vb.get("g2pubs_prepared_keys") or {}).get("verifies_per_s")}
+    mid = d.get("mid_batches")
+    if isinstance(mid, dict) and "error" not in mid:
+        line["mid_batches"] = mid.get("pairings_per_s")
+    il = d.get("inlibrary_bench")
+    if isinstance(il, dict) and "error" not in il and il.get("devices", 1) > 1:
+        line["inlibrary"] = _pick(il, ("devices", "rccl_ranks", "tuples_per_call", "pairings_per_s", "g2pubs_verifies_per_s", "g1pubs_verifies_per_s"))
+    errs = [k for k, x in d.items() if isinstance(x, dict) and "error" in x]
+    if errs:
+        line["leg_errors"] = errs
+    if detail_file:
+        line["detail"] = detail_file
+    for drop in ("mid_batches", "verifies_per_s", "self_check", "library", "launch"):
+        if len(json.dumps(line, separators=(",", ":"))) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line, separators=(",", ":"))) >= LINE_LIMIT:                  # last resort: configs without their sub-objects
+        for e in line["configs"].values():
+            for sub in (e.values() if "value" not in e else [e]):
+                sub.pop("cpu_baseline", None)
+    return line
+
+
+def write_detail(d):
+    """the full record of a run: bench_detail.json at the repo root, and under gpurun_out/ (what a gpurun call brings back)"""
+    rel = "bench_detail.json"
+    for path in (os.path.join(ROOT, rel), os.path.join(ROOT, "gpurun_out", rel)):
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(d, f, indent=1)
+        except OSError:
+            pass
+    return rel
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # legs
 # ---------------------------------------------------------------------------------------------------------------------
@@ -323,7 +464,7 @@ def verify_bench(E, steps=5, warmup=2, n=65536):
     group the bitmap all-reduce (SUM over disjoint bit ownership == OR, RCCL) runs inside every timed step."""
     import torch
     engine, dev, rank, world, dist = E.engine, E.dev, E.rank, E.world, E.dist
-    out = {"tuples_per_gpu": n, "steps": steps, "warmup": warmup,
+    out = {"tuples_per_gpu": n, "steps": steps, "warmup": warmup, "rccl_ranks": world if E.use_dist else 0,
            "collective": ("one all_reduce(SUM, int32 lanes, disjoint bit ownership) of the %d-byte bitmap over RCCL inside every timed step" % (world * n // 8)) if E.use_dist else "none (one GPU)"}
     weights = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=dev)
     for group in ("g2pubs", "g1pubs"):
@@ -495,6 +636,8 @@ def aggregate_dev_bench(E, group, n, reps=3):
                                 "roofline": roofline_of(profp, n, BYTES[group + "_aggregate"], E.ctr),
                                 "note": "one prepared table per signer resident in HBM; the Miller loops read the lines (k_miller1x2_prep_pair)"}
         del tab
+    if E.cpu:
+        out["cpu_baseline"] = cpu_aggregate(engine, group)
     return out, (packed, allpk, agg)
 
 
@@ -584,7 +727,7 @@ def inlibrary_bench(E, ndev, n_per_dev=65536, steps=3):
     collective).  PCIe-inclusive by construction."""
     engine = E.engine
     n = ndev * n_per_dev
-    out = {"devices": engine.device_count(), "shards": engine.shard_count(), "tuples_per_call": n, "steps": steps,
+    out = {"devices": engine.device_count(), "shards": engine.shard_count(), "tuples_per_call": n, "steps": steps, "rccl_ranks": ndev if ndev > 1 else 0,
            "collective": "ncclAllReduce(uint8 SUM, disjoint bit ownership) of the %d-byte bitmap inside every verify call" % (n // 8) if ndev > 1 else "none (one device: the call is not split)"}
     g1, g2 = synth_inputs(engine, n, seed=99)
 
@@ -723,13 +866,14 @@ def main():
 
     # parity gate, outside the timed region, on every rank and device: a fast kernel with different results is not a result
     from oracle import refcpu as RC
-    idx = sorted({0, 1, 63, 64, n // 3, n // 2, n - 65, n - 1} & set(range(n)))
+    # one whole workgroup's rows (the first 64 tuples) + 8 rows spread over the batch; the full 65 536 rows: tests/test_gpu_fullsize.py
+    idx = sorted((set(range(64)) | {64, n // 3, n // 2, n // 2 + 1, n - 130, n - 65, n - 2, n - 1}) & set(range(n)))
+    want = RC.pairing_batch(g1[idx].tobytes(), g2[idx].tobytes(), len(idx))
     good, bad_at = True, None
     for di, (_, _, o) in enumerate(bufs):
         got = o[idx].cpu().numpy().view(np.uint64)
-        for kk, i in enumerate(idx):
-            if not np.array_equal(got[kk], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]):
-                good, bad_at = False, (di, i)
+        if not np.array_equal(got, want):
+            good, bad_at = False, (di, [idx[k] for k in range(len(idx)) if not np.array_equal(got[k], want[k])][:4])
     flag = torch.tensor([0 if good else 1], dtype=torch.int32, device=E.dev)
     if E.use_dist:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -815,10 +959,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (15 x 27-bit limbs, int64 accumulate)",
             "data": "synthetic",
             "launch": "torchrun: one process per GPU" if torchrun else "single process: %d device(s) behind the C ABI (blsmi_init_devices)" % ndev,
-            "devices": total_gpus, "rccl_ranks": world if E.use_dist else (ndev if ndev > 1 else 0),
+            "devices": total_gpus, "rccl_ranks": world if E.use_dist else 0,
             "library": engine.version(),
-            "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exp) per GPU per step, inputs resident in HBM, "
-                                   "output bit-exact Fq12 (tests/test_gpu_pairing.py; %d rows per device re-checked against the oracle after the timed region)" % (n, len(idx)),
+            "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exponentiation = bls.Pairing) per GPU per step, inputs resident in HBM, output bit-exact Fq12" % n,
                        "pairings_per_gpu": n, "parallelism": "shard%d" % total_gpus,
                        "layout": "one tuple per lane" if suffix == "" else "lane pair per tuple (one Fq2 coefficient per lane), 2 waves/SIMD"},
             "self_check": {"rows_per_device": len(idx), "against": "oracle Pairing() (oracle/refcpu.c), bit-exact 576-byte Fq12", "passed": True},
@@ -847,41 +990,20 @@ def main():
                 line["reference_shapes"] = {"error": repr(e)[:300]}
         if E.cpu:
             line["cpu_baseline"] = cpu_pairing(g1, g2)
-            if "g2pubs_aggregate_dev_bench" in line and "error" not in line["g2pubs_aggregate_dev_bench"] and "verify_bench" in line:
-                pass
-        # ---- one entry per BASELINE config ----
-        cfg = {}
-        if "config0" in line:
-            cfg["0"] = line["config0"]
-        cfg["1"] = {"workload": line["config"]["workload"], "value": line["value"], "unit": "pairings/s", "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "frac", "traffic")} if roof else None,
-                    "cpu_baseline": {k: line["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind")} if "cpu_baseline" in line else None}
-        if "pairing_prepared" in line and "error" not in line["pairing_prepared"]:
-            cfg["1"]["prepared_g2"] = {k: line["pairing_prepared"][k] for k in ("pairings_per_s", "ms_per_step", "prepare_points_per_s")}
-        if "msm_bench" in line and "error" not in line["msm_bench"]:
-            cfg["2"] = {"workload": "2^20-point G1 and G2 scalar multiplication + MSM, resident", **{k: line["msm_bench"][k] for k in ("g1_mul", "g1_msm", "g2_mul", "g2_msm") if k in line["msm_bench"]}}
-        if "aggregate_bench" in line and "error" not in line["aggregate_bench"]:
-            cfg["3"] = {"workload": "one 2^20-signature g2pubs VerifyAggregate, distinct messages, %d GPU(s)" % total_gpus,
-                        "host_buffers": {k: line["aggregate_bench"][k] for k in ("ms", "signatures_per_s", "exchange")}}
-            if "g2pubs_aggregate_dev_bench" in line and "error" not in line["g2pubs_aggregate_dev_bench"]:
-                cfg["3"]["resident"] = line["g2pubs_aggregate_dev_bench"]
-        if "g1pubs_aggregate_bench" in line and "error" not in line["g1pubs_aggregate_bench"]:
-            cfg["4"] = dict(workload="one 262 144-message g1pubs VerifyAggregate (G1 pubkeys, G2 signatures), one GPU", **line["g1pubs_aggregate_bench"])
-        if E.cpu and "verify_bench" in line and "g2pubs_cpu_baseline" in line["verify_bench"]:
-            vb = line["verify_bench"]
-            # the CPU does n + 1 full pairings + n hashes per aggregate: ~ one Verify's work per signature (2 Miller loops + FE + hash vs 1 + FE + hash)
-            for key, grp in (("3", "g2pubs"), ("4", "g1pubs")):
-                if key in cfg and grp + "_cpu_baseline" in vb:
-                    cfg[key]["cpu_baseline"] = dict(vb[grp + "_cpu_baseline"], note="per signature the reference's VerifyAggregate does one hash-to-curve + one full Pairing (n + 1 pairings in all, "
-                                                    "g2pubs/bls.go:262-268); %s.Verify on the same host (hash + 2-pair Miller loop + final exponentiation) is the closest timed shape, within ~25 %% of it" % grp)
-        line["configs"] = cfg
-        sys.stdout.flush()
-        os.dup2(saved_stdout, 1)
-        print(json.dumps(line), flush=True)
-        os.dup2(2, 1)
+        # ---- output: everything into bench_detail.json and onto stderr; the compact line is the LAST thing the run writes ----
+        line["configs"] = compact_configs(line)
+        detail_rel = write_detail(line)
+        text = json.dumps(compact_line(line, detail_rel), separators=(",", ":"))
+        assert len(text) < LINE_LIMIT, "bench.py: the stdout line is %d bytes (limit %d)" % (len(text), LINE_LIMIT)
+        print("bench.py detail (also in %s):\n%s" % (detail_rel, json.dumps(line)), file=sys.stderr, flush=True)
     if E.use_dist:
         dist.barrier()
         dist.destroy_process_group()
-
+    if rank == 0:
+        sys.stdout.flush(); sys.stderr.flush()
+        os.dup2(saved_stdout, 1)
+        print(text, flush=True)
+        os.dup2(2, 1)
 
 if __name__ == "__main__":
     main()
