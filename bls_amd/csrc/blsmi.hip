@@ -58,7 +58,7 @@ std::mutex g_mu;
 std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
-char g_version[200] = "blsmi 0.4 (uninitialised)";
+char g_version[200] = "blsmi 0.5 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
@@ -114,6 +114,19 @@ struct Arena {
         for (auto& b : blocks) b.used = 0;
     }
     void release() { for (auto& b : blocks) (void)hipFree(b.p); blocks.clear(); }
+    size_t total() const { size_t t = 0; for (auto& b : blocks) t += b.cap; return t; }
+    // give back blocks, largest first, until at most `keep` bytes remain.  Caller: no work of this context is in flight.  Returns bytes freed.
+    size_t trim(size_t keep) {
+        size_t t = total(), freed = 0;
+        while (t > keep && !blocks.empty()) {
+            size_t big = 0;
+            for (size_t i = 1; i < blocks.size(); i++) if (blocks[i].cap > blocks[big].cap) big = i;
+            (void)hipFree(blocks[big].p);
+            t -= blocks[big].cap; freed += blocks[big].cap;
+            blocks.erase(blocks.begin() + big);
+        }
+        return freed;
+    }
 };
 struct Device;
 struct Ctx {
@@ -129,6 +142,7 @@ struct Ctx {
     Device* dev = nullptr;
     // per-kernel timing (blsmi_set_profiling): events recorded between the major kernels of the call that holds this context
     std::vector<hipEvent_t> pev; std::vector<const char*> pname; size_t pused = 0;
+    bool pclosed = false;               // the call's closing mark is already recorded (on a caller-supplied stream, by UseStream)
     hipError_t ensure_aux() {
         if (aux[0]) return hipSuccess;
         hipError_t e;
@@ -149,6 +163,7 @@ struct Device {
     Ctx ctx[MAX_CTX];
     Gens gens;
     int leased = 0;                     // contexts in use (device choice for unpinned calls)
+    unsigned long long leases = 0;      // context leases served since initialisation (blsmi_debug_device_leases)
     // collectives: one RCCL communicator rank and one stream per device, plus a grow-only exchange buffer
     ncclComm_t comm = nullptr;
     hipStream_t coll_stream = nullptr;
@@ -161,6 +176,10 @@ size_t g_shard_min = 8192;              // batches below this many tuples are no
 bool g_force_rccl = false;              // BLSMI_FORCE_RCCL=1: build the communicator even for one device (exercises the collective path on a 1-GPU box)
 int g_nctx = 4;                         // BLSMI_STREAMS: contexts per device
 int g_rr = 0;                           // round-robin start for unpinned leases
+// Retention cap of a call context's temporaries (arena + Miller-loop hand-off buffer): what a context holds beyond this many bytes when
+// its call ends goes back to the driver there and then (BLSMI_ARENA_KEEP_MB, default 4096; blsmi_trim for an explicit give-back).
+// Without it every context kept the peak of the largest call it ever served -- tens of GB after a burst of 2^20-point calls.
+size_t g_arena_keep = (size_t)4096 << 20;
 thread_local Ctx* tl_ctx = nullptr;
 #define g_stream (tl_ctx->stream)
 #define g_ws (tl_ctx->ws)
@@ -193,6 +212,14 @@ struct Rccl {
     }
 } g_rccl;
 bool g_have_comm = false;
+// TEST HOOK (BLSMI_DEVICE_ALIAS=0,0[,0,0], read by blsmi_init_devices): N LOGICAL devices -- each with its own context pool, streams,
+// generator tables and exchange buffer, exactly what a device of an N-GPU node gets -- that all sit on the physical GPUs the list names.
+// RCCL refuses two ranks on one GPU, so under the hook (and only there) the two collectives are a host-staged stand-in with the same
+// semantics (coll_* in verify_host.inc); the product path is RCCL.  A one-GPU box thereby executes g_dev[d] for d > 0, the
+// `shard % ndev` routing, the per-device pools and the owner routing of the *_dev entry points (blsmi_debug_alias_own).
+bool g_alias = false;
+struct AliasRange { const char* lo; const char* hi; int dev; };
+std::vector<AliasRange> g_alias_own;   // device-pointer ranges assigned to a logical device (g_mu)
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, g_rccl.GetErrorString(r_)); return BLSMI_E_RCCL; } } while (0)
 
 inline unsigned nblocks(size_t n) { return (unsigned)((n + WG - 1) / WG); }
@@ -236,9 +263,13 @@ int init_device(Device& d) {            // caller holds g_mu
 }
 // Latency path (k_lat.hip): batches of at most g_lat_max tuples run one tuple per WAVE instead of one per lane pair.
 // (2 048 waves fit the chip at once; beyond a few thousand tuples the lane-pair kernels win on throughput.)
+// per-call opt-out of the endomorphism ladders (the *_ex entry points with BLSMI_MUL_ANY_POINT): set on every thread that works for such a call
+thread_local bool tl_mul_any = false;
+struct MulAny { bool saved; explicit MulAny(bool on) : saved(tl_mul_any) { tl_mul_any = on; } ~MulAny() { tl_mul_any = saved; } };
 std::atomic<bool> g_mul_subgroup{true}; // scalar multiplication through the endomorphisms (multiplicands in the subgroup); BLSMI_MUL_GENERIC=1 / blsmi_set_mul_assume_subgroup(0): plain ladder
 std::atomic<size_t> g_lat_max{8192};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely).  The two paths meet at ~10 000 tuples
                                         // for pairings and verifies alike (tools/crossover.py: 8192 pairings 8.4 ms against 10.7, 16 384: 16.4 against 11.3)
+inline bool mul_subgroup() { return !tl_mul_any && g_mul_subgroup.load(std::memory_order_relaxed); }
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -248,7 +279,7 @@ int ensure_init_list(const int* devs, int ndev) {
     if (ndev < 1 || ndev > MAX_DEV) return BLSMI_E_ARG;
     for (int i = 0; i < ndev; i++) {
         if (devs[i] < 0 || devs[i] >= count) return BLSMI_E_ARG;
-        for (int j = 0; j < i; j++) if (devs[j] == devs[i]) return BLSMI_E_ARG;
+        for (int j = 0; j < i; j++) if (devs[j] == devs[i] && !g_alias) return BLSMI_E_ARG;
     }
     const char* lay = getenv("BLSMI_LAYOUT");
     g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
@@ -256,10 +287,11 @@ int ensure_init_list(const int* devs, int ndev) {
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
     if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_ARENA_KEEP_MB")) g_arena_keep = (size_t)strtoull(v, nullptr, 10) << 20;
     if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
     for (int i = 0; i < ndev; i++) {
-        g_dev[i].id = devs[i]; g_dev[i].index = i;
+        g_dev[i].id = devs[i]; g_dev[i].index = i; g_dev[i].leases = 0;
         int rc = init_device(g_dev[i]);
         if (rc) return rc;
     }
@@ -267,7 +299,10 @@ int ensure_init_list(const int* devs, int ndev) {
     g_nshards = ndev;
     if (const char* v = getenv("BLSMI_SHARDS")) { int k = atoi(v); if (k >= 1 && k <= 64) g_nshards = k; }
     if (const char* v = getenv("BLSMI_SHARD_MIN")) g_shard_min = (size_t)strtoull(v, nullptr, 10);
-    if (ndev > 1 || g_force_rccl) {
+    if (g_alias) {                                                         // host-staged stand-in for the collectives (test hook)
+        for (int i = 0; i < ndev; i++) { HIPCHK(hipSetDevice(g_dev[i].id)); HIPCHK(hipStreamCreateWithFlags(&g_dev[i].coll_stream, hipStreamNonBlocking)); }
+        g_have_comm = ndev > 1;
+    } else if (ndev > 1 || g_force_rccl) {
         if (!g_rccl.load()) return BLSMI_E_RCCL;
         ncclComm_t comms[MAX_DEV];
         NCCLCHK(g_rccl.CommInitAll(comms, ndev, devs));
@@ -281,7 +316,7 @@ int ensure_init_list(const int* devs, int ndev) {
     HIPCHK(hipSetDevice(g_dev[0].id));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g_dev[0].id));
-    snprintf(g_version, sizeof g_version, "blsmi 0.4 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_have_comm ? " rccl" : "");
+    snprintf(g_version, sizeof g_version, "blsmi 0.5 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_alias ? " ALIASED-DEVICES(test hook: host-staged collectives)" : g_have_comm ? " rccl" : "");
     g_ready = true;
     return BLSMI_OK;
 }
@@ -341,15 +376,24 @@ struct CtxLease {
         if (dev_index < 0) g_rr = (g_rr + 1) % g_ndev;
         if (hipSetDevice(c->dev->id) != hipSuccess) { rc = BLSMI_E_HIP; return; }      // the current device is per-thread state
         if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = BLSMI_E_HIP; return; }
-        c->busy = true; c->dev->leased++;
-        c->pused = 0;
-        c->arena.reset();                                                   // the temporaries of the context's previous call
+        c->busy = true; c->dev->leased++; c->dev->leases++;
+        c->pused = 0; c->pclosed = false;
+        c->arena.reset();                                                   // the temporaries of the context's previous call (its streams are idle: see the destructor)
         outer = tl_ctx;
         tl_ctx = mine = c;
     }
     ~CtxLease() {
         if (!mine) return;
-        if (mine->pused) { prof_mark(nullptr); prof_collect(*mine); }
+        if (mine->pused) { if (!mine->pclosed) prof_mark(nullptr); prof_collect(*mine); }
+        // Entry points are blocking, so on every normal return the context's streams are idle and these queries cost a microsecond.
+        // An ERROR return (HIPCHK, a nonzero rc) leaves without synchronising: drain whatever it had enqueued, so that the next call on
+        // this context does not recycle arena memory under a kernel or copy that is still running.
+        if (mine->stream && hipStreamQuery(mine->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(mine->stream); }
+        for (auto a : mine->aux) if (a && hipStreamQuery(a) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(a); }
+        if (mine->arena.total() + mine->ws.cap > g_arena_keep) {           // retention cap: an outsized call's temporaries go back now
+            if (mine->ws.cap > g_arena_keep / 2) mine->ws.release();
+            (void)mine->arena.trim(g_arena_keep > mine->ws.cap ? g_arena_keep - mine->ws.cap : 0);
+        }
         { std::lock_guard<std::mutex> lk(g_mu); mine->busy = false; mine->dev->leased--; }
         tl_ctx = outer;
         if (outer) (void)hipSetDevice(outer->dev->id);
@@ -360,14 +404,24 @@ struct CtxLease {
 // A caller-supplied stream (the *_dev entry points) stands in for the leased context's stream for one call.
 struct UseStream {
     hipStream_t saved;
-    explicit UseStream(void* s) : saved(tl_ctx->stream) { if (s) tl_ctx->stream = (hipStream_t)s; }
-    ~UseStream() { tl_ctx->stream = saved; }
+    bool mine;
+    explicit UseStream(void* s) : saved(tl_ctx->stream), mine(s != nullptr) { if (s) tl_ctx->stream = (hipStream_t)s; }
+    ~UseStream() {
+        if (mine) {
+            // the closing profile mark belongs on the stream the kernels ran on, not on the context's own stream
+            if (tl_ctx->pused && !tl_ctx->pclosed) { prof_mark(nullptr); tl_ctx->pclosed = true; }
+            // an error return leaves work on the CALLER's stream: drain it before the call's temporaries can be recycled
+            if (hipStreamQuery(tl_ctx->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(tl_ctx->stream); }
+        }
+        tl_ctx->stream = saved;
+    }
 };
 // device (index into g_dev) that owns a device pointer handed to a *_dev entry point; -1 if it is not one of ours
 int device_index_of_pointer(const void* p) {
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_alias) for (auto& r : g_alias_own) if ((const char*)p >= r.lo && (const char*)p < r.hi) return r.dev < g_ndev ? r.dev : -1;
     return device_index_of_ordinal(a.device);
 }
 
@@ -431,12 +485,47 @@ BLSMI_API int blsmi_init_devices(int ndev) {
     std::lock_guard<std::mutex> lk(g_mu);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return BLSMI_E_NODEVICE;
+    int devs[MAX_DEV];
+    int nalias = 0;
+    if (const char* al = getenv("BLSMI_DEVICE_ALIAS")) {                   // test hook: logical devices on the listed physical ones
+        for (const char* q = al; *q && nalias < MAX_DEV;) {
+            char* end = nullptr;
+            long v = strtol(q, &end, 10);
+            if (end == q || v < 0 || v >= count) return BLSMI_E_ARG;
+            devs[nalias++] = (int)v;
+            q = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') return BLSMI_E_ARG;
+        }
+    }
+    if (nalias) {
+        if (ndev <= 0) ndev = nalias;
+        if (ndev > nalias) return BLSMI_E_ARG;
+        if (g_ready) return (ndev == g_ndev && g_alias) ? BLSMI_OK : BLSMI_E_ARG;
+        g_alias = true;
+        int rc = ensure_init_list(devs, ndev);
+        if (rc) g_alias = false;
+        return rc;
+    }
     if (ndev <= 0) ndev = count;
     if (ndev > count || ndev > MAX_DEV) return BLSMI_E_ARG;
     if (g_ready) return ndev == g_ndev ? BLSMI_OK : BLSMI_E_ARG;
-    int devs[MAX_DEV];
     for (int i = 0; i < ndev; i++) devs[i] = i;
     return ensure_init_list(devs, ndev);
+}
+// TEST HOOK, meaningful only under BLSMI_DEVICE_ALIAS: the device-pointer range [p, p + bytes) belongs to logical device `device_index`
+// (on real hardware hipPointerGetAttributes answers this; aliased devices share one ordinal).  bytes == 0 forgets the range at p.
+BLSMI_API int blsmi_debug_alias_own(const void* p, size_t bytes, int device_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_alias || !p || device_index < 0 || device_index >= g_ndev) return BLSMI_E_ARG;
+    for (size_t i = 0; i < g_alias_own.size(); i++) if (g_alias_own[i].lo == (const char*)p) { g_alias_own.erase(g_alias_own.begin() + i); break; }
+    if (bytes) g_alias_own.push_back({(const char*)p, (const char*)p + bytes, device_index});
+    return BLSMI_OK;
+}
+// context leases (= entry-point calls and shards of split calls) device `device_index` has served since blsmi_init*; -1: no such device
+BLSMI_API long long blsmi_debug_device_leases(int device_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ready || device_index < 0 || device_index >= g_ndev) return -1;
+    return (long long)g_dev[device_index].leases;
 }
 BLSMI_API int blsmi_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_ready ? g_ndev : 0; }
 BLSMI_API int blsmi_shard_count(void) { std::lock_guard<std::mutex> lk(g_mu); return g_ready ? g_nshards : 0; }
@@ -475,8 +564,44 @@ BLSMI_API void blsmi_shutdown(void) {
         if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     }
     g_have_comm = false;
+    g_alias = false; g_alias_own.clear();
     g_ndev = 0;
     g_ready = false;
+}
+// Give device memory the library holds for FUTURE calls back to the driver: every idle call context's temporaries beyond
+// keep_bytes_per_context (0: all of them) and the stream-ordered pool's cache.  Contexts serving a call are skipped.  Tables the caller
+// created (blsmi_g2_prepared_create) and the per-device constants are not touched.
+BLSMI_API int blsmi_trim(size_t keep_bytes_per_context, size_t* freed_bytes) {
+    std::unique_lock<std::mutex> lk(g_mu);
+    size_t freed = 0;
+    if (freed_bytes) *freed_bytes = 0;
+    if (!g_ready) return BLSMI_OK;
+    for (int d = 0; d < g_ndev; d++) {
+        Device& dv = g_dev[d];
+        HIPCHK(hipSetDevice(dv.id));
+        for (int i = 0; i < MAX_CTX; i++) {
+            Ctx& c = dv.ctx[i];
+            if (c.busy) continue;                                          // under g_mu: nobody can lease it meanwhile
+            if (c.ws.cap > keep_bytes_per_context) { freed += c.ws.cap; c.ws.release(); }
+            freed += c.arena.trim(keep_bytes_per_context > c.ws.cap ? keep_bytes_per_context - c.ws.cap : 0);
+        }
+        bool any_busy = false;
+        for (int i = 0; i < MAX_CTX; i++) any_busy |= dv.ctx[i].busy;
+        if (!any_busy && dv.coll.cap > keep_bytes_per_context) { freed += dv.coll.cap; dv.coll.release(); }
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+    }
+    if (tl_ctx) (void)hipSetDevice(tl_ctx->dev->id);
+    if (freed_bytes) *freed_bytes = freed;
+    return BLSMI_OK;
+}
+// bytes of device memory the call contexts currently hold for temporaries (all devices); diagnostic companion of blsmi_trim
+BLSMI_API size_t blsmi_held_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    size_t t = 0;
+    if (!g_ready) return 0;
+    for (int d = 0; d < g_ndev; d++) { for (int i = 0; i < MAX_CTX; i++) t += g_dev[d].ctx[i].arena.total() + g_dev[d].ctx[i].ws.cap; t += g_dev[d].coll.cap; }
+    return t;
 }
 BLSMI_API const char* blsmi_version(void) { return g_version; }
 
@@ -540,6 +665,26 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
 BLSMI_API int blsmi_set_latency_threshold(size_t max_tuples) {
     g_lat_max.store(max_tuples);
     return BLSMI_OK;
+}
+// Latency hint for the host shim: 1 when n operations of `shape` in ONE call are expected to finish sooner on one core of the upstream
+// pure-Go path than on the device.  A lone call costs the depth of one wave walking the whole computation (flat in n up to ~2 000
+// operations), so the break-even is n* = device latency of a lone call / CPU time per operation -- both measured by bench.py's
+// `reference_shapes` leg (profiles/r04*_bench_detail.json: one MI355X against one host core on the C restatement of the reference).
+BLSMI_API int blsmi_prefer_cpu(int shape, size_t n) {
+    struct Row { float gpu_ms_lone_call, cpu_ms_per_op; };
+    static const Row rows[] = {
+        /* BLSMI_SHAPE_PAIRING         */ {1.38f, 2.92f},
+        /* BLSMI_SHAPE_MILLER_LOOP     */ {0.71f, 0.54f},      // over an already prepared G2 argument, as bls.MillerLoop takes it
+        /* BLSMI_SHAPE_FINAL_EXP       */ {0.84f, 2.14f},
+        /* BLSMI_SHAPE_G2_PREPARE      */ {1.39f, 0.19f},
+        /* BLSMI_SHAPE_VERIFY          */ {2.19f, 3.72f},
+        /* BLSMI_SHAPE_SIGN            */ {1.43f, 0.45f},
+        /* BLSMI_SHAPE_VERIFY_DOMAIN   */ {3.18f, 5.62f},
+        /* BLSMI_SHAPE_POINT_ADD       */ {0.25f, 0.0065f},    // AggregateSignatures / AggregatePublicKeys: one Jacobian addition per element
+    };
+    if (shape < 0 || shape >= (int)(sizeof rows / sizeof rows[0])) return 0;
+    if (n == 0) return 1;
+    return (double)n * rows[shape].cpu_ms_per_op < rows[shape].gpu_ms_lone_call ? 1 : 0;
 }
 BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
     g_mul_subgroup.store(on != 0);
@@ -699,7 +844,7 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
         HIPCHK(hipGetLastError());
         return BLSMI_OK;
     }
-    if (m <= g_lat_max && g_mul_subgroup.load(std::memory_order_relaxed)) { // small call: one multiplication per wave (k_lat.hip, SEL levels over the decomposed scalar)
+    if (m <= g_lat_max && mul_subgroup()) { // small call: one multiplication per wave (k_lat.hip, SEL levels over the decomposed scalar)
         const size_t prog = PB == 96 ? LAT_MUL1_OFFSET : LAT_MUL2_OFFSET;
         DBuf good, rec; HIPCHK(good.alloc(m, s)); HIPCHK(rec.alloc(64 * m, s));
         hipLaunchKernelGGL(k_glv_recode, dim3(nblocks(m)), dim3(WG), 0, s, d_scalars, PB == 96 ? 1 : 2, rec.as<u8>(), m);
@@ -714,7 +859,7 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
     }
     // points of the prime-order subgroup (the default): the ladder through the curve endomorphisms (glv.cuh) -- half / a quarter
     // of the doublings; arbitrary curve points (blsmi_set_mul_assume_subgroup(0)): the plain fixed-window ladder
-    const bool glv = g_mul_subgroup.load(std::memory_order_relaxed);
+    const bool glv = mul_subgroup();
     if (glv) {
         prof_mark(PB == 192 ? (g_pair_layout ? "k_g2_mul_glv_pair" : "k_g2_mul_glv") : "k_g1_mul_glv");
         if (PB == 192 && g_pair_layout) hipLaunchKernelGGL(k_g2_mul_glv_pair, dim3((unsigned)((m + PT - 1) / PT)), dim3(WG), 0, s, base, stride, d_scalars, d_out, d_inf, m);
@@ -734,7 +879,7 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
     return BLSMI_OK;
 }
 template <int PB, class K>
-static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) {
+static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n, bool any_point = false) {
     if (n && ((!pts && !gen_group) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
     if (n == 0) return BLSMI_OK;
     { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc; }
@@ -742,6 +887,7 @@ static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t*
     // logical shards): each block has its own host thread and stream, so one block's copies run beside another's kernel
     return run_shards(plan_shards(n, 64), [&](int, size_t lo, size_t hi) -> int {
         const size_t m = hi - lo;
+        MulAny any_guard(any_point);                                       // shards run on their own threads
         DBuf dp, ds, dout, dinf;
         HIPCHK(ds.alloc(32 * m)); HIPCHK(dout.alloc((size_t)PB * m)); HIPCHK(dinf.alloc(m));
         if (pts) { HIPCHK(dp.alloc((size_t)PB * m)); HIPCHK(hipMemcpyAsync(dp.p, pts + (size_t)PB * lo, (size_t)PB * m, hipMemcpyHostToDevice, g_stream)); }
@@ -760,11 +906,12 @@ BLSMI_API int blsmi_g1_mul_generator_batch(const uint8_t* scalars, uint8_t* out,
 BLSMI_API int blsmi_g2_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, 2, scalars, out, out_inf, n); }
 // device-pointer forms: points (NULL = the group generator), scalars, results and infinity bytes resident on one device
 template <int PB, class K>
-static int mul_batch_dev(K kernel, int gen_group, const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream) {
+static int mul_batch_dev(K kernel, int gen_group, const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream, bool any_point = false) {
     if (n == 0) return BLSMI_OK;
     if (!d_scalars || !d_out || !d_out_inf) return BLSMI_E_ARG;
     LOCK_AND_INIT_AT(d_out);
     UseStream us(stream);
+    MulAny any_guard(any_point);
     int rc = mul_dev_core<PB>(kernel, (const u8*)d_pts, gen_group, (const u8*)d_scalars, (u8*)d_out, (u8*)d_out_inf, n, g_stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g_stream));
@@ -772,6 +919,23 @@ static int mul_batch_dev(K kernel, int gen_group, const void* d_pts, const void*
 }
 BLSMI_API int blsmi_g1_mul_batch_dev(const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream) { return mul_batch_dev<96>(k_g1_mul, 1, d_pts, d_scalars, d_out, d_out_inf, n, stream); }
 BLSMI_API int blsmi_g2_mul_batch_dev(const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream) { return mul_batch_dev<192>(k_g2_mul, 2, d_pts, d_scalars, d_out, d_out_inf, n, stream); }
+// per-call choice of the ladder (flags & BLSMI_MUL_ANY_POINT: the plain windowed ladder, which serves every curve point like MulFR, g1.go:80-90)
+BLSMI_API int blsmi_g1_mul_batch_ex(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n, unsigned flags) {
+    if ((n && !pts) || (flags & ~(unsigned)BLSMI_MUL_ANY_POINT)) return BLSMI_E_ARG;
+    return mul_batch<96>(k_g1_mul, pts, 0, scalars, out, out_inf, n, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
+BLSMI_API int blsmi_g2_mul_batch_ex(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n, unsigned flags) {
+    if ((n && !pts) || (flags & ~(unsigned)BLSMI_MUL_ANY_POINT)) return BLSMI_E_ARG;
+    return mul_batch<192>(k_g2_mul, pts, 0, scalars, out, out_inf, n, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
+BLSMI_API int blsmi_g1_mul_batch_dev_ex(const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream, unsigned flags) {
+    if ((n && !d_pts) || (flags & ~(unsigned)BLSMI_MUL_ANY_POINT)) return BLSMI_E_ARG;
+    return mul_batch_dev<96>(k_g1_mul, 1, d_pts, d_scalars, d_out, d_out_inf, n, stream, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
+BLSMI_API int blsmi_g2_mul_batch_dev_ex(const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream, unsigned flags) {
+    if ((n && !d_pts) || (flags & ~(unsigned)BLSMI_MUL_ANY_POINT)) return BLSMI_E_ARG;
+    return mul_batch_dev<192>(k_g2_mul, 2, d_pts, d_scalars, d_out, d_out_inf, n, stream, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
 
 // tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
 template <int PB, int W, class K0, class K1, class K2>
@@ -1054,7 +1218,7 @@ static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, 
     int rc = BLSMI_E_SKEW;
     bool arrived = !points_arrive;                                         // the host form hands over its copy of the points: issued at the latest before the first kernel that reads them
     auto arrive_once = [&]() -> int { if (arrived) return BLSMI_OK; arrived = true; return points_arrive(); };
-    if (n >= bucket_min && g_mul_subgroup.load(std::memory_order_relaxed)) rc = msm_bucket_glv_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s, arrive_once);
+    if (n >= bucket_min && mul_subgroup()) rc = msm_bucket_glv_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s, arrive_once);
     else if (n >= bucket_min) { rc = arrive_once(); if (!rc) rc = msm_bucket_dev<PB, W>(mk, d_pts, d_scalars, n, d_out, d_flag, s); }
     if (rc != BLSMI_E_SKEW) return rc;
     rc = arrive_once();
@@ -1066,10 +1230,11 @@ static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, 
     return sum_dev<PB, W>(k0, k1, kfinal, dm.as<u8>(), dinf.as<u8>(), n, d_out, d_flag, s);   // synchronises: the temporaries may go
 }
 template <int PB, int W, class KM, class K0, class K1, class K2>
-static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int* out_inf) {
+static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int* out_inf, bool any_point = false) {
     if (!out || !out_inf || (n && (!pts || !scalars))) return BLSMI_E_ARG;
     if (n == 0) { memset(out, 0, PB); *out_inf = 1; return BLSMI_OK; }
     LOCK_AND_INIT();
+    MulAny any_guard(any_point);
     DBuf dp, ds, dout, dflag;
     HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(ds.alloc(32 * n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
     // scalars first; the points follow while the digit passes (which need the scalars only) run
@@ -1093,10 +1258,11 @@ static int msm_host(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, cons
     return BLSMI_OK;
 }
 template <int PB, int W, class KM, class K0, class K1, class K2>
-static int msm_dev_api(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream) {
+static int msm_dev_api(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream, bool any_point = false) {
     if (!d_out || !out_inf || (n && (!d_pts || !d_scalars))) return BLSMI_E_ARG;
     LOCK_AND_INIT_AT(d_out);
     UseStream us(stream);
+    MulAny any_guard(any_point);
     if (n == 0) { HIPCHK(hipMemsetAsync(d_out, 0, PB, g_stream)); HIPCHK(hipStreamSynchronize(g_stream)); *out_inf = 1; return BLSMI_OK; }
     DBuf dflag; HIPCHK(dflag.alloc(sizeof(i32)));
     int rc = msm_dev_core<PB, W>(mk, kmul, k0, k1, kfinal, (const u8*)d_pts, (const u8*)d_scalars, n, (u8*)d_out, dflag.as<i32>(), g_stream);
@@ -1119,6 +1285,23 @@ BLSMI_API int blsmi_g1_msm_dev(const void* d_pts, const void* d_scalars, size_t 
 }
 BLSMI_API int blsmi_g2_msm_dev(const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream) {
     return msm_dev_api<192, 6>(g_mk2, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, d_pts, d_scalars, n, d_out, out_inf, stream);
+}
+#define BLSMI_FLAGS_OK(f) (((f) & ~(unsigned)BLSMI_MUL_ANY_POINT) == 0)
+BLSMI_API int blsmi_g1_msm_ex(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[96], int* out_inf, unsigned flags) {
+    if (!BLSMI_FLAGS_OK(flags)) return BLSMI_E_ARG;
+    return msm_host<96, 3>(g_mk1, k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, scalars, n, out, out_inf, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
+BLSMI_API int blsmi_g2_msm_ex(const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t out[192], int* out_inf, unsigned flags) {
+    if (!BLSMI_FLAGS_OK(flags)) return BLSMI_E_ARG;
+    return msm_host<192, 6>(g_mk2, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, scalars, n, out, out_inf, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
+BLSMI_API int blsmi_g1_msm_dev_ex(const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream, unsigned flags) {
+    if (!BLSMI_FLAGS_OK(flags)) return BLSMI_E_ARG;
+    return msm_dev_api<96, 3>(g_mk1, k_g1_mul, k_g1_sum0, k_g1_sum, k_g1_sum_final, d_pts, d_scalars, n, d_out, out_inf, stream, (flags & BLSMI_MUL_ANY_POINT) != 0);
+}
+BLSMI_API int blsmi_g2_msm_dev_ex(const void* d_pts, const void* d_scalars, size_t n, void* d_out, int* out_inf, void* stream, unsigned flags) {
+    if (!BLSMI_FLAGS_OK(flags)) return BLSMI_E_ARG;
+    return msm_dev_api<192, 6>(g_mk2, k_g2_mul, k_g2_sum0, k_g2_sum, k_g2_sum_final, d_pts, d_scalars, n, d_out, out_inf, stream, (flags & BLSMI_MUL_ANY_POINT) != 0);
 }
 
 #include "verify_host.inc"

@@ -48,6 +48,38 @@ def init_devices(ndev=0):
     _check(_lib().blsmi_init_devices(int(ndev)), "blsmi_init_devices")
 
 
+def debug_alias_own(ptr, nbytes, device_index):
+    """TEST HOOK (BLSMI_DEVICE_ALIAS): the device-pointer range belongs to logical device `device_index` (include/blsmi.h)."""
+    _check(_lib().blsmi_debug_alias_own(C.c_void_p(int(ptr)), C.c_size_t(int(nbytes)), int(device_index)), "blsmi_debug_alias_own")
+
+
+def trim(keep_bytes_per_context=0):
+    """Give the temporaries idle call contexts hold beyond keep_bytes_per_context (and the pool cache) back to the driver; bytes freed."""
+    freed = C.c_size_t(0)
+    _check(_lib().blsmi_trim(C.c_size_t(int(keep_bytes_per_context)), C.byref(freed)), "blsmi_trim")
+    return int(freed.value)
+
+
+def held_bytes():
+    """device memory the call contexts currently hold for temporaries (all devices)"""
+    _lib().blsmi_held_bytes.restype = C.c_size_t
+    return int(_lib().blsmi_held_bytes())
+
+
+SHAPE_PAIRING, SHAPE_MILLER_LOOP, SHAPE_FINAL_EXP, SHAPE_G2_PREPARE, SHAPE_VERIFY, SHAPE_SIGN, SHAPE_VERIFY_DOMAIN, SHAPE_POINT_ADD = range(8)
+
+
+def prefer_cpu(shape, n):
+    """True when n operations of `shape` in one call finish sooner on one core of the upstream CPU path (include/blsmi.h)"""
+    return bool(_lib().blsmi_prefer_cpu(int(shape), C.c_size_t(int(n))))
+
+
+def device_leases(device_index):
+    """context leases device `device_index` has served since initialisation (-1: no such device)"""
+    _lib().blsmi_debug_device_leases.restype = C.c_longlong
+    return int(_lib().blsmi_debug_device_leases(int(device_index)))
+
+
 def device_count():
     return int(_lib().blsmi_device_count())
 
@@ -162,8 +194,13 @@ def g1pubs_verify_with_domain_batch_dev(d_msgs32, d_domain, d_pks, d_sigs, d_inf
     _check(_lib().blsmi_g1pubs_verify_with_domain_batch_dev(C.c_void_p(d_msgs32), C.c_void_p(d_domain), C.c_void_p(d_pks), C.c_void_p(d_sigs), C.c_void_p(d_inf or 0), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_with_domain_batch_dev")
 
 
-def mul_batch_dev(group, d_pts, d_scalars, d_out, d_out_inf, n, stream=0):
-    """k_i * P_i with everything resident on the device (ints = device pointers; d_pts = 0: the group generator)."""
+def mul_batch_dev(group, d_pts, d_scalars, d_out, d_out_inf, n, stream=0, any_point=False):
+    """k_i * P_i with everything resident on the device (ints = device pointers; d_pts = 0: the group generator).
+    any_point: multiplicands outside the prime-order subgroup are allowed for this call (see g1_mul_batch)."""
+    if any_point:
+        fn = _lib().blsmi_g1_mul_batch_dev_ex if group == "g1" else _lib().blsmi_g2_mul_batch_dev_ex
+        _check(fn(C.c_void_p(d_pts or 0), C.c_void_p(d_scalars), C.c_void_p(d_out), C.c_void_p(d_out_inf), C.c_size_t(n), C.c_void_p(stream), C.c_uint(MUL_ANY_POINT)), "mul_batch_dev_ex")
+        return
     fn = _lib().blsmi_g1_mul_batch_dev if group == "g1" else _lib().blsmi_g2_mul_batch_dev
     _check(fn(C.c_void_p(d_pts or 0), C.c_void_p(d_scalars), C.c_void_p(d_out), C.c_void_p(d_out_inf), C.c_size_t(n), C.c_void_p(stream)), "mul_batch_dev")
 
@@ -176,10 +213,14 @@ def sum_dev(group, d_pts, d_in_inf, n, d_out, stream=0):
     return bool(oinf.value)
 
 
-def msm_dev(group, d_pts, d_scalars, n, d_out, stream=0):
+def msm_dev(group, d_pts, d_scalars, n, d_out, stream=0, any_point=False):
     """sum_i k_i P_i over resident points and scalars -> affine bytes at d_out (device); True when it is the point at infinity."""
-    fn = _lib().blsmi_g1_msm_dev if group == "g1" else _lib().blsmi_g2_msm_dev
     oinf = C.c_int(0)
+    if any_point:
+        fn = _lib().blsmi_g1_msm_dev_ex if group == "g1" else _lib().blsmi_g2_msm_dev_ex
+        _check(fn(C.c_void_p(d_pts), C.c_void_p(d_scalars), C.c_size_t(n), C.c_void_p(d_out), C.byref(oinf), C.c_void_p(stream), C.c_uint(MUL_ANY_POINT)), "msm_dev_ex")
+        return bool(oinf.value)
+    fn = _lib().blsmi_g1_msm_dev if group == "g1" else _lib().blsmi_g2_msm_dev
     _check(fn(C.c_void_p(d_pts), C.c_void_p(d_scalars), C.c_size_t(n), C.c_void_p(d_out), C.byref(oinf), C.c_void_p(stream)), "msm_dev")
     return bool(oinf.value)
 
@@ -289,19 +330,32 @@ def g2pubs_verify_aggregate_prepared_dev(d_msgs, d_off, d_prepared, d_key_idx, s
 
 
 # ---- groups ----------------------------------------------------------------------------------------
-def _mul(fn, pb, pts, scalars, n):
+MUL_ANY_POINT = 1          # BLSMI_MUL_ANY_POINT (include/blsmi.h)
+
+
+def _mul(fn, pb, pts, scalars, n, flags=None):
     p, s = _u8(pts, pb * n), _u8(scalars, 32 * n)
     out = np.empty(pb * n, dtype=np.uint8)              # every byte is written by the call
     inf = np.empty(n, dtype=np.uint8)
-    _check(fn(_p8(p), _p8(s), _p8(out), _p8(inf), C.c_size_t(n)), "mul_batch")
+    extra = () if flags is None else (C.c_uint(flags),)
+    _check(fn(_p8(p), _p8(s), _p8(out), _p8(inf), C.c_size_t(n), *extra), "mul_batch")
     return out.reshape(n, pb), inf.astype(bool)
 
 
-def g1_mul_batch(pts, scalars, n):
+def g1_mul_batch(pts, scalars, n, any_point=False):
+    """k_i * P_i (G1Affine.MulFR, g1.go:80-90).  The default ladder runs through the curve endomorphism and REQUIRES multiplicands
+    in the prime-order subgroup (hash points, generators, keys / signatures that passed Deserialize's subgroup check): an on-curve
+    point outside it gives a different point, silently.  any_point=True selects, for this call only, the plain windowed ladder
+    that serves every curve point like the reference does (e.g. after g1_decompress_batch(check_subgroup=False))."""
+    if any_point:
+        return _mul(_lib().blsmi_g1_mul_batch_ex, 96, pts, scalars, n, MUL_ANY_POINT)
     return _mul(_lib().blsmi_g1_mul_batch, 96, pts, scalars, n)
 
 
-def g2_mul_batch(pts, scalars, n):
+def g2_mul_batch(pts, scalars, n, any_point=False):
+    """k_i * P_i (G2Affine.MulFR, g2.go:92-102); subgroup points unless any_point=True -- see g1_mul_batch."""
+    if any_point:
+        return _mul(_lib().blsmi_g2_mul_batch_ex, 192, pts, scalars, n, MUL_ANY_POINT)
     return _mul(_lib().blsmi_g2_mul_batch, 192, pts, scalars, n)
 
 
@@ -323,21 +377,26 @@ def g2_mul_generator_batch(scalars, n):
     return _mul_gen(_lib().blsmi_g2_mul_generator_batch, 192, scalars, n)
 
 
-def _msm(fn, pb, pts, scalars, n):
+def _msm(fn, pb, pts, scalars, n, flags=None):
     p = _u8(pts, pb * n) if n else np.zeros(1, np.uint8)
     s = _u8(scalars, 32 * n) if n else np.zeros(1, np.uint8)
     out = np.zeros(pb, dtype=np.uint8)
     oinf = C.c_int(0)
-    _check(fn(_p8(p), _p8(s), C.c_size_t(n), _p8(out), C.byref(oinf)), "msm")
+    extra = () if flags is None else (C.c_uint(flags),)
+    _check(fn(_p8(p), _p8(s), C.c_size_t(n), _p8(out), C.byref(oinf), *extra), "msm")
     return None if oinf.value else out.tobytes()
 
 
-def g1_msm(pts, scalars, n):
-    """sum_i k_i * P_i -> 96 affine bytes, or None for the point at infinity."""
+def g1_msm(pts, scalars, n, any_point=False):
+    """sum_i k_i * P_i -> 96 affine bytes, or None for the point at infinity (subgroup points unless any_point=True, see g1_mul_batch)."""
+    if any_point:
+        return _msm(_lib().blsmi_g1_msm_ex, 96, pts, scalars, n, MUL_ANY_POINT)
     return _msm(_lib().blsmi_g1_msm, 96, pts, scalars, n)
 
 
-def g2_msm(pts, scalars, n):
+def g2_msm(pts, scalars, n, any_point=False):
+    if any_point:
+        return _msm(_lib().blsmi_g2_msm_ex, 192, pts, scalars, n, MUL_ANY_POINT)
     return _msm(_lib().blsmi_g2_msm, 192, pts, scalars, n)
 
 

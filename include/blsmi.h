@@ -50,19 +50,38 @@ int blsmi_init(int device);
  * BLSMI_SHARD_MIN (smallest batch that is split, default 8192), BLSMI_FORCE_RCCL=1 (build the communicator even
  * for one device).  librccl is loaded with dlopen only when ndev > 1 (or forced): BLSMI_E_RCCL if that fails. */
 int blsmi_init_devices(int ndev);
+/* TEST HOOK, not a deployment mode.  With BLSMI_DEVICE_ALIAS=0,0[,0,0] in the environment blsmi_init_devices builds that many LOGICAL
+ * devices -- each with its own context pool, streams, generator tables and exchange buffer, as on an N-GPU node -- on the physical GPUs
+ * the list names (ndev <= 0: as many as the list has), and, because RCCL refuses two ranks on one GPU, runs the two collectives through
+ * a host-staged stand-in with the same buffers and results (blsmi_version() then says ALIASED-DEVICES).  It exists so that a one-GPU
+ * box executes the multi-device code: shard -> device routing, per-device pools, owner routing of the *_dev entry points.
+ * blsmi_debug_alias_own tells the library which logical device "owns" a device-pointer range (on real hardware the HIP runtime
+ * answers that; aliased devices share one ordinal); bytes == 0 forgets the range.  BLSMI_E_ARG outside the hook. */
+int blsmi_debug_alias_own(const void *d_ptr, size_t bytes, int device_index);
 int blsmi_device_count(void);   /* devices in use (0 before initialisation) */
+/* Diagnostic: context leases (entry-point calls + shards of split calls) that device `device_index` (0 .. blsmi_device_count() - 1) has
+ * served since initialisation; -1 for no such device.  Lets an operator (and the tests) see that work reaches every device. */
+long long blsmi_debug_device_leases(int device_index);
 int blsmi_shard_count(void);
 void blsmi_shutdown(void);
 /* "blsmi <ABI version> gfx950 CUs=.. devices=.. shards=..".  ABI history: 0.2 gave blsmi_g{1,2}pubs_aggregate_partial its trailing
  * `int *bad` argument (a caller built against the 5-argument prototype of 0.1 must be rebuilt); 0.3 adds the *_dev forms of
  * mul / sum / msm / verify_aggregate and changes no existing prototype; 0.4 adds the prepared-key entry points.  Check the prefix
- * before binding by hand. */
+ * before binding by hand.  0.5 adds blsmi_trim / blsmi_held_bytes, the *_ex forms of mul / msm (per-call BLSMI_MUL_ANY_POINT),
+ * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes. */
 const char *blsmi_version(void);
 
 /* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
  * ordinary (pageable) memory, which the HIP runtime stages at ~10 GB/s; from blsmi_host_alloc memory the copies are single DMAs at
  * PCIe rate (65 536 pairings from host buffers: 26 -> 22 ms).  A cgo caller serialises its points straight into such a buffer
  * (INTEGRATION.md 2e).  The memory is visible to every device the library drives. */
+/* Device memory held for future calls.  Every call context (BLSMI_STREAMS per device) keeps the temporaries of its last call for reuse
+ * -- steady state makes no allocator call at all -- up to a retention cap of BLSMI_ARENA_KEEP_MB (default 4096) per context: what an
+ * outsized call needed beyond the cap is returned to the driver when that call ends.  blsmi_trim gives back what IDLE contexts hold
+ * beyond keep_bytes_per_context (0: everything) plus the runtime's pool cache, e.g. after a burst of 2^20-point calls or before another
+ * library in the process needs the HBM; *freed_bytes (may be NULL) reports how much.  blsmi_held_bytes: the current total. */
+int blsmi_trim(size_t keep_bytes_per_context, size_t *freed_bytes);
+size_t blsmi_held_bytes(void);
 int blsmi_host_alloc(size_t bytes, void **out);
 int blsmi_host_free(void *p);
 
@@ -79,6 +98,15 @@ int blsmi_set_profiling(int on);
  * 64 lanes, field elements staged in LDS) instead of one per lane pair: ~10x lower latency for the one-tuple-per-call
  * Go API (g2pubs/bls.go:159-162), same results.  Default 8192 (environment BLSMI_LAT_MAX) -- the two paths cross at ~10 000 tuples --; 0 switches it off. */
 int blsmi_set_latency_threshold(size_t max_tuples);
+/* When should a lone call stay on the upstream CPU path?  A call with few elements costs the dependent depth of ONE wave walking the
+ * whole computation -- about 0.7 ms for a Miller loop, 1.4 ms for a pairing, a signature or a G2 preparation, 2.2 ms for a Verify --
+ * whatever n is, up to a few thousand elements.  Where one CPU core needs less than that for the whole call (BLSSign 0.45 ms,
+ * G2AffineToPrepared 0.19 ms, a Jacobian addition 6.5 us: bench.py `reference_shapes`), the shim should not cross the boundary.
+ * blsmi_prefer_cpu(shape, n) returns 1 in exactly those cases (n * cpu time per operation < device latency of a lone call), else 0:
+ * Sign n <= 3, G2 prepare n <= 7, MillerLoop n = 1, point sums n <= 38; never for Pairing / FinalExponentiation / Verify. */
+enum { BLSMI_SHAPE_PAIRING = 0, BLSMI_SHAPE_MILLER_LOOP = 1, BLSMI_SHAPE_FINAL_EXP = 2, BLSMI_SHAPE_G2_PREPARE = 3, BLSMI_SHAPE_VERIFY = 4,
+       BLSMI_SHAPE_SIGN = 5, BLSMI_SHAPE_VERIFY_DOMAIN = 6, BLSMI_SHAPE_POINT_ADD = 7 };
+int blsmi_prefer_cpu(int shape, size_t n);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
 /* General form: with profiling on, every entry point records HIP events on its launch stream between its major kernels.  This
  * returns the calling thread's log since it last asked, as "kernel=ms;kernel=ms;..." in launch order (a name repeats when a
@@ -98,8 +126,11 @@ int blsmi_final_exponentiation_batch(const uint64_t *in_fq12, uint64_t *out_fq12
  * multiplication is (hash points: Sign; the generators: PrivToPub; keys and signatures that passed Deserialize*'s subgroup
  * check).  For them the multiplication runs through the curve endomorphisms (G1: k = k1 + k2 z^2 with phi; G2: base-|x| digits
  * with psi -- bls_amd/csrc/glv.cuh), half / a quarter of the reference's doublings, the same group element and affine bytes.
- * For ARBITRARY curve points (the reference's bit-serial MulFR accepts any) call blsmi_set_mul_assume_subgroup(0) first -- or set
- * BLSMI_MUL_GENERIC=1 -- and the plain fixed-window ladder is used.  Process-wide switch, default 1. */
+ * For ARBITRARY curve points (the reference's bit-serial MulFR accepts any; an on-curve point outside the subgroup fed to the default
+ * ladder yields a DIFFERENT point, silently) use the *_ex forms below with BLSMI_MUL_ANY_POINT: the choice is made per call and costs
+ * nothing to concurrent callers.  blsmi_set_mul_assume_subgroup(0) / BLSMI_MUL_GENERIC=1 change the PROCESS-WIDE default of the plain
+ * entry points instead: every call in flight reads it, so set it once before the first call (legacy switch; prefer the flag). */
+#define BLSMI_MUL_ANY_POINT 1u   /* multiplicands may lie outside the prime-order subgroup: plain fixed-window ladder / plain bucket MSM */
 int blsmi_set_mul_assume_subgroup(int on);
 int blsmi_g1_mul_batch(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
 int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
@@ -121,6 +152,11 @@ int blsmi_g2_sum(const uint8_t *pts, const uint8_t *in_inf, size_t n, uint8_t ou
  * from there on the bucket method (16-bit windows), with a fallback to the former for degenerate scalar sets. */
 int blsmi_g1_msm(const uint8_t *pts /* n*96 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[96], int *out_inf);
 int blsmi_g2_msm(const uint8_t *pts /* n*192 */, const uint8_t *scalars /* n*32 */, size_t n, uint8_t out[192], int *out_inf);
+/* The same four with the ladder chosen PER CALL: flags = 0 (subgroup points, as above) or BLSMI_MUL_ANY_POINT; other bits: BLSMI_E_ARG. */
+int blsmi_g1_mul_batch_ex(const uint8_t *pts, const uint8_t *scalars, uint8_t *out, uint8_t *out_inf, size_t n, unsigned flags);
+int blsmi_g2_mul_batch_ex(const uint8_t *pts, const uint8_t *scalars, uint8_t *out, uint8_t *out_inf, size_t n, unsigned flags);
+int blsmi_g1_msm_ex(const uint8_t *pts, const uint8_t *scalars, size_t n, uint8_t out[96], int *out_inf, unsigned flags);
+int blsmi_g2_msm_ex(const uint8_t *pts, const uint8_t *scalars, size_t n, uint8_t out[192], int *out_inf, unsigned flags);
 /* Device-pointer forms of the above (BASELINE config 3 with inputs resident in HBM): every d_* buffer lives on ONE of the
  * library's devices (the call runs on the device that owns d_out), layouts as in the host forms; d_pts == NULL multiplies
  * the group generator; d_out_inf is n bytes, d_in_inf may be NULL.  The single-point results of sum / msm stay on the
@@ -132,6 +168,11 @@ int blsmi_g1_sum_dev(const void *d_pts, const void *d_in_inf, size_t n, void *d_
 int blsmi_g2_sum_dev(const void *d_pts, const void *d_in_inf, size_t n, void *d_out, int *out_inf, void *stream);
 int blsmi_g1_msm_dev(const void *d_pts, const void *d_scalars, size_t n, void *d_out, int *out_inf, void *stream);
 int blsmi_g2_msm_dev(const void *d_pts, const void *d_scalars, size_t n, void *d_out, int *out_inf, void *stream);
+/* ... and with the per-call ladder choice (flags as for blsmi_g1_mul_batch_ex; d_pts must not be NULL) */
+int blsmi_g1_mul_batch_dev_ex(const void *d_pts, const void *d_scalars, void *d_out, void *d_out_inf, size_t n, void *stream, unsigned flags);
+int blsmi_g2_mul_batch_dev_ex(const void *d_pts, const void *d_scalars, void *d_out, void *d_out_inf, size_t n, void *stream, unsigned flags);
+int blsmi_g1_msm_dev_ex(const void *d_pts, const void *d_scalars, size_t n, void *d_out, int *out_inf, void *stream, unsigned flags);
+int blsmi_g2_msm_dev_ex(const void *d_pts, const void *d_scalars, size_t n, void *d_out, int *out_inf, void *stream, unsigned flags);
 
 /* ---- hash to curve (HashG1 hash.go:326-331, HashG2 hash.go:405-411, HashG2WithDomain
  * g2.go:1041-1085) -- messages are concatenated in `msgs`, message i = msgs[off[i] .. off[i+1]) -- */

@@ -1,0 +1,155 @@
+"""-m gpu, round 4: per-call ladder choice for scalar multiplication of arbitrary curve points, blsmi_trim and the arena's
+retention cap, the latency hint, and the mid-size layout boundaries."""
+import threading
+
+import numpy as np
+import pytest
+
+from gpu_common import P, RC, rand_g1, rand_g2, sk_bytes
+from test_gpu_round3 import _torsion_points
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bls_amd import engine
+    engine.init(0)
+    return engine
+
+
+def test_any_point_flag_selects_the_plain_ladder_per_call(eng):
+    """MulFR accepts any curve point (g1.go:80-90, g2.go:92-102).  any_point=True gives the oracle's multiple for points outside the
+    subgroup, on the small-call path, on the throughput kernels and in the MSM -- while default-ladder calls run CONCURRENTLY on other
+    threads with their own (subgroup) inputs and keep their results: the choice is per call, no process-wide state is touched."""
+    g1s, g2s = _torsion_points()
+    xs = P.XORShift(4101)
+    ks = [sk_bytes(xs) for _ in range(6)]
+    want1 = [RC.g1_mul(p, k) for p, k in zip(g1s, ks)]
+    want2 = [RC.g2_mul(p, k) for p, k in zip(g2s, ks)]
+    sub1 = [rand_g1(xs) for _ in range(6)]; sub2 = [rand_g2(xs) for _ in range(6)]
+    wsub1 = [RC.g1_mul(p, k) for p, k in zip(sub1, ks)]; wsub2 = [RC.g2_mul(p, k) for p, k in zip(sub2, ks)]
+    stop = threading.Event()
+    bad = []
+
+    def default_caller():
+        while not stop.is_set():
+            o1, _ = eng.g1_mul_batch(b"".join(sub1), b"".join(ks), 6)
+            o2, _ = eng.g2_mul_batch(b"".join(sub2), b"".join(ks), 6)
+            if [x.tobytes() for x in o1] != wsub1 or [x.tobytes() for x in o2] != wsub2:
+                bad.append("default ladder disturbed")
+    th = [threading.Thread(target=default_caller) for _ in range(2)]
+    for t in th:
+        t.start()
+    try:
+        for lat in (8192, 0):                                              # one multiplication per wave / the throughput ladders
+            eng.set_latency_threshold(lat)
+            for reps in (1, 40):                                           # 6 and 240 points (whole and ragged workgroups)
+                o1, i1 = eng.g1_mul_batch(b"".join(g1s) * reps, b"".join(ks) * reps, 6 * reps, any_point=True)
+                o2, i2 = eng.g2_mul_batch(b"".join(g2s) * reps, b"".join(ks) * reps, 6 * reps, any_point=True)
+                assert [x.tobytes() for x in o1] == want1 * reps and not i1.any()
+                assert [x.tobytes() for x in o2] == want2 * reps and not i2.any()
+                # subgroup points through the any-point ladder: the same bytes as the default one
+                o1, _ = eng.g1_mul_batch(b"".join(sub1), b"".join(ks), 6, any_point=True)
+                assert [x.tobytes() for x in o1] == wsub1
+    finally:
+        eng.set_latency_threshold(8192)
+        stop.set()
+        for t in th:
+            t.join()
+    assert not bad
+    # MSM over points outside the subgroup == sum of the oracle's multiples (small n: multiples + tree sum; the default would be wrong here)
+    assert eng.g1_msm(b"".join(g1s), b"".join(ks), 6, any_point=True) == RC.g1_sum(b"".join(want1), 6)
+    assert eng.g2_msm(b"".join(g2s), b"".join(ks), 6, any_point=True) == RC.g2_sum(b"".join(want2), 6)
+    # the default ladder on these points is NOT MulFR: that is the documented precondition, pinned here so that it stays documented
+    o1, _ = eng.g1_mul_batch(b"".join(g1s), b"".join(ks), 6)
+    assert [x.tobytes() for x in o1] != want1
+
+
+def test_any_point_device_forms_and_bucket_msm(eng):
+    """the *_dev_ex forms, and the bucket MSM (n = 2^17) through the plain buckets when any_point is set: a batch that contains points
+    outside the subgroup against sum-of-multiples computed by the any-point ladder itself (cross-check) and a sample against the oracle"""
+    import torch
+    dev = torch.device("cuda", 0)
+    g1s, g2s = _torsion_points()
+    n = 1 << 17
+    rng = np.random.default_rng(4102)
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); k[:, 0] &= 0x3f
+    xs = P.XORShift(4103)
+    for grp, pb, tors, rnd, ref_mul, summ in (("g1", 96, g1s, rand_g1, RC.g1_mul, eng.g1_sum), ("g2", 192, g2s, rand_g2, RC.g2_mul, eng.g2_sum)):
+        base = [np.frombuffer(t, dtype=np.uint8) for t in tors] + [np.frombuffer(rnd(xs), dtype=np.uint8) for _ in range(10)]
+        pts = np.ascontiguousarray(np.tile(np.stack(base), (n // 16, 1)))
+        d_p = torch.from_numpy(pts.reshape(-1)).to(dev); d_k = torch.from_numpy(k.reshape(-1)).to(dev)
+        d_out = torch.empty(n * pb, dtype=torch.uint8, device=dev); d_inf = torch.empty(n, dtype=torch.uint8, device=dev)
+        eng.mul_batch_dev(grp, d_p.data_ptr(), d_k.data_ptr(), d_out.data_ptr(), d_inf.data_ptr(), n, any_point=True)
+        out = d_out.cpu().numpy().reshape(n, pb)
+        for i in (0, 5, 6, 17, n - 16, n - 11, n - 1):
+            assert out[i].tobytes() == ref_mul(pts[i].tobytes(), k[i].tobytes()), (grp, i)
+        assert not d_inf.cpu().numpy().any()
+        total = summ(out.reshape(-1), n)
+        d_one = torch.zeros(pb, dtype=torch.uint8, device=dev)
+        assert eng.msm_dev(grp, d_p.data_ptr(), d_k.data_ptr(), n, d_one.data_ptr(), any_point=True) is False
+        assert d_one.cpu().numpy().tobytes() == total, grp
+        assert (eng.g1_msm if grp == "g1" else eng.g2_msm)(pts.reshape(-1), k.reshape(-1), n, any_point=True) == total
+    lib = __import__("bls_amd._native", fromlist=["load"]).load()
+    assert lib.blsmi_g1_mul_batch_ex(None, None, None, None, 0, 2) == -3           # unknown flag bits are refused
+
+
+def test_trim_returns_the_temporaries_and_calls_still_work(eng):
+    """blsmi_trim / blsmi_held_bytes: after a large call the contexts hold its temporaries (that is the design: steady state makes no
+    allocator call); trim(0) gives all of it back, and the next call -- which has to allocate again -- returns the same results."""
+    xs = P.XORShift(4104)
+    n = 20000                                                              # above the latency hand-over: the throughput kernels' workspace
+    g1 = rand_g1(xs) * 1; g2 = rand_g2(xs) * 1
+    a = g1 * n; b = g2 * n
+    want = RC.pairing_batch(g1, g2, 1)[0]
+    out = eng.pairing_batch(a, b, n)
+    assert np.array_equal(out[0], want) and np.array_equal(out[n - 1], want)
+    held = eng.held_bytes()
+    assert held >= 720 * n                                                 # at least the Miller-loop -> final-exponentiation hand-off
+    freed = eng.trim(0)
+    assert freed >= 720 * n and eng.held_bytes() == 0
+    out = eng.pairing_batch(a, b, n)
+    assert np.array_equal(out[0], want) and np.array_equal(out[n - 1], want)
+    # keep_bytes is a per-context ceiling, not a request to free everything
+    held = eng.held_bytes()
+    assert eng.trim(1 << 40) == 0 and eng.held_bytes() == held
+
+
+def test_retention_cap_releases_an_outsized_calls_temporaries():
+    """BLSMI_ARENA_KEEP_MB=8: a call whose temporaries exceed the cap returns them when it ends (own process: read at initialisation)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from bls_amd import engine as e\n"
+            "from gpu_common import RC\n"
+            "e.init(0)\n"
+            "n = 1 << 17\n"
+            "k = np.random.default_rng(1).integers(0, 256, size=(n, 32), dtype=np.uint8); k[:, 0] &= 0x3f\n"
+            "p, _ = e.g1_mul_generator_batch(k.reshape(-1), n)\n"
+            "r1 = e.g1_msm(p.reshape(-1), k.reshape(-1), n)\n"
+            "h1 = e.held_bytes()\n"
+            "r2 = e.g1_msm(p.reshape(-1), k.reshape(-1), n)\n"
+            "h2 = e.held_bytes()\n"
+            "assert r1 == r2 and r1 == e.g1_sum(e.g1_mul_batch(p.reshape(-1), k.reshape(-1), n)[0].reshape(-1), n)\n"
+            "assert h1 <= 8 << 20 and h2 <= 8 << 20, (h1, h2)\n"
+            "print('OK', h1, h2)\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ); env["BLSMI_ARENA_KEEP_MB"] = "8"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_latency_hint(eng):
+    """blsmi_prefer_cpu: the lone calls that lose to one CPU core (BLSSign, G2Prepare, MillerLoop) are flagged, the ones that
+    win are not, and the hint flips at the measured break-even"""
+    E = eng
+    assert E.prefer_cpu(E.SHAPE_SIGN, 1) and E.prefer_cpu(E.SHAPE_SIGN, 3) and not E.prefer_cpu(E.SHAPE_SIGN, 4)
+    assert E.prefer_cpu(E.SHAPE_G2_PREPARE, 7) and not E.prefer_cpu(E.SHAPE_G2_PREPARE, 8)
+    assert E.prefer_cpu(E.SHAPE_MILLER_LOOP, 1) and not E.prefer_cpu(E.SHAPE_MILLER_LOOP, 2)
+    for shape in (E.SHAPE_PAIRING, E.SHAPE_FINAL_EXP, E.SHAPE_VERIFY, E.SHAPE_VERIFY_DOMAIN):
+        assert not E.prefer_cpu(shape, 1)
+    assert E.prefer_cpu(E.SHAPE_POINT_ADD, 38) and not E.prefer_cpu(E.SHAPE_POINT_ADD, 39)
+    assert not E.prefer_cpu(99, 1) and not E.prefer_cpu(-1, 1)
