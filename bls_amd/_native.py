@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 # translation units of libblsmi.so: the host side + one unit per kernel family, compiled in parallel
-_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_hash.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "k_lat.hip", "k_util.hip"]
+_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_hash.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "k_lat.hip", "k_util.hip"]
 LAT_BIN = os.path.join(CSRC, "lat_programs.z")            # level programs of the latency path (gen_lat.py), zlib-compressed, embedded into blsmi.hip.o
 BUILD_DIR = os.path.join(CSRC, "build")
 # -Werror=pass-failed: a kernel that misses its declared waves-per-SIMD (a shared device function that outgrew the register budget)

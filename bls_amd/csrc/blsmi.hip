@@ -269,6 +269,13 @@ struct MulAny { bool saved; explicit MulAny(bool on) : saved(tl_mul_any) { tl_mu
 std::atomic<bool> g_mul_subgroup{true}; // scalar multiplication through the endomorphisms (multiplicands in the subgroup); BLSMI_MUL_GENERIC=1 / blsmi_set_mul_assume_subgroup(0): plain ladder
 std::atomic<size_t> g_lat_max{8192};    // BLSMI_LAT_MAX, blsmi_set_latency_threshold (read by every call, written rarely).  The two paths meet at ~10 000 tuples
                                         // for pairings and verifies alike (tools/crossover.py: 8192 pairings 8.4 ms against 10.7, 16 384: 16.4 against 11.3)
+// Three layouts by batch size (pairings and verifies alike; tools/midsize.py): one tuple per WAVE up to min(g_lat_max, g_quad_min) tuples,
+// one per lane QUAD up to g_quad_max (16 384 tuples = one wave on every SIMD), one per lane PAIR beyond (65 536 fill the chip twice over).
+std::atomic<size_t> g_quad_max{16384};  // BLSMI_QUAD_MAX, blsmi_set_quad_threshold (0: no quad kernels)
+std::atomic<size_t> g_quad_min{6656};   // BLSMI_QUAD_MIN: the quad kernels take over from the latency path here already (7.0 ms flat against 1 ms per 1 024 tuples)
+inline bool use_quad(size_t n) { return g_pair_layout && n > std::min(g_lat_max.load(), g_quad_min.load()) && n <= g_quad_max; }
+inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
+inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }
 inline bool mul_subgroup() { return !tl_mul_any && g_mul_subgroup.load(std::memory_order_relaxed); }
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
@@ -287,6 +294,8 @@ int ensure_init_list(const int* devs, int ndev) {
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
     if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_QUAD_MAX")) g_quad_max = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_QUAD_MIN")) g_quad_min = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_ARENA_KEEP_MB")) g_arena_keep = (size_t)strtoull(v, nullptr, 10) << 20;
     if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
@@ -624,7 +633,7 @@ BLSMI_API int blsmi_host_free(void* p) {
 // ---- pairing ------------------------------------------------------------------------------------
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;
-    if (mode == 0 && n <= g_lat_max) {                                     // small call: one pairing per wave (k_lat.hip)
+    if (mode == 0 && use_lat(n)) {                                         // small call: one pairing per wave (k_lat.hip)
         prof_mark("k_lat:pairing1");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(LAT_PAIRING1_OFFSET), s, (const u8*)g_gens.lat + LAT_PAIRING1_OFFSET,
                            (const u8*)d_g1, (size_t)96, (const u8*)d_g2, (size_t)192, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
@@ -647,6 +656,16 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
+    if (mode == 0 && use_quad(n)) {                                        // mid-size batch: four lanes per tuple, one wave per SIMD at 16 384 tuples
+        prof_mark("k_miller1h_quad");
+        hipLaunchKernelGGL(k_miller1h_quad, dim3(qblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+        prof_mark("k_final_exp_quad");
+        hipLaunchKernelGGL(k_final_exp_quad, dim3(qblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, 0);
+        prof_mark(nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return BLSMI_OK;
+    }
     // mode 1 (MillerLoop): the reference's steps; mode 0 (Pairing): the homogeneous steps
     prof_mark(g_pair_layout ? (mode ? "k_miller1_pair" : "k_miller1h_pair") : (mode ? "k_miller1" : "k_miller1h"));
     if (g_pair_layout) hipLaunchKernelGGL(mode ? k_miller1_pair : k_miller1h_pair, dim3(pblocks), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
@@ -685,6 +704,10 @@ BLSMI_API int blsmi_prefer_cpu(int shape, size_t n) {
     if (shape < 0 || shape >= (int)(sizeof rows / sizeof rows[0])) return 0;
     if (n == 0) return 1;
     return (double)n * rows[shape].cpu_ms_per_op < rows[shape].gpu_ms_lone_call ? 1 : 0;
+}
+BLSMI_API int blsmi_set_quad_threshold(size_t max_tuples) {
+    g_quad_max.store(max_tuples);
+    return BLSMI_OK;
 }
 BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
     g_mul_subgroup.store(on != 0);
@@ -769,8 +792,10 @@ BLSMI_API int blsmi_final_exponentiation_batch(const uint64_t* in, uint64_t* out
 // ---- unit-level ops -------------------------------------------------------------------------------
 BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flag, size_t n) {
     const bool pairl = (op_in & BLSMI_OP_LANE_PAIR) != 0;                 // run the tower op in the lane-pair layout
-    const int op = op_in & ~BLSMI_OP_LANE_PAIR;
+    const bool quadl = (op_in & BLSMI_OP_LANE_QUAD) != 0;                 // ... the Fq12 op in the lane-quad layout
+    const int op = op_in & ~(BLSMI_OP_LANE_PAIR | BLSMI_OP_LANE_QUAD);
     if (pairl && (op < 16 || op >= 64)) return BLSMI_E_ARG;
+    if (quadl && (pairl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014)) return BLSMI_E_ARG;
     int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
     if (n && (!a || !out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
@@ -782,7 +807,8 @@ BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, ui
     if (b) HIPCHK(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(dflag.p, 1, n, g_stream));
     dim3 g(nblocks(n)), w(WG);
-    if (pairl) hipLaunchKernelGGL(k_debug_pairl, dim3((unsigned)((n + WG / 2 - 1) / (WG / 2))), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
+    if (quadl) hipLaunchKernelGGL(k_debug_quad, dim3(qblocks(n)), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
+    else if (pairl) hipLaunchKernelGGL(k_debug_pairl, dim3((unsigned)((n + WG / 2 - 1) / (WG / 2))), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
     else if (op < 16) hipLaunchKernelGGL(k_debug_fq, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
     else if (op < 32) hipLaunchKernelGGL(k_debug_fq2, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
     else if (op < 48) hipLaunchKernelGGL(k_debug_fq6, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), n);

@@ -93,6 +93,11 @@ def set_latency_threshold(max_tuples):
     _check(_lib().blsmi_set_latency_threshold(C.c_size_t(int(max_tuples))), "blsmi_set_latency_threshold")
 
 
+def set_quad_threshold(max_tuples):
+    """Batches above the latency threshold and of at most max_tuples tuples take the lane-quad kernels (four lanes per tuple); 0 = off."""
+    _check(_lib().blsmi_set_quad_threshold(C.c_size_t(int(max_tuples))), "blsmi_set_quad_threshold")
+
+
 def set_mul_assume_subgroup(on=True):
     """scalar multiplications through the curve endomorphisms (multiplicands in the prime-order subgroup; the default) or,
     with on=False, the plain windowed ladder that serves every curve point"""
@@ -640,7 +645,10 @@ def debug_hash_redo(kind, msgs, good, out, domain8=None):
     return o
 
 
-def debug_op(name, a, b=None, lane_pair=False, raw_flag=False):
+LANE_QUAD = 0x200          # BLSMI_OP_LANE_QUAD
+
+
+def debug_op(name, a, b=None, lane_pair=False, raw_flag=False, lane_quad=False):
     op = OPS[name]
     width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 else (3 if op in (64, 65, 68) else 6)
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 6 * width)
@@ -652,5 +660,5 @@ def debug_op(name, a, b=None, lane_pair=False, raw_flag=False):
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 6 * width)
         assert b.shape == a.shape
         bp = b.ctypes.data_as(_u64p)
-    _check(_lib().blsmi_debug_op(op | (LANE_PAIR if lane_pair else 0), a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
+    _check(_lib().blsmi_debug_op(op | (LANE_PAIR if lane_pair else 0) | (LANE_QUAD if lane_quad else 0), a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
     return out, (flag.copy() if raw_flag else flag.astype(bool))

@@ -98,6 +98,11 @@ int blsmi_set_profiling(int on);
  * 64 lanes, field elements staged in LDS) instead of one per lane pair: ~10x lower latency for the one-tuple-per-call
  * Go API (g2pubs/bls.go:159-162), same results.  Default 8192 (environment BLSMI_LAT_MAX) -- the two paths cross at ~10 000 tuples --; 0 switches it off. */
 int blsmi_set_latency_threshold(size_t max_tuples);
+/* Mid-size batches: pairing / verify batches above the latency threshold and of at most `max_tuples` tuples run in the LANE-QUAD layout
+ * -- four lanes per tuple, 16 384 tuples = one wave on every SIMD of the chip -- instead of the lane-pair layout, which needs 65 536
+ * tuples to fill it (16 384 pairings: 11.5 ms there).  Default 16 384 (environment BLSMI_QUAD_MAX); 0 switches the layout off.
+ * Same results bit for bit on all three paths. */
+int blsmi_set_quad_threshold(size_t max_tuples);
 /* When should a lone call stay on the upstream CPU path?  A call with few elements costs the dependent depth of ONE wave walking the
  * whole computation -- about 0.7 ms for a Miller loop, 1.4 ms for a pairing, a signature or a G2 preparation, 2.2 ms for a Verify --
  * whatever n is, up to a few thousand elements.  Where one CPU core needs less than that for the whole call (BLSSign 0.45 ms,
@@ -292,6 +297,7 @@ enum blsmi_debug_op {
     BLSMI_OP_SWU_G1 = 68 /* t in word 0 of a 3-Fq record -> (x, y, 0) */, BLSMI_OP_SWU_G2 /* t in words 0-1 of a 6-Fq record -> (x, y, 0) */
 };
 #define BLSMI_OP_LANE_PAIR 0x100 /* OR into an FQ2 / FQ6 / FQ12 op: run it in the lane-pair layout of the pairing kernels */
+#define BLSMI_OP_LANE_QUAD 0x200 /* OR into an FQ12 op: run it in the lane-quad layout (four lanes per tuple, k_pairing_quad.hip) */
 int blsmi_debug_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *flag /* n, may be NULL */, size_t n);
 /* G2AffineToPrepared (g2.go:650-801) of one affine G2 point: 68 line-coefficient triples, each Fq2 as 12 LE uint64 Montgomery(2^384)
  * limbs, in Miller-loop order.  mode 0: computed by the one-tuple-per-lane doubling/addition steps; 1: by the lane-pair

@@ -25,15 +25,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=["latency-path", "throughput-path"])
+@pytest.fixture(scope="module", params=["latency-path", "lane-quad", "lane-pair"])
 def eng(request):
-    """Every test of this module runs twice: small batches through the latency path (one tuple per wave, k_lat.hip: the
-    default for <= 4096 tuples) and through the throughput kernels (one tuple per lane pair)."""
+    """Every test of this module runs three times: small batches through the latency path (one tuple per wave, k_lat.hip), through the
+    lane-quad kernels (the mid-size layout) and through the lane-pair kernels (the full-chip layout)."""
     from bls_amd import engine
     engine.init(0)
+    # three paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
     engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
+    engine.set_quad_threshold(0 if request.param == "lane-pair" else 16384)
     yield engine
-    engine.set_latency_threshold(8192)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
 
 
 def _g2pubs_tuples(n, seed, every):

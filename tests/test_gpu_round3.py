@@ -27,13 +27,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 Q = P.Q
 
 
-@pytest.fixture(scope="module", params=["latency-path", "throughput-path"])
+@pytest.fixture(scope="module", params=["latency-path", "lane-quad", "lane-pair"])
 def eng(request):
     from bls_amd import engine
     engine.init(0)
+    # three paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
     engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
+    engine.set_quad_threshold(0 if request.param == "lane-pair" else 16384)
     yield engine
-    engine.set_latency_threshold(8192)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
 
 
 def _dev(x):

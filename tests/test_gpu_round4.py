@@ -83,10 +83,15 @@ def test_any_point_device_forms_and_bucket_msm(eng):
         d_out = torch.empty(n * pb, dtype=torch.uint8, device=dev); d_inf = torch.empty(n, dtype=torch.uint8, device=dev)
         eng.mul_batch_dev(grp, d_p.data_ptr(), d_k.data_ptr(), d_out.data_ptr(), d_inf.data_ptr(), n, any_point=True)
         out = d_out.cpu().numpy().reshape(n, pb)
-        for i in (0, 5, 6, 17, n - 16, n - 11, n - 1):
-            assert out[i].tobytes() == ref_mul(pts[i].tobytes(), k[i].tobytes()), (grp, i)
-        assert not d_inf.cpu().numpy().any()
-        total = summ(out.reshape(-1), n)
+        inf = d_inf.cpu().numpy()
+        # (a curve point outside the subgroup may have small order -- (0, 2) on E has order 3 -- so some multiples ARE the point at
+        # infinity: the flag must agree with the oracle, which returns None there)
+        for i in list(range(48)) + [n - 16, n - 11, n - 1]:
+            want = ref_mul(pts[i].tobytes(), k[i].tobytes())
+            assert bool(inf[i]) == (want is None), (grp, i)
+            if want is not None:
+                assert out[i].tobytes() == want, (grp, i)
+        total = summ(out.reshape(-1), n, inf)
         d_one = torch.zeros(pb, dtype=torch.uint8, device=dev)
         assert eng.msm_dev(grp, d_p.data_ptr(), d_k.data_ptr(), n, d_one.data_ptr(), any_point=True) is False
         assert d_one.cpu().numpy().tobytes() == total, grp

@@ -12,15 +12,17 @@ from gpu_common import P, RC, rand_g1, rand_g2, sk_bytes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["latency-path", "throughput-path"])
+@pytest.fixture(scope="module", params=["latency-path", "lane-quad", "lane-pair"])
 def eng(request):
-    """Every test of this module runs twice: small batches through the latency path (one tuple per wave, k_lat.hip: the
-    default for <= 4096 tuples) and through the throughput kernels (one tuple per lane pair)."""
+    """Every test of this module runs three times: small batches through the latency path (one tuple per wave, k_lat.hip), through the
+    lane-quad kernels (the mid-size layout) and through the lane-pair kernels (the full-chip layout)."""
     from bls_amd import engine
     engine.init(0)
+    # three paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
     engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
+    engine.set_quad_threshold(0 if request.param == "lane-pair" else 16384)
     yield engine
-    engine.set_latency_threshold(8192)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
 
 
 MSGS = [b"", b"a", b"the message to be signed", b"Hello world! 16 characters 0", bytes(range(55)), bytes(range(56)), bytes(range(64)), bytes(200), b"x" * 1000]

@@ -4,8 +4,8 @@ import os
 import re
 
 D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls_amd", "csrc")
-FILES = ["k_pairing_single.hip", "k_fe_single.hip", "k_pairing_pair.hip", "pair_kernels.inc", "k_prepared_pair.hip", "k_lat.hip", "k_hash.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "msm.inc"]
-PAT = re.compile(r"^(KERNEL2|KERNEL_PAIR|KERNEL_LAT|KERNEL|__global__ void __launch_bounds__\([^)]*\))\s+(k_\w+)\(([^)]*)\)\s*\{", re.M)
+FILES = ["k_pairing_single.hip", "k_fe_single.hip", "k_pairing_pair.hip", "pair_kernels.inc", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_lat.hip", "k_hash.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "msm.inc"]
+PAT = re.compile(r"^(KERNEL2|KERNEL_PAIR|KERNEL_QUAD|KERNEL_LAT|KERNEL|__global__ void __launch_bounds__\([^)]*\))\s+(k_\w+)\(([^)]*)\)\s*\{", re.M)
 
 out = """// kernels.h -- declarations of the kernels defined in the k_*.hip translation units, for the host side (blsmi.hip).
 // Generated from the definitions by tools/gen_kernel_decls.py; the launch bounds live with the definitions.
@@ -14,6 +14,7 @@ out = """// kernels.h -- declarations of the kernels defined in the k_*.hip tran
 using namespace blsmi;
 #define WG 64
 constexpr int PT = WG / 2;          // tuples per workgroup of the lane-pair kernels
+constexpr int QT = WG / 4;          // tuples per workgroup of the lane-quad kernels
 """
 seen = set()
 for f in FILES:
