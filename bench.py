@@ -390,7 +390,7 @@ def compact_line(d, detail_file=None):
                                   "g2pubs_prepared_keys": (vb.get("g2pubs_prepared_keys") or {}).get("verifies_per_s")}
     mid = d.get("mid_batches")
     if isinstance(mid, dict) and "error" not in mid:
-        line["mid_batches"] = mid.get("pairings_per_s")
+        line["mid_batches"] = {"pairings_per_s": mid.get("pairings_per_s"), "verifies_per_s": mid.get("verifies_per_s")}
     il = d.get("inlibrary_bench")
     if isinstance(il, dict) and "error" not in il and il.get("devices", 1) > 1:
         line["inlibrary"] = _pick(il, ("devices", "rccl_ranks", "tuples_per_call", "pairings_per_s", "g2pubs_verifies_per_s", "g1pubs_verifies_per_s"))
@@ -551,6 +551,41 @@ def verify_bench(E, steps=5, warmup=2, n=65536):
                 wd["roofline"] = roofline_of(profiled(E.lib, local_step_domain), n, BYTES["verify"], E.ctr, lambda k: 2 * n if k.endswith("_pair") else n)
             out["g1pubs_with_domain"] = wd
     out["note"] = "all tuples valid; inputs resident in HBM; hash-to-curve on the GPU included; 1 Verify = 2 Miller-loop pairs + 1 final exponentiation + 1 hash"
+    return out
+
+
+def mid_bench(E, steps=5, warmup=2):
+    """Batches between the latency hand-over and a full chip (the reference's API is one tuple per call and its aggregate benchmarks use
+    128 signers, g1pubs/verify_benchmark_test.go:33-85: real batches are not 65 536 tuples): pairings at 8 192 / 16 384 / 32 768 and
+    g2pubs / g1pubs verifies at 16 384, inputs resident, on the library's own choice of layout (one tuple per wave up to ~6 600 tuples,
+    per lane QUAD up to 16 384, per lane pair beyond); every size's first 16 rows re-checked against the oracle."""
+    import torch
+    from oracle import refcpu as RC
+    engine, dev = E.engine, E.dev
+    nmax = 32768
+    g1, g2 = synth_inputs(engine, nmax, seed=77)
+    d1 = torch.from_numpy(g1).to(dev); d2 = torch.from_numpy(g2).to(dev); do = torch.zeros((nmax, 72), dtype=torch.int64, device=dev)
+    want = RC.pairing_batch(g1[:16].tobytes(), g2[:16].tobytes(), 16)
+    out = {"steps": steps, "pairings_per_s": {}, "pairing_ms": {}, "pairing_kernels": {}, "verifies_per_s": {}, "verify_ms": {}}
+    for n in (8192, 16384, 32768):
+        def step():
+            engine.pairing_batch_dev(d1.data_ptr(), d2.data_ptr(), do.data_ptr(), n)
+        dt = timed_steps(E, step, steps, warmup)
+        assert np.array_equal(do[:16].cpu().numpy().view(np.uint64), want), "mid-size pairings differ from the oracle at n = %d" % n
+        out["pairings_per_s"][str(n)] = round(n * steps / dt, 1); out["pairing_ms"][str(n)] = round(dt / steps * 1e3, 3)
+        out["pairing_kernels"][str(n)] = {k: round(v[0], 3) for k, v in profiled(E.lib, step).items() if not k.startswith("(")}
+    n = 16384
+    for group in ("g2pubs", "g1pubs"):
+        packed, pks, sigs = _verify_tuples(engine, group, n, tag=11)
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (packed.buf.copy(), packed.off.view(np.int64), pks, sigs)]
+        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+        def vstep():
+            engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+        dt = timed_steps(E, vstep, steps, warmup)
+        assert bool(d_ok.all().item())
+        out["verifies_per_s"][group + "@16384"] = round(n * steps / dt, 1); out["verify_ms"][group + "@16384"] = round(dt / steps * 1e3, 3)
+    out["note"] = "round 3 (lane-pair kernels only): 16 384 pairings 11.6 ms (1.41 M/s), 32 768 12.6 ms; g2pubs verifies at 16 384 16.9 ms"
     return out
 
 
@@ -926,6 +961,7 @@ def main():
                 leg("g2pubs_aggregate_dev_bench", lambda: _agg("g2pubs", 1 << 20))
                 leg("g1pubs_aggregate_bench", lambda: _agg("g1pubs", 1 << 18))
             leg("config0", lambda: config0(E))
+            leg("mid_batches", lambda: mid_bench(E))
         if not torchrun:                                                   # one process behind the C ABI: the split host entry points
             leg("inlibrary_bench", lambda: inlibrary_bench(E, ndev))
             if ndev > 1 and not args.no_aggregate:

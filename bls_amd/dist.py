@@ -94,7 +94,7 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         fkey = _fingerprint_key(all_gather_bytes, world)
         keys = np.frombuffer(message_keys(shard_msgs), dtype=np.uint8).reshape(-1, 33)
         fp = row_fingerprints(keys, fkey) if keys.shape[0] else np.zeros(0, np.uint64)
-        gathered = all_gather_bytes(fp.tobytes() + bytes([status]))
+        gathered = _tagged(all_gather_bytes, b"F", fp.tobytes() + bytes([status]))
         any_status = 0
         for g in gathered:
             any_status |= g[-1]
@@ -103,9 +103,9 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         allfp = np.concatenate([np.frombuffer(g[:-1], dtype=np.uint64) for g in gathered]) if gathered else np.zeros(0, np.uint64)
         mine = np.sort(allfp[allfp % np.uint64(world) == np.uint64(rank)])
         suspect = bool(mine.size > 1 and (mine[1:] == mine[:-1]).any())
-        flags = all_gather_bytes(bytes([1 if suspect else 0]))
+        flags = _tagged(all_gather_bytes, b"S", bytes([1 if suspect else 0]), 1)
         if any(f[0] for f in flags):
-            gk = all_gather_bytes(keys.tobytes())
+            gk = _tagged(all_gather_bytes, b"X", keys.tobytes())
             allk = np.concatenate([np.frombuffer(g, dtype=np.uint8).reshape(-1, 33) for g in gk])
             if has_duplicate_rows(allk):
                 return False                                   # some message occurs twice
@@ -117,7 +117,7 @@ def sharded_verify_aggregate(group, shard_msgs, shard_pks, sig, rank, world, all
         if fut is not None:
             import concurrent.futures
             concurrent.futures.wait([fut])                     # never leave the shard's call running behind a return
-    parts = all_gather_bytes(np.asarray(part, dtype=np.uint64).tobytes() + bytes([(1 if bad else 0) | (2 if failure is not None else 0)]))
+    parts = _tagged(all_gather_bytes, b"P", np.asarray(part, dtype=np.uint64).tobytes() + bytes([(1 if bad else 0) | (2 if failure is not None else 0)]), 577)
     if failure is not None:
         raise failure
     if any(p[-1] & 2 for p in parts):
@@ -137,32 +137,44 @@ _EXEC = None
 
 
 def _executor():
-    """one worker thread per process for the shard's device call (not one pool per VerifyAggregate)"""
+    """a small pool per process for the shards' device calls (not one pool per VerifyAggregate; several workers so that
+    VerifyAggregates issued from different threads do not queue behind one another -- the library leases them separate contexts)"""
     global _EXEC
     if _EXEC is None:
         import concurrent.futures
-        _EXEC = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="blsmi-shard")
+        _EXEC = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="blsmi-shard")
     return _EXEC
 
 
-_FP_KEYS = {}
 _FP_TEST_MASK = None      # test hook: AND every fingerprint with this mask (forces collisions between distinct messages)
 
 
+class OutOfStep(RuntimeError):
+    """the ranks' collective sequences have drifted apart (a restarted rank, a different group): a payload carried the wrong tag"""
+
+
+def _tagged(all_gather_bytes, tag, payload, fixed_len=None):
+    """all-gather of tag + payload; every part must carry the same tag (and length, when fixed): a rank that is one collective
+    ahead or behind -- restarted into an existing group, or raised before its first call -- is detected instead of misparsed"""
+    parts = all_gather_bytes(tag + payload)
+    for i, p in enumerate(parts):
+        if p[:1] != tag or (fixed_len is not None and len(p) != 1 + fixed_len):
+            raise OutOfStep("sharded_verify_aggregate: rank %d sent a %r-tagged payload of %d bytes where %r (%s bytes) was expected"
+                            % (i, bytes(p[:1]), len(p), tag, "any" if fixed_len is None else 1 + fixed_len))
+    return [p[1:] for p in parts]
+
+
 def _fingerprint_key(all_gather_bytes, world):
-    """(k0, k1) of the keyed message fingerprint, the same on every rank and unknown to whoever supplies the messages: on the
-    first call every rank contributes 16 random bytes through one all-gather and the XOR of the contributions is kept for
-    the life of the process (every rank makes that first call together: the function is a collective)."""
-    key = _FP_KEYS.get(world)
-    if key is None:
-        import os
-        parts = all_gather_bytes(os.urandom(16))
-        acc = np.zeros(2, dtype=np.uint64)
-        for p in parts:
-            acc ^= np.frombuffer(p[:16], dtype=np.uint64)
-        key = (np.uint64(acc[0]), np.uint64(acc[1]) | np.uint64(1))
-        _FP_KEYS[world] = key
-    return key
+    """(k0, k1) of the keyed message fingerprint for THIS call, the same on every rank and unknown to whoever supplies the
+    messages: every rank contributes 16 fresh random bytes through one tagged all-gather, the key is the XOR.  Derived per
+    call (17 bytes per rank: nothing beside the fingerprints) -- a key cached per process made the first call a hidden collective
+    that a restarted rank, or one joining a second group of the same size, would replay out of step."""
+    import os
+    parts = _tagged(all_gather_bytes, b"K", os.urandom(16), 16)
+    acc = np.zeros(2, dtype=np.uint64)
+    for p in parts:
+        acc ^= np.frombuffer(p[:16], dtype=np.uint64)
+    return (np.uint64(acc[0]), np.uint64(acc[1]) | np.uint64(1))
 
 
 def row_fingerprints(keys, fkey=(np.uint64(0x9e3779b97f4a7c15), np.uint64(0xff51afd7ed558ccd))):

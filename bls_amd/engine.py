@@ -137,28 +137,35 @@ def _msgs(msgs):
 
 # ---- pairing ---------------------------------------------------------------------------------------
 class HostBuffer:
-    """Page-locked host memory from the library (blsmi_host_alloc) as a numpy uint8 array: `.a`.  Free with .free() (or let it go:
-    the finaliser frees it).  Arrays handed to the host entry points from such memory are copied by DMA instead of being staged."""
+    """Page-locked host memory from the library (blsmi_host_alloc) as a numpy uint8 array: `.a`.  Arrays handed to the host entry
+    points from such memory are copied by DMA instead of being staged.  The block is returned to the runtime when the LAST numpy view of
+    it is gone: `.a` and every slice taken from it keep the allocation alive (they hold the ctypes block whose finaliser frees it), so
+    .free() -- or dropping the HostBuffer -- can never pull memory from under a view that is still in use."""
 
     def __init__(self, nbytes):
-        self._p = C.c_void_p()
-        _lib().blsmi_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
-        _check(_lib().blsmi_host_alloc(C.c_size_t(int(nbytes)), C.byref(self._p)), "blsmi_host_alloc")
+        import weakref
+        p = C.c_void_p()
+        lib = _lib()
+        lib.blsmi_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+        lib.blsmi_host_free.argtypes = [C.c_void_p]
+        _check(lib.blsmi_host_alloc(C.c_size_t(int(nbytes)), C.byref(p)), "blsmi_host_alloc")
         self.nbytes = int(nbytes)
-        self.a = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(self.nbytes,)) if nbytes else np.zeros(0, np.uint8)
+        if nbytes:
+            block = (C.c_uint8 * self.nbytes).from_address(p.value)         # every numpy view below references this object
+            self._finalizer = weakref.finalize(block, lib.blsmi_host_free, C.c_void_p(p.value))
+            self.a = np.frombuffer(block, dtype=np.uint8)
+        else:
+            self._finalizer = None
+            self.a = np.zeros(0, np.uint8)
+
+    @property
+    def alive(self):
+        """False once the block has gone back to the runtime (no view of it is left)"""
+        return self._finalizer is not None and self._finalizer.alive
 
     def free(self):
-        if self._p and self._p.value:
-            _lib().blsmi_host_free.argtypes = [C.c_void_p]
-            _lib().blsmi_host_free(self._p)
-            self._p = C.c_void_p()
-            self.a = None
-
-    def __del__(self):
-        try:
-            self.free()
-        except Exception:
-            pass
+        """drop this object's reference; the memory is released as soon as no view of `.a` remains (at once if there is none)"""
+        self.a = None
 
 
 def pairing_batch(g1_aff, g2_aff, n, out=None):
@@ -228,6 +235,20 @@ def msm_dev(group, d_pts, d_scalars, n, d_out, stream=0, any_point=False):
     fn = _lib().blsmi_g1_msm_dev if group == "g1" else _lib().blsmi_g2_msm_dev
     _check(fn(C.c_void_p(d_pts), C.c_void_p(d_scalars), C.c_size_t(n), C.c_void_p(d_out), C.byref(oinf), C.c_void_p(stream)), "msm_dev")
     return bool(oinf.value)
+
+
+def verify_aggregate_common_dev(group, d_pks, n, msg, sig, domain=None, stream=0):
+    """VerifyAggregateCommon (g2pubs/bls.go:275-278, g1pubs/bls.go:287-297) with the n public keys resident on the device (int =
+    device pointer); msg / sig = host bytes; domain (8 bytes, g1pubs only): the *WithDomain form over a 32-byte message."""
+    ok = C.c_int(0)
+    m = _u8(msg) if len(msg) else None
+    if domain is not None:
+        assert group == "g1pubs"
+        _check(_lib().blsmi_g1pubs_verify_aggregate_common_with_domain_dev(C.c_void_p(d_pks or 0), C.c_size_t(n), _p8(_u8(msg, 32)), _p8(_u8(domain, 8)), _p8(_u8(sig, 192)), C.byref(ok), C.c_void_p(stream)), "verify_aggregate_common_with_domain_dev")
+        return bool(ok.value)
+    fn, sgb = (_lib().blsmi_g2pubs_verify_aggregate_common_dev, 96) if group == "g2pubs" else (_lib().blsmi_g1pubs_verify_aggregate_common_dev, 192)
+    _check(fn(C.c_void_p(d_pks or 0), C.c_size_t(n), _p8(m) if m is not None else None, C.c_size_t(len(msg)), _p8(_u8(sig, sgb)), C.byref(ok), C.c_void_p(stream)), "verify_aggregate_common_dev")
+    return bool(ok.value)
 
 
 def verify_aggregate_dev(group, d_msgs, d_off, d_pks, sig, n, stream=0):

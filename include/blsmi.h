@@ -265,6 +265,13 @@ int blsmi_g2pubs_verify_aggregate_dev(const void *d_msgs, const void *d_off, con
 int blsmi_g1pubs_verify_aggregate_dev(const void *d_msgs, const void *d_off, const void *d_pks, const uint8_t sig[192], size_t n, int *ok, void *stream);
 int blsmi_g1pubs_verify_aggregate_with_domain_dev(const void *d_msgs32, const void *d_domain, const void *d_pks, const uint8_t sig[192], size_t n, int *ok, void *stream);
 
+/* device-pointer forms of VerifyAggregateCommon (g2pubs/bls.go:275-278, g1pubs/bls.go:287-297): the n public keys resident on one of
+ * the library's devices (a validator set kept in HBM) are summed where they lie, then one Verify runs; message, domain and signature are
+ * HOST bytes.  n = 0: the empty sum is the point at infinity, verdict 0.  (blsmi 0.5) */
+int blsmi_g2pubs_verify_aggregate_common_dev(const void *d_pks /* n*192 */, size_t n, const uint8_t *msg, size_t msg_len, const uint8_t sig[96], int *ok, void *stream);
+int blsmi_g1pubs_verify_aggregate_common_dev(const void *d_pks /* n*96 */, size_t n, const uint8_t *msg, size_t msg_len, const uint8_t sig[192], int *ok, void *stream);
+int blsmi_g1pubs_verify_aggregate_common_with_domain_dev(const void *d_pks /* n*96 */, size_t n, const uint8_t msg32[32], const uint8_t domain[8], const uint8_t sig[192], int *ok, void *stream);
+
 /* ---- Deserialize + Verify in one pass: keys and signatures in the compressed wire format (what
  * PublicKey.Serialize / Signature.Serialize produce, g2pubs/bls.go:18-20, 67-69): g2pubs pk 96 B + sig 48 B,
  * g1pubs pk 48 B + sig 96 B.  check_subgroup != 0 applies the subgroup test of DeserializePublicKey /

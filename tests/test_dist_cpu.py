@@ -190,3 +190,23 @@ def test_sharded_verify_aggregate_gloo_world2():
         assert p.exitcode == 0
     for rank, ok, ok_dup, ok_bad, ref in res:
         assert ok is True and ref is True and ok_dup is False and ok_bad is False
+
+
+def test_ranks_out_of_step_are_detected_not_misparsed():
+    """every exchange of sharded_verify_aggregate is tagged and (where fixed) length-checked: a rank that replays an earlier or later
+    collective -- restarted into a live group, or joined to a second group of the same size -- raises OutOfStep on every
+    rank instead of having its nonce read as fingerprints"""
+    import os
+    from bls_amd import dist as bdist
+    ok = bdist._tagged(lambda b: [b, b"K" + bytes(16)], b"K", os.urandom(16), 16)
+    assert len(ok) == 2 and len(ok[1]) == 16
+    with pytest.raises(bdist.OutOfStep):
+        bdist._tagged(lambda b: [b, b"F" + bytes(8 * 5 + 1)], b"K", os.urandom(16), 16)          # the peer is one collective ahead
+    with pytest.raises(bdist.OutOfStep):
+        bdist._tagged(lambda b: [b, b"K" + bytes(15)], b"K", os.urandom(16), 16)                 # right tag, wrong length
+    with pytest.raises(bdist.OutOfStep):
+        bdist._tagged(lambda b: [b"", b], b"P", bytes(577), 577)
+    # the per-call key: two calls give different keys (nothing is cached per process), both odd in k1
+    gather = lambda b: [b, b"K" + bytes(16)]                                                     # noqa: E731
+    k1, k2 = bdist._fingerprint_key(gather, 2), bdist._fingerprint_key(gather, 2)
+    assert k1 != k2 and int(k1[1]) & 1 and int(k2[1]) & 1

@@ -158,3 +158,48 @@ def test_latency_hint(eng):
         assert not E.prefer_cpu(shape, 1)
     assert E.prefer_cpu(E.SHAPE_POINT_ADD, 38) and not E.prefer_cpu(E.SHAPE_POINT_ADD, 39)
     assert not E.prefer_cpu(99, 1) and not E.prefer_cpu(-1, 1)
+
+
+def test_verify_aggregate_common_with_resident_keys(eng):
+    """VerifyAggregateCommon (g2pubs/bls.go:275-278, g1pubs/bls.go:287-297 incl. the *WithDomain form) with the public keys resident in
+    HBM: verdicts equal the oracle's and the host form's -- true aggregate, one key dropped from the signature, a foreign key in the
+    set, empty message, n = 0 -- for a handful of signers and for 3 000 (tree sum over several levels)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    xs = P.XORShift(4105)
+    msg = b"common message"; m32 = bytes(range(32)); dom = bytes(range(8))
+    for group, O, nk in (("g2pubs", RC.g2pubs, 5), ("g1pubs", RC.g1pubs, 5), ("g2pubs", RC.g2pubs, 3000), ("g1pubs", RC.g1pubs, 3000)):
+        sks = [sk_bytes(xs) for _ in range(7)]
+        pks7 = [O.priv_to_pub(s) for s in sks]
+        pkb = len(pks7[0])
+        # nk signers: the 7 keys repeated (the aggregate signature is the matching multiple of the 7 signatures' sum)
+        reps = [nk // 7 + (1 if i < nk % 7 else 0) for i in range(7)]
+        pks = [pks7[i % 7] for i in range(nk)]
+        mul = eng.g1_mul_batch if group == "g2pubs" else eng.g2_mul_batch
+        summ = eng.g1_sum if group == "g2pubs" else eng.g2_sum
+        def aggregate(message, sign, count):
+            sigs = [sign(message, s) for s in sks]
+            sb = len(sigs[0])
+            scaled, inf = mul(b"".join(sigs), b"".join(int(c).to_bytes(32, "big") for c in count), 7)
+            return summ(scaled.reshape(-1), 7, inf.astype(np.uint8))
+        d_k = torch.from_numpy(np.frombuffer(b"".join(pks), dtype=np.uint8).copy()).to(dev)
+        host = eng.g2pubs_verify_aggregate_common if group == "g2pubs" else eng.g1pubs_verify_aggregate_common
+        for message in (msg, b""):
+            agg = aggregate(message, O.sign, reps)
+            assert eng.verify_aggregate_common_dev(group, d_k.data_ptr(), nk, message, agg) is True
+            assert host(message, b"".join(pks), agg, nk) is True
+            if nk <= 8:
+                assert O.verify_aggregate_common(agg, pks, message) is True
+            short = aggregate(message, O.sign, [reps[0] - 1] + reps[1:])                 # one signature missing
+            assert eng.verify_aggregate_common_dev(group, d_k.data_ptr(), nk, message, short) is False
+            if nk <= 8:
+                assert O.verify_aggregate_common(short, pks, message) is False
+        bad = d_k.clone(); bad[pkb * (nk - 1):pkb * nk] = torch.from_numpy(np.frombuffer(O.priv_to_pub(sk_bytes(xs)), dtype=np.uint8).copy()).to(dev)
+        assert eng.verify_aggregate_common_dev(group, bad.data_ptr(), nk, msg, aggregate(msg, O.sign, reps)) is False
+        assert eng.verify_aggregate_common_dev(group, 0, 0, msg, aggregate(msg, O.sign, reps)) is False       # no keys: the sum is infinity
+        if group == "g1pubs":
+            aggd = aggregate(m32, lambda m, s: RC.g1pubs.sign_with_domain(m, s, dom), reps)
+            assert eng.verify_aggregate_common_dev(group, d_k.data_ptr(), nk, m32, aggd, domain=dom) is True
+            assert eng.verify_aggregate_common_dev(group, d_k.data_ptr(), nk, m32, aggd, domain=bytes(8)) is False
+            if nk <= 8:
+                assert RC.g1pubs.verify_aggregate_common_with_domain(aggd, pks, m32, dom) is True

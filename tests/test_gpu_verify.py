@@ -432,8 +432,8 @@ def test_sharded_verify_aggregate_single_process(eng):
                     return gather
                 # pass 1: record each rank's contributions; pass 2: replay with full gathers
                 contrib = []
-                fkey = (np.uint64(0x1234567890abcdef), np.uint64(0xfedcba0987654321))   # the nonce the ranks would have agreed on
-                bdist._FP_KEYS[world] = fkey
+                fkey = (np.uint64(0x1234567890abcdef), np.uint64(0xfedcba0987654321))   # the nonce the ranks agree on: XOR of their contributions
+                knonce = [b"K" + np.array(fkey, dtype=np.uint64).tobytes()] + [b"K" + bytes(16)] * (world - 1)
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
                     keys = np.frombuffer(bdist.message_keys(msgs[lo:hi]), dtype=np.uint8).reshape(-1, 33)
@@ -443,11 +443,10 @@ def test_sharded_verify_aggregate_single_process(eng):
                 outs = []
                 for r in range(world):
                     lo, hi = bdist.shard_bounds(n, r, world)
-                    # the three exchanges of a duplicate-free aggregate: fingerprints, suspicion flags, partial products
-                    seq = iter([[c[0] for c in contrib], [b"\x00"] * world, [c[1] for c in contrib]])
+                    # the four (tagged) exchanges of a duplicate-free aggregate: nonce, fingerprints, suspicion flags, partial products
+                    seq = iter([knonce, [b"F" + c[0] for c in contrib], [b"S\x00"] * world, [b"P" + c[1] for c in contrib]])
                     outs.append(bdist.sharded_verify_aggregate(group, msgs[lo:hi], b"".join(pk_list[lo:hi]), agg, r, world, lambda b: next(seq)))
                 assert len(set(outs)) == 1
-                bdist._FP_KEYS.pop(world, None)
                 return outs[0]
             assert run(pks) is True
             assert run([pks[1], pks[0]] + pks[2:]) is False
