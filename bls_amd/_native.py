@@ -18,6 +18,14 @@ BUILD_DIR = os.path.join(CSRC, "build")
 # -Werror=pass-failed: a kernel that misses its declared waves-per-SIMD (a shared device function that outgrew the register budget)
 # stops the build instead of running at half occupancy
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Werror=pass-failed"]
+# The lane-pair / lane-quad pairing kernels compute in 14 x 28-bit limbs (fp.cuh: BLSMI_LIMBS28; 196 instead of 225 multiply-adds per
+# product), every other unit in 15 x 27; buffers that cross between kernels keep the 27-bit form.  BLSMI_BUILD_LIMBS27=1 builds those
+# units in 15 x 27 as well (A/B).
+_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip")
+
+
+def _unit_flags(u):
+    return ["-DBLSMI_LIMBS28"] if u in _LIMBS28_UNITS else []
 
 
 def _deps(unit):
@@ -63,6 +71,9 @@ def build(force=False, verbose=False):
     gen = os.path.join(CSRC, "gen_consts.py")
     if not os.path.exists(consts) or os.path.getmtime(gen) > os.path.getmtime(consts):
         subprocess.check_call(["python3", gen])
+    consts28 = os.path.join(CSRC, "consts28.cuh")
+    if not os.path.exists(consts28) or os.path.getmtime(gen) > os.path.getmtime(consts28):
+        subprocess.check_call(["python3", gen, "--limbs28"])
     genlat = os.path.join(CSRC, "gen_lat.py")
     if not os.path.exists(LAT_BIN) or os.path.getmtime(genlat) > os.path.getmtime(LAT_BIN):
         subprocess.check_call(["python3", genlat])
@@ -79,7 +90,7 @@ def build(force=False, verbose=False):
         if not force and not _unit_stale(u):
             continue
         obj = os.path.join(BUILD_DIR, u + ".o")
-        cmd = [hipcc] + _FLAGS + ["-c", "-MD", "-MF", os.path.join(BUILD_DIR, u + ".d"), "-o", obj, os.path.join(CSRC, u)]
+        cmd = [hipcc] + _FLAGS + _unit_flags(u) + ["-c", "-MD", "-MF", os.path.join(BUILD_DIR, u + ".d"), "-o", obj, os.path.join(CSRC, u)]
         if u == "blsmi.hip":
             cmd.insert(1, '-DBLSMI_LAT_BIN="%s"' % LAT_BIN)
         if verbose:
@@ -128,6 +139,12 @@ def load():
     """Return the ctypes handle of libblsmi.so; never falls back to anything else."""
     global _lib
     if _lib is not None:
+        return _lib
+    alt = os.environ.get("BLSMI_LIB")                      # development only: an A/B build of the same library (tools/build_variant.sh)
+    if alt:
+        _prefer_torch_hip_runtime()
+        _lib = C.CDLL(os.path.abspath(alt))
+        _lib.blsmi_version.restype = C.c_char_p
         return _lib
     if not os.path.exists(SO_PATH):
         raise NativeError("bls_amd/libblsmi.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -155,7 +155,7 @@ struct Ctx {
 constexpr int MAX_CTX = 16;
 constexpr int MAX_DEV = 16;
 // G1/G2 generators in wire form and the generator's prepared lines, written once per device at init (read-only afterwards)
-struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; u8* lat = nullptr;         // lat: the latency-path programs (k_lat.hip)
+struct Gens { u8* g1 = nullptr; u8* g2 = nullptr; i32* lines = nullptr; i32* lines_pair = nullptr; u8* lat = nullptr;   // lines_pair: the same lines in the limbs of the lane-pair / lane-quad pairing kernels (14 x 28 bits); lat: the latency-path programs (k_lat.hip)
               i32* fixed1 = nullptr; i32* fixed2 = nullptr; };                                    // fixed-base tables of the generators (k_curve.hip: PrivToPub)
 struct Device {
     int id = -1;                        // HIP device ordinal
@@ -235,6 +235,8 @@ int init_device(Device& d) {            // caller holds g_mu
         hipLaunchKernelGGL(k_write_generators, dim3(1), dim3(WG), 0, nullptr, d.gens.g1, d.gens.g2);
         HIPCHK(hipMalloc((void**)&d.gens.lines, sizeof(i32) * 68 * 3 * 2 * NL));
         hipLaunchKernelGGL(k_prepare_generator_lines, dim3(1), dim3(WG), 0, nullptr, (const u8*)d.gens.g2, d.gens.lines);
+        HIPCHK(hipMalloc((void**)&d.gens.lines_pair, sizeof(i32) * 68 * 3 * 2 * NL));
+        hipLaunchKernelGGL(k_prepare_generator_lines_pair, dim3(1), dim3(WG), 0, nullptr, (const u8*)d.gens.g2, d.gens.lines_pair);
         HIPCHK(hipGetLastError());
         if (inflate_programs()) { fprintf(stderr, "blsmi: the embedded level programs do not inflate\n"); return BLSMI_E_ARG; }
         HIPCHK(hipMalloc((void**)&d.gens.lat, LAT_TOTAL_BYTES));
@@ -568,7 +570,7 @@ BLSMI_API void blsmi_shutdown(void) {
             (void)hipStreamDestroy(c.stream);
             c.stream = nullptr;
         }
-        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); (void)hipFree(dv.gens.lat); (void)hipFree(dv.gens.fixed1); (void)hipFree(dv.gens.fixed2); dv.gens = Gens{}; }
+        if (dv.gens.g1) { (void)hipFree(dv.gens.g1); (void)hipFree(dv.gens.g2); (void)hipFree(dv.gens.lines); (void)hipFree(dv.gens.lines_pair); (void)hipFree(dv.gens.lat); (void)hipFree(dv.gens.fixed1); (void)hipFree(dv.gens.fixed2); dv.gens = Gens{}; }
         hipMemPool_t pool;
         if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     }

@@ -19,15 +19,18 @@ using namespace blsmi;
 // device-side I/O helpers
 // ------------------------------------------------------------------------------------------------
 // internal structure-of-arrays buffers: word (e, j) of tuple t lives at buf[(e*NL + j)*n + t]
+// (always the 15 x 27-bit limbs of the Montgomery(2^405) form: the 28-bit-limb pairing kernels convert here, fp.cuh: fp_to_limbs27)
 BLSMI_DEV void soa_store(i32* buf, size_t n, size_t t, int e, const FpS& x) {
+    i32 w[NL_IO];
+    fp_to_limbs27(x, w);
 #pragma unroll
-    for (int j = 0; j < NL; j++) buf[((size_t)e * NL + j) * n + t] = x.v[j];
+    for (int j = 0; j < NL_IO; j++) buf[((size_t)e * NL_IO + j) * n + t] = w[j];
 }
 BLSMI_DEV FpS soa_load(const i32* buf, size_t n, size_t t, int e) {
-    FpS x;
+    i32 w[NL_IO];
 #pragma unroll
-    for (int j = 0; j < NL; j++) x.v[j] = buf[((size_t)e * NL + j) * n + t];
-    return x;
+    for (int j = 0; j < NL_IO; j++) w[j] = buf[((size_t)e * NL_IO + j) * n + t];
+    return fp_from_limbs27(w);
 }
 BLSMI_DEV void soa_store12(i32* buf, size_t n, size_t t, const Fp12S& f) {
     const FpS* c = reinterpret_cast<const FpS*>(&f);

@@ -31,13 +31,34 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef uint8_t u8;
 
+// Two builds of this header.  Default: 15 x 27-bit limbs, R = 2^405 -- every kernel family but one.  With -DBLSMI_LIMBS28 (the lane-pair and
+// lane-quad pairing kernels): 14 x 28-bit limbs, R = 2^392: 196 instead of 225 multiply-adds per product -- the lane-pair Fq2 product
+// 3 236 against 3 738 ns per call (tools/ubench_core28.hip, profiles/r04_ubench_core28.log) -- paid for with head-room: R / q is 2 560
+// instead of 2^24, so a stored value may be no larger than 11 q and a VALUE REDUCTION (fp_reduce) replaces the limb normalisation at
+// some results.  The bound V counts units of q / VU so that a Montgomery product (|value| < 1.41 q) is "3 halves" rather than "2 q":
+// with whole-q bounds the Fq6 products' outputs would need reducing, with halves they do not.  Every formula still computes its bounds
+// at compile time; where an operand is too large for a product the reduction is inserted by the type system (fp_fit).
+#ifdef BLSMI_LIMBS28
+constexpr int NL = 14;                 // limbs
+constexpr int LB = 28;                 // bits per limb
+constexpr int VU = 2;                  // V counts halves of q
+constexpr int LMAX = 7;                // L*(2^28+64) < 2^31
+constexpr int LPROD_MAX = 8;           // 14*(La*Lb+1)*2^56*(1+eps) < 2^63  <=>  La*Lb <= 8
+constexpr int VPROD_MAX = 4096;        // in units^2: |a*b|/R <= 1024 q^2 / 2^392 = 0.4 q: products land in (-0.4q, 1.4q)
+constexpr int VSTORE = 22;             // storage bound: 11 q -- two sums of two stored values still multiply in one fused pass (2 * 44 * 44 <= VPROD_MAX)
+#else
 constexpr int NL = 15;                 // limbs
 constexpr int LB = 27;                 // bits per limb
-constexpr i32 MASK = (1 << LB) - 1;
+constexpr int VU = 1;                  // V counts multiples of q
 constexpr int LMAX = 15;               // L*(2^27+64) < 2^31
 constexpr int LPROD_MAX = 33;          // 15*(La*Lb+1)*2^54*(1+eps) < 2^63  <=>  La*Lb <= 33
 constexpr int VPROD_MAX = 1 << 23;     // |a*b|/R <= 2^23 q^2 / 2^405 < 0.41 q: products land in (-0.41q, 1.41q)
-constexpr int VMAX = 1 << 12;          // top limb = value/2^378 stays far inside int32
+constexpr int VSTORE = 256;
+#endif
+constexpr i32 MASK = (1 << LB) - 1;
+constexpr int VMAX = 1 << 12;          // top limb = value/2^(LB (NL-1)) stays far inside int32
+constexpr int VMUL = VU + (VU + 1) / 2;    // bound of a Montgomery product: 2 q, or 3 halves of q (|value| < 1.41 q either way)
+constexpr int VRED = 2 * VU + 1;           // bound of fp_reduce's output: (-1.01 q, 2.01 q)
 #define BLSMI_DEV __device__ __forceinline__
 
 template <int L_, int V_>
@@ -45,12 +66,16 @@ struct Fp {
     static constexpr int L = L_, V = V_;
     i32 v[NL];
 };
-using FpS = Fp<1, 256>;                // storage type: (near-)normalised limbs, |value| <= 256 q
-using FpC = Fp<1, 1>;                  // canonical: limbs in [0,2^27), value in [0,q)
+using FpS = Fp<1, VSTORE>;             // storage type: (near-)normalised limbs, |value| <= VSTORE q / VU
+using FpC = Fp<1, VU>;                 // canonical: limbs in [0,2^LB), value in [0,q)
 
 }  // namespace blsmi
 #include "tower_fwd.cuh"
+#ifdef BLSMI_LIMBS28
+#include "consts28.cuh"
+#else
 #include "consts.cuh"
+#endif
 namespace blsmi {
 
 // widen the promised bounds (never narrows)
@@ -121,7 +146,10 @@ BLSMI_DEV Fp<L, V> fp_neg(const Fp<L, V>& a) {
 }
 template <int K, int L, int V>
 BLSMI_DEV auto fp_muls(const Fp<L, V>& a) {     // multiply by a small positive constant K
-    if constexpr (L * K > LMAX) return fp_muls<K>(fp_norm(a));
+    if constexpr (K > LMAX) {                   // (28-bit limbs: 8 and 12 exceed the limb head-room even on a normalised value) K = 4 * (K / 4)
+        static_assert(K % 4 == 0 && K / 4 <= LMAX, "factor the constant");
+        return fp_muls<K / 4>(fp_norm(fp_muls<4>(a)));
+    } else if constexpr (L * K > LMAX) return fp_muls<K>(fp_norm(a));
     else {
         static_assert(V * K <= VMAX, "value bound exceeded: insert fp_reduce");
         Fp<L * K, V * K> r;
@@ -132,13 +160,41 @@ BLSMI_DEV auto fp_muls(const Fp<L, V>& a) {     // multiply by a small positive 
 }
 template <int L, int V> BLSMI_DEV auto fp_dbl(const Fp<L, V>& a) { return fp_muls<2>(a); }
 
+// ---- value reduction: subtract round(value/q)*q with exact carries -> value in (-1.01q, 2.01q) ------
+// The quotient is estimated in fp32 from the two top limbs (value / 2^351); un-normalised lower limbs
+// (|limb| <= 15 * 2^27) move the estimate by < 2^-25, and the exact carry pass below normalises anyway.
+template <int L, int V>
+BLSMI_DEV Fp<1, VRED> fp_reduce(const Fp<L, V>& x) {
+    static_assert(V <= VMAX, "value bound exceeded");
+    static_assert(L <= LMAX, "limb bound exceeded before reduce");
+    const Fp<L, V>& y = x;
+    const float top = (float)y.v[NL - 1] * (float)(1 << LB) + (float)y.v[NL - 2];
+    const i32 k = (i32)floorf(top * BLSMI_Q_TOP2_INV);
+    Fp<1, VRED> r;
+    i64 c = 0;
+#pragma unroll
+    for (int i = 0; i < NL - 1; i++) {
+        c += (i64)y.v[i] - (i64)k * C_Q[i];
+        r.v[i] = (i32)c & MASK;
+        c >>= LB;
+    }
+    c += (i64)y.v[NL - 1] - (i64)k * C_Q[NL - 1];
+    r.v[NL - 1] = (i32)c;
+    return r;
+}
+// fp_fit<VT>(x): x itself when its value bound is at most VT, else its reduction -- how products make their operands fit
+template <int VT, int L, int V>
+BLSMI_DEV auto fp_fit(const Fp<L, V>& x) {
+    if constexpr (V <= VT) return x; else { static_assert(VRED <= VT, "no reduction can make this operand fit"); return fp_reduce(x); }
+}
+constexpr int isqrt_floor(int n) { int r = 0; while ((long long)(r + 1) * (r + 1) <= n) r++; return r; }
 // ---- Montgomery multiplication (fq.go:70-79 = MultiplyFQRepr + MontReduce + reduceAssign) ----------
 // Product-scanning: column k accumulates a_i*b_(k-i) and m_i*q_(k-i) in ONE int64 (v_mad_i64_i32),
 // m_k = -acc/q mod 2^27 zeroes the low limb, the column is retired by an arithmetic shift.
 // Output: limbs 0..13 in [0,2^27), signed top limb, value in (-0.41q, 1.41q) (|value| <= 2q).
 // Kept out of line (vector-typed arguments travel in VGPRs v0-v29): the ~4 KB body stays hot in
 // the instruction cache while tower code shrinks to call sequences.
-typedef i32 vlimbs __attribute__((ext_vector_type(15)));
+typedef i32 vlimbs __attribute__((ext_vector_type(NL)));
 
 BLSMI_DEV vlimbs fp_mul_body(vlimbs a, vlimbs b) {
     i32 m[NL];
@@ -205,13 +261,14 @@ BLSMI_DEV auto fp_mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
     if constexpr (La * Lb > LPROD_MAX) {
         if constexpr (La >= Lb) return fp_mul(fp_norm(a), b);
         else return fp_mul(a, fp_norm(b));
+    } else if constexpr ((long long)Va * Vb > VPROD_MAX) {               // too large for one Montgomery pass: reduce the larger operand (28-bit limbs only)
+        if constexpr (Va >= Vb) return fp_mul(fp_reduce(a), b); else return fp_mul(a, fp_reduce(b));
     } else {
-        static_assert((long long)Va * Vb <= VPROD_MAX, "operand values too large for Montgomery: reduce one first");
         vlimbs x, y;
 #pragma unroll
         for (int i = 0; i < NL; i++) { x[i] = a.v[i]; y[i] = b.v[i]; }
         vlimbs z = fp_mul_core(x, y);
-        Fp<1, 2> r;
+        Fp<1, VMUL> r;
 #pragma unroll
         for (int i = 0; i < NL; i++) r.v[i] = z[i];
         return r;
@@ -220,41 +277,19 @@ BLSMI_DEV auto fp_mul(const Fp<La, Va>& a, const Fp<Lb, Vb>& b) {
 template <int L, int V>
 BLSMI_DEV auto fp_sqr(const Fp<L, V>& a) {
     if constexpr (2 * L * L > LPROD_MAX) return fp_sqr(fp_norm(a));
+    else if constexpr ((long long)V * V > VPROD_MAX) return fp_sqr(fp_reduce(a));
     else {
-        static_assert((long long)V * V <= VPROD_MAX, "operand value too large for Montgomery: reduce first");
         vlimbs x;
 #pragma unroll
         for (int i = 0; i < NL; i++) x[i] = a.v[i];
         vlimbs z = fp_sqr_core(x);
-        Fp<1, 2> r;
+        Fp<1, VMUL> r;
 #pragma unroll
         for (int i = 0; i < NL; i++) r.v[i] = z[i];
         return r;
     }
 }
 
-// ---- value reduction: subtract round(value/q)*q with exact carries -> value in (-1.01q, 2.01q) ------
-// The quotient is estimated in fp32 from the two top limbs (value / 2^351); un-normalised lower limbs
-// (|limb| <= 15 * 2^27) move the estimate by < 2^-25, and the exact carry pass below normalises anyway.
-template <int L, int V>
-BLSMI_DEV Fp<1, 3> fp_reduce(const Fp<L, V>& x) {
-    static_assert(V <= VMAX, "value bound exceeded");
-    static_assert(L <= LMAX, "limb bound exceeded before reduce");
-    const Fp<L, V>& y = x;
-    const float top = (float)y.v[NL - 1] * 134217728.0f + (float)y.v[NL - 2];
-    const i32 k = (i32)floorf(top * BLSMI_Q_TOP2_INV);
-    Fp<1, 3> r;
-    i64 c = 0;
-#pragma unroll
-    for (int i = 0; i < NL - 1; i++) {
-        c += (i64)y.v[i] - (i64)k * C_Q[i];
-        r.v[i] = (i32)c & MASK;
-        c >>= LB;
-    }
-    c += (i64)y.v[NL - 1] - (i64)k * C_Q[NL - 1];
-    r.v[NL - 1] = (i32)c;
-    return r;
-}
 // bring any value into the storage type with the least work
 template <int L, int V>
 BLSMI_DEV FpS fp_store(const Fp<L, V>& x) {
@@ -275,7 +310,7 @@ BLSMI_DEV void limbs_addsub_q(const i32 in[NL], i32 out[NL], i32 addmask, i32 su
 }
 template <int L, int V>
 BLSMI_DEV FpC fp_canon(const Fp<L, V>& x) {
-    Fp<1, 3> r = fp_reduce(x);                            // limbs 0..13 in [0,2^27), value in (-1.01q, 2.01q)
+    Fp<1, VRED> r = fp_reduce(x);                         // limbs 0..NL-2 in [0,2^LB), value in (-1.01q, 2.01q)
     i32 t[NL], d[NL];
     limbs_addsub_q(r.v, t, r.v[NL - 1] >> 31, 0);          // + q if negative  -> [0, 2.01q)
 #pragma unroll
@@ -391,7 +426,7 @@ __device__ __noinline__ vlimbs fp_inv_core(vlimbs a_canon) {
     for (int i = 0; i < NL; i++) { f[i] = C_Q[i]; g[i] = a_canon[i]; d[i] = 0; e[i] = 0; }
     e[0] = 1;
     i32 zeta = -1;                                                         // -(delta + 1/2), delta starts at 1/2
-    for (int it = 0; it < 34; it++) {
+    for (int it = 0; it < (878 + LB - 1) / LB + 1; it++) {               // 34 batches of 27 divsteps (33 of 28): >= the 878-divstep bound
         // transition matrix of the next 27 divsteps from the low bits of f and g
         u32 u = 1, v = 0, qq = 0, r = 1;
         u32 fl = (u32)f[0] | ((u32)f[1] << LB), gl = (u32)g[0] | ((u32)g[1] << LB);
@@ -453,11 +488,11 @@ BLSMI_DEV FpS fp_inv(const Fp<L, V>& a) {
 #pragma unroll
     for (int i = 0; i < NL; i++) x[i] = c.v[i];
     const vlimbs z = fp_inv_core(x);
-    Fp<2, 3> r;                                                            // limb-wise negated limbs: |limb| < 2^27 + 1, |value| < 2q
+    Fp<2, 3 * VU> r;                                                       // limb-wise negated limbs: |limb| < 2^LB + 1, |value| < 2q
 #pragma unroll
     for (int i = 0; i < NL; i++) r.v[i] = z[i];
     // z = (a R)^-1 as a plain integer = a^-1 R^-1; one Montgomery product with R^3 gives a^-1 R
-    return fp_store(fp_mul(fp_relabel<1, 3>(fp_norm(r)), C_R3));
+    return fp_store(fp_mul(fp_relabel<1, 3 * VU>(fp_norm(r)), C_R3));
 }
 
 // Square root (fq.go:203-217): a1 = a^((q-3)/4); a0 = a1^2 a; ok iff a0 != -1; root = a1*a.
@@ -496,7 +531,7 @@ BLSMI_DEV void limbs_to_words(const i32 l[NL], u32 w[12]) {   // limbs must be c
 }
 // normal-form integer (raw limbs, must be < q else it becomes 0 like FQReprToFQ fq.go:49-56) -> Montgomery
 BLSMI_DEV FpS fp_from_words(const u32 w[12]) {
-    Fp<1, 1> raw;
+    Fp<1, VU> raw;
     words_to_limbs(w, raw.v);
     i32 c = 0;
 #pragma unroll
@@ -519,10 +554,62 @@ BLSMI_DEV void fp_to_mont384_words(const Fp<L, V>& a, u32 w[12]) {
     limbs_to_words(c.v, w);
 }
 BLSMI_DEV FpS fp_from_mont384_words(const u32 w[12]) {
-    Fp<1, 10> raw;                                         // a 384-bit word may exceed q (2^384 < 10 q)
+    Fp<1, 10 * VU> raw;                                    // a 384-bit word may exceed q (2^384 < 10 q)
     words_to_limbs(w, raw.v);
     return fp_relabel<1, FpS::V>(fp_mul(raw, C_FROM_M384));
 }
+// ---- the 27-bit-limb kernels' form of a value, at kernel boundaries ------------------------------------------------------------
+// Buffers that cross between kernels (the Miller-loop -> final-exponentiation hand-off, the Fq12 product tree, prepared lines) hold
+// field elements as the 15 x 27-bit limbs of the Montgomery(2^405) form -- the format of every kernel family but the 28-bit pairing
+// kernels, which convert where they load and store (6 elements per lane and kernel: ~0.1 % of a pairing).  x R27 = x R28 2^13.
+constexpr int NL_IO = 15;              // words per field element in those buffers (either build)
+constexpr i32 MASK27 = (1 << 27) - 1;
+#ifdef BLSMI_LIMBS28
+template <int L2, int V2, int L, int V>
+BLSMI_DEV Fp<L2, V2> fp_bound_of_constant(const Fp<L, V>& a) {            // a constant table entry is typed FpS but IS below q
+    Fp<L2, V2> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = a.v[i];
+    return r;
+}
+// 15 near-normalised signed limbs, |value| <= 256 q (what fp_store of the 27-bit build leaves) -> the same element here
+BLSMI_DEV FpS fp_from_limbs27(const i32 l[NL_IO]) {
+    i32 t[NL_IO];
+    i32 c = 0;
+#pragma unroll
+    for (int i = 0; i < NL_IO - 1; i++) { const i32 s = l[i] + C_512Q_27[i] + c; t[i] = s & MASK27; c = s >> 27; }   // + 512 q: non-negative, exact carries
+    t[NL_IO - 1] = l[NL_IO - 1] + C_512Q_27[NL_IO - 1] + c;
+    Fp<1, 768 * VU> raw;                                                   // the integer a R27 + k q, below 2^392, re-sliced into 28-bit limbs
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+        const int bit = LB * j, i = bit / 27, sh = bit % 27;
+        u32 x = (u32)t[i] >> sh;
+        if (i + 1 < NL_IO) x |= (u32)t[i + 1] << (27 - sh);
+        raw.v[j] = (i32)(x & (u32)MASK);
+    }
+    return fp_relabel<1, FpS::V>(fp_mul(raw, fp_bound_of_constant<1, VU>(C_FROM27)));   // mont28(X, R28 / 2^13) = a R28
+}
+template <int L, int V>
+BLSMI_DEV void fp_to_limbs27(const Fp<L, V>& a, i32 out[NL_IO]) {          // canonical a R27 mod q as 15 x 27-bit limbs
+    const FpC c = fp_canon(fp_mul(fp_store(a), fp_bound_of_constant<1, VU>(C_TO27)));
+#pragma unroll
+    for (int i = 0; i < NL_IO; i++) {
+        const int bit = 27 * i, j = bit / LB, sh = bit % LB;
+        u32 x = (u32)c.v[j] >> sh;
+        if (j + 1 < NL) x |= (u32)c.v[j + 1] << (LB - sh);
+        out[i] = (i32)(x & (u32)MASK27);
+    }
+}
+#else
+BLSMI_DEV FpS fp_from_limbs27(const i32 l[NL_IO]) { FpS r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) r.v[i] = l[i];
+    return r; }
+template <int L, int V>
+BLSMI_DEV void fp_to_limbs27(const Fp<L, V>& a, i32 out[NL_IO]) { const FpS s = fp_store(a);
+#pragma unroll
+    for (int i = 0; i < NL; i++) out[i] = s.v[i]; }
+#endif
 // big-endian 48-byte field element (g1.go:157-167 wire order) <-> words
 BLSMI_DEV void be48_to_words(const u8* p, u32 w[12]) {
 #pragma unroll

@@ -133,7 +133,10 @@ KERNEL k_glv_recode(const u8* scalars, int group, u8* rec, size_t n) {
 #pragma unroll
     for (int i = 0; i < 16; i++) o[i] = __builtin_bswap32(w[15 - i]);
 }
-KERNEL2 k_g1_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
+#ifndef BLSMI_GLV_WAVES
+#define BLSMI_GLV_WAVES 2
+#endif
+__global__ void __launch_bounds__(WG, BLSMI_GLV_WAVES) k_g1_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<FpS, 96>(pts, pt_stride, scalars, out, out_inf, n); }
 KERNEL k_g2_mul_glv(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) { mul_glv_body<Fp2S, 192>(pts, pt_stride, scalars, out, out_inf, n); }
 
 // ---- fixed-base multiplication of the group generators (PrivToPub, g2pubs/bls.go:138-140, g1pubs/bls.go:144-146) ------------------
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(WG, 2) k_g2_mul_pair(const u8* pts, size_t pt_
     const P2::G2AffP a = jac_to_affine(res);
     if (t < n) { pair_store_g2(out + (size_t)192 * t, par, a); if (!par) out_inf[t] = a.inf ? 1 : 0; }
 }
-__global__ void __launch_bounds__(WG, 2) k_g2_mul_glv_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
+__global__ void __launch_bounds__(WG, BLSMI_GLV_WAVES) k_g2_mul_glv_pair(const u8* pts, size_t pt_stride, const u8* scalars, u8* out, u8* out_inf, size_t n) {
     const int par = threadIdx.x & 1;
     const size_t t = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
     const size_t tt = t < n ? t : n - 1;

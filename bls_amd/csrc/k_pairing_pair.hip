@@ -61,4 +61,13 @@ __global__ void __launch_bounds__(WG, 2) k_debug_prepare_pair(const u8* g2, i32*
     if (threadIdx.x >= 2) return;
     const int par = threadIdx.x & 1;
     P2::prepare_lines(P2::wrap(load_be48(g2 + 48 * par)), P2::wrap(load_be48(g2 + 96 + 48 * par)), table);
+    for (int e = 0; e < 68 * 3; e++) P2::fp2_table_to_limbs27(table, e);      // the reader (k_debug_lines_to_m384) is a 27-bit-limb kernel
+}
+// G2AffineToPrepared of the G2 generator in THIS translation unit's own limbs (the table k_miller2_pair / k_miller2_quad read as `pre`:
+// with 28-bit limbs here, the start-up table of k_prepare_generator_lines -- 27-bit limbs -- is not theirs to read)
+__global__ void __launch_bounds__(WG, 2) k_prepare_generator_lines_pair(const u8* g2, i32* table) {
+    namespace P2 = blsmi::pairl;
+    if (threadIdx.x >= 2) return;
+    const int par = threadIdx.x & 1;
+    P2::prepare_lines(P2::wrap(load_be48(g2 + 48 * par)), P2::wrap(load_be48(g2 + 96 + 48 * par)), table);
 }

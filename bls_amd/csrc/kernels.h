@@ -25,6 +25,7 @@ __global__ void k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_
 // k_pairing_pair.hip
 __global__ void k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_debug_prepare_pair(const u8* g2, i32* table);
+__global__ void k_prepare_generator_lines_pair(const u8* g2, i32* table);
 // pair_kernels.inc
 __global__ void k_miller1_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_miller1h_pair(const u8* g1, const u8* g2, i32* fbuf, size_t n);

@@ -6,7 +6,11 @@
 #include "glv.cuh"        // (curve.cuh + the one-element-per-lane endomorphisms, which must see BLSMI_FP2_K before it is re-pointed)
 
 #ifdef BLSMI_ASM_CORES
+#ifdef BLSMI_CORE_ASM_INC
+#include BLSMI_CORE_ASM_INC
+#else
 #include "core_asm.inc"
+#endif
 #endif
 namespace blsmi {
 namespace pairl {

@@ -289,3 +289,7 @@ def test_core_asm_blobs_are_current(tmp_path):
     out = tmp_path / "core_asm.inc"
     subprocess.check_call([sys.executable, os.path.join(csrc, "gen_core_asm.py"), str(tmp_path)], timeout=600)
     assert out.read_text() == open(os.path.join(csrc, "core_asm.inc")).read(), "core_asm.inc is stale: run python bls_amd/csrc/gen_core_asm.py"
+    # ... and the blobs of the 14 x 28-bit build (k_fe_pair.hip with -DBLSMI_LIMBS28)
+    out28 = tmp_path / "core_asm28.inc"
+    subprocess.check_call([sys.executable, os.path.join(csrc, "gen_core_asm.py"), str(tmp_path), "--limbs28"], timeout=600)
+    assert out28.read_text() == open(os.path.join(csrc, "core_asm28.inc")).read(), "core_asm28.inc is stale: run python bls_amd/csrc/gen_core_asm.py --limbs28"
