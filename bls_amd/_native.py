@@ -21,7 +21,7 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 # The lane-pair / lane-quad pairing kernels compute in 14 x 28-bit limbs (fp.cuh: BLSMI_LIMBS28; 196 instead of 225 multiply-adds per
 # product), every other unit in 15 x 27; buffers that cross between kernels keep the 27-bit form.  BLSMI_BUILD_LIMBS27=1 builds those
 # units in 15 x 27 as well (A/B).
-_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip")
+_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_hash_pair.hip", "k_hash.hip", "k_curve.hip", "k_msm_pair.hip")
 
 
 def _unit_flags(u):
@@ -43,6 +43,11 @@ def _deps(unit):
 def _unit_stale(unit):
     obj = os.path.join(BUILD_DIR, unit + ".o")
     if not os.path.exists(obj):
+        return True
+    try:                                                  # built with other flags (the unit changed representation, an A/B build): rebuild
+        if open(obj + ".flags").read() != " ".join(_FLAGS + _unit_flags(unit)):
+            return True
+    except OSError:
         return True
     deps = _deps(unit)
     if deps is None:
@@ -99,6 +104,9 @@ def build(force=False, verbose=False):
     failed = [u for u, p in procs if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
+    for u, _ in procs:
+        with open(os.path.join(BUILD_DIR, u + ".o.flags"), "w") as f:
+            f.write(" ".join(_FLAGS + _unit_flags(u)))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", SO_PATH] + [os.path.join(BUILD_DIR, u + ".o") for u in _UNITS] + ["-lz"]
     if verbose:
         print(" ".join(cmd))

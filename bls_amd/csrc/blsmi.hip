@@ -1208,15 +1208,17 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     prof_mark(W == 6 ? (pairk ? "k_g2_msm_fold2_pair" : "k_g2_msm_fold2") : "k_g1_msm_fold2");
     i32* src = ch0.as<i32>(); i32* dst = ch1.as<i32>();
     int narr = 2, m = 0;
+    const bool lat_tail = g_lat_max > 0 && per_win_chunks == ((size_t)1 << 13) && K == 8;   // the tail runs as a latency program (k_lat.hip), which reads the inter-kernel record form
     for (size_t len = per_win_chunks; len > 1; len /= 2, narr++, m++) {
         const size_t lanes = (size_t)(narr + 1) * nbw * (len / 2);
-        if (pairk) hipLaunchKernelGGL(k_g2_msm_fold2_pair, dim3((unsigned)((lanes + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len);
-        else if (W == 6) hipLaunchKernelGGL(k_g2_msm_fold2, dim3(nblocks(lanes)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len);
-        else hipLaunchKernelGGL(k_g1_msm_fold2, dim3(nblocks(lanes)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len);
+        const int io = (lat_tail && len == 2) ? 1 : 0;                     // the last level writes what the tail program reads
+        if (pairk) hipLaunchKernelGGL(k_g2_msm_fold2_pair, dim3((unsigned)((lanes + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len, io);
+        else if (W == 6) hipLaunchKernelGGL(k_g2_msm_fold2, dim3(nblocks(lanes)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len, io);
+        else hipLaunchKernelGGL(k_g1_msm_fold2, dim3(nblocks(lanes)), dim3(WG), 0, s, (const i32*)src, dst, narr, nbw, len, io);
         std::swap(src, dst);
     }
     const size_t nrec = (size_t)(m + 2) * nbw;                             // X, L, O_0 .. O_{m-1} per window
-    if (g_lat_max > 0 && m == 13 && K == 8) {                              // Horner over the O's and over the 8 / 4 windows + ToAffine: one wave (k_lat.hip: msmfin1 / msmfin2)
+    if (lat_tail) {                              // Horner over the O's and over the 8 / 4 windows + ToAffine: one wave (k_lat.hip: msmfin1 / msmfin2)
         const size_t prog = W == 3 ? LAT_MSMFIN1_OFFSET : LAT_MSMFIN2_OFFSET;
         DBuf good; HIPCHK(good.alloc(1, s));
         prof_mark(W == 3 ? "k_lat:msmfin1" : "k_lat:msmfin2");

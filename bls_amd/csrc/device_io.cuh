@@ -19,19 +19,38 @@ using namespace blsmi;
 // device-side I/O helpers
 // ------------------------------------------------------------------------------------------------
 // internal structure-of-arrays buffers: word (e, j) of tuple t lives at buf[(e*NL + j)*n + t]
-// (always the 15 x 27-bit limbs of the Montgomery(2^405) form: the 28-bit-limb pairing kernels convert here, fp.cuh: fp_to_limbs27)
-BLSMI_DEV void soa_store(i32* buf, size_t n, size_t t, int e, const FpS& x) {
+// Two forms.  *_io: ALWAYS the 15 x 27-bit limbs of the Montgomery(2^405) form, whatever this unit's own limbs are -- the format of
+// buffers that cross between kernel families (the Miller-loop -> final-exponentiation hand-off, the Fq12 product tree, what the latency
+// programs of k_lat.hip read): a 28-bit-limb unit converts here (fp.cuh: fp_to_limbs27 / fp_from_limbs27).  Plain soa_store / soa_load
+// are the *_io forms unless the unit says BLSMI_SOA_NATIVE: then they keep the unit's own limbs (buffers no other unit reads: the
+// MSM passes and point sums of k_curve.hip / k_msm_pair.hip).  With 27-bit limbs the two coincide.
+BLSMI_DEV void soa_store_io(i32* buf, size_t n, size_t t, int e, const FpS& x) {
     i32 w[NL_IO];
     fp_to_limbs27(x, w);
 #pragma unroll
     for (int j = 0; j < NL_IO; j++) buf[((size_t)e * NL_IO + j) * n + t] = w[j];
 }
-BLSMI_DEV FpS soa_load(const i32* buf, size_t n, size_t t, int e) {
+BLSMI_DEV FpS soa_load_io(const i32* buf, size_t n, size_t t, int e) {
     i32 w[NL_IO];
 #pragma unroll
     for (int j = 0; j < NL_IO; j++) w[j] = buf[((size_t)e * NL_IO + j) * n + t];
     return fp_from_limbs27(w);
 }
+#ifdef BLSMI_SOA_NATIVE
+BLSMI_DEV void soa_store(i32* buf, size_t n, size_t t, int e, const FpS& x) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) buf[((size_t)e * NL + j) * n + t] = x.v[j];
+}
+BLSMI_DEV FpS soa_load(const i32* buf, size_t n, size_t t, int e) {
+    FpS x;
+#pragma unroll
+    for (int j = 0; j < NL; j++) x.v[j] = buf[((size_t)e * NL + j) * n + t];
+    return x;
+}
+#else
+BLSMI_DEV void soa_store(i32* buf, size_t n, size_t t, int e, const FpS& x) { soa_store_io(buf, n, t, e, x); }
+BLSMI_DEV FpS soa_load(const i32* buf, size_t n, size_t t, int e) { return soa_load_io(buf, n, t, e); }
+#endif
 BLSMI_DEV void soa_store12(i32* buf, size_t n, size_t t, const Fp12S& f) {
     const FpS* c = reinterpret_cast<const FpS*>(&f);
 #pragma unroll

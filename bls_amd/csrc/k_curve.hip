@@ -1,4 +1,5 @@
 // k_curve.hip -- scalar multiplication, point sums, the bucket-method MSM, and the Fq6 / curve unit ops of the parity tests.
+#define BLSMI_SOA_NATIVE                // the Jacobian SoA buffers of the sums and of the MSM passes are read by this unit (and k_msm_pair.hip) only
 #include "tower.cuh"
 #include "device_io.cuh"
 #include "glv.cuh"
@@ -211,6 +212,15 @@ BLSMI_DEV void jac_soa_store(i32* buf, size_t n, size_t t, const Jac<F>& p) {
 #pragma unroll
     for (int e = 0; e < W; e++) soa_store(buf, n, t, e, c[e]);
     buf[(size_t)W * NL * n + t] = p.inf;
+}
+// the same record in the inter-kernel form (15 x 27-bit limbs): what the MSM's last fold level leaves for the tail program of k_lat.hip
+template <class F>
+BLSMI_DEV void jac_soa_store_io(i32* buf, size_t n, size_t t, const Jac<F>& p) {
+    constexpr int W = jac_words<F>::value;
+    const FpS* c = reinterpret_cast<const FpS*>(&p);
+#pragma unroll
+    for (int e = 0; e < W; e++) soa_store_io(buf, n, t, e, c[e]);
+    buf[(size_t)W * NL_IO * n + t] = p.inf;
 }
 template <class F>
 BLSMI_DEV Jac<F> jac_soa_load(const i32* buf, size_t n, size_t t) {

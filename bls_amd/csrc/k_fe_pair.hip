@@ -3,9 +3,6 @@
 // (BLSMI_ASM_CORES: core_asm.inc, gen_core_asm.py) instead of out-of-line functions: every compiled function begins with
 // s_waitcnt vmcnt(0), which drains the caller's scratch stores at each of the ~5 000 products of a final exponentiation; an asm statement
 // does not.  Same-box A/B: k_final_exp_pair 11.39 -> 10.93 ms.  The Miller-loop kernels keep the function cores (9.46 -> 9.53 ms with blobs).
-#ifdef BLSMI_LIMBS28
-#define BLSMI_CORE_ASM_INC "core_asm28.inc"   // the same blobs for 14 x 28-bit limbs (gen_core_asm.py --limbs28)
-#endif
 #define BLSMI_ASM_CORES
 #include "pairing.cuh"
 #include "device_io.cuh"

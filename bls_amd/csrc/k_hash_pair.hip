@@ -6,7 +6,9 @@
 // the root of each map, one 379-squaring exponentiation each -- are split over the pair: the even lane takes map 1's, the odd lane
 // map 2's, so no lane repeats its partner's work.  Same point, same bytes as hash_g2.  Inputs the fused identities exclude
 // (g(x0) = 0, the two maps landing on opposite points) are flagged in good[] and redone by k_hash_g2_redo.
+#ifndef BLSMI_LIMBS28                // (with the 14-limb blobs clang 22's machine scheduler segfaults on iso3_jac: function cores in that build)
 #define BLSMI_ASM_CORES          // the lane-pair multiply cores as assembly blobs (core_asm.inc), as in k_fe_pair.hip: 6.41 -> 6.23 ms per 65 536 messages
+#endif
 #include "hash.cuh"
 #include "device_io.cuh"
 #include "pair_field.cuh"

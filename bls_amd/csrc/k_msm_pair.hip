@@ -3,7 +3,10 @@
 // compiled with the lane-pair multiply cores as assembly blobs (BLSMI_ASM_CORES, core_asm.inc, as k_fe_pair.hip):
 // k_g2_msm_bucket_raw_pair 12.2 -> 11.7 ms at 2^20 points, the 2^20-point G2 MSM 16.4 -> 15.6 ms; the scalar-multiplication kernels of
 // k_curve.hip keep the function cores (99.5 -> 100.8 ms with blobs).
+#ifndef BLSMI_LIMBS28                // (with the 14-limb blobs clang 22's machine scheduler segfaults on jac_add: function cores in that build)
 #define BLSMI_ASM_CORES
+#endif
+#define BLSMI_SOA_NATIVE                // the MSM's SoA buffers are shared with k_curve.hip only (same limbs there)
 #include "tower.cuh"
 #include "device_io.cuh"
 #include "glv.cuh"
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_chunk2_pair(const i32* buckets
     }
     if (t0 < nct) { pair_soa_store(out, 2 * nct, t, par, running); pair_soa_store(out, 2 * nct, nct + t, par, local); }
 }
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_fold2_pair(const i32* src, i32* dst, int narr, int nwin, size_t len) {
+__global__ void __launch_bounds__(WG, 2) k_g2_msm_fold2_pair(const i32* src, i32* dst, int narr, int nwin, size_t len, int io) {
     const int par = threadIdx.x & 1;
     const size_t half = len / 2, per_arr = (size_t)nwin * half, total = (size_t)(narr + 1) * per_arr;
     const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
@@ -111,5 +114,10 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_fold2_pair(const i32* src, i32
     } else {
         v = pair_soa_load(src, nsrc, (size_t)w * len + 2 * j + 1, par);
     }
-    if (t0 < total) pair_soa_store(dst, total, t, par, v);
+    if (t0 < total) {
+        if (io) {                                                          // the last level: the tail program of k_lat.hip reads the inter-kernel form
+            soa_store_io(dst, total, t, 0 + par, v.x.c); soa_store_io(dst, total, t, 2 + par, v.y.c); soa_store_io(dst, total, t, 4 + par, v.z.c);
+            if (!par) dst[(size_t)6 * NL_IO * total + t] = v.inf;
+        } else pair_soa_store(dst, total, t, par, v);
+    }
 }

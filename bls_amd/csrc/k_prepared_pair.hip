@@ -25,7 +25,7 @@ struct PairG1 { FpS x, y; };
 struct PairG2 { P2::Fp2S x, y; };
 constexpr int PT = WG / 2;
 constexpr int PREP_KEY_AT = blsmi_prep::KEY_AT, PREP_FLAG_AT = blsmi_prep::FLAG_AT, PREP_WORDS = blsmi_prep::WORDS;
-static_assert(blsmi_prep::LINE_WORDS == 68 * 3 * 2 * NL, "table layout");
+static_assert(blsmi_prep::LINE_WORDS == 68 * 3 * 2 * NL_IO, "table layout: NL_IO = 15 words per coefficient, of which this build's limbs fill the first NL");
 
 BLSMI_DEV void pair_store12(i32* buf, size_t n, size_t t, int par, const P2::Fp12S& f) {
     const FpS* c = reinterpret_cast<const FpS*>(&f);
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(WG) k_prepared_export(const i32* tables, u64* 
     if (i >= n * 408) return;
     const size_t key = i / 408; const int e = (int)(i % 408);
     FpS x;
-    const i32* src = tables + key * PREP_WORDS + (size_t)e * NL;
+    const i32* src = tables + key * PREP_WORDS + (size_t)e * NL_IO;
 #pragma unroll
     for (int k = 0; k < NL; k++) x.v[k] = src[k];
     store_m384(out + 6 * i, x);

@@ -112,7 +112,7 @@ __global__ void k_g2_msm_bucket_raw_pair(const i32* raw, const u32* idx, const u
 __global__ void k_g2_msm_chunk_pair(const i32* buckets, i32* chunks, int c, int K, size_t nb, size_t nchunks_total);
 __global__ void k_g2_msm_fold_pair(const i32* src, i32* dst, size_t seg, size_t half, int nwin);
 __global__ void k_g2_msm_chunk2_pair(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct);
-__global__ void k_g2_msm_fold2_pair(const i32* src, i32* dst, int narr, int nwin, size_t len);
+__global__ void k_g2_msm_fold2_pair(const i32* src, i32* dst, int narr, int nwin, size_t len, int io);
 // msm.inc
 __global__ void k_msm_hist(const u8* scalars, size_t n, int c, int nwin, u32* hist);
 __global__ void k_msm_scan(const u32* hist, u32* offs, u32* cursor, int c);
@@ -140,7 +140,7 @@ __global__ void k_msm_max_cap(const u32* count, size_t nb, u32 cap, u32* offs, u
 __global__ void k_g1_msm_bucket_raw(const i32* raw, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t per_win, size_t nb);
 __global__ void k_g1_msm_chunk2(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct);
 __global__ void k_g2_msm_chunk2(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct);
-__global__ void k_g1_msm_fold2(const i32* src, i32* dst, int narr, int nwin, size_t len);
-__global__ void k_g2_msm_fold2(const i32* src, i32* dst, int narr, int nwin, size_t len);
+__global__ void k_g1_msm_fold2(const i32* src, i32* dst, int narr, int nwin, size_t len, int io);
+__global__ void k_g2_msm_fold2(const i32* src, i32* dst, int narr, int nwin, size_t len, int io);
 __global__ void k_g1_msm_final2(const i32* recs, int nwin, int m, int logk, int c, u8* out, i32* out_inf);
 __global__ void k_g2_msm_final2(const i32* recs, int nwin, int m, int logk, int c, u8* out, i32* out_inf);

@@ -6,8 +6,8 @@
 #include "glv.cuh"        // (curve.cuh + the one-element-per-lane endomorphisms, which must see BLSMI_FP2_K before it is re-pointed)
 
 #ifdef BLSMI_ASM_CORES
-#ifdef BLSMI_CORE_ASM_INC
-#include BLSMI_CORE_ASM_INC
+#ifdef BLSMI_LIMBS28
+#include "core_asm28.inc"               // the same blobs for 14 x 28-bit limbs (gen_core_asm.py --limbs28)
 #else
 #include "core_asm.inc"
 #endif
