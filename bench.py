@@ -52,9 +52,10 @@ BYTES = {"pairing": 864,           # 96 B G1 + 192 B G2 in, 576 B Fq12 out
          "g2pubs_aggregate": 224, "g1pubs_aggregate": 128}   # 32-byte message + key in
 # integer-VALU issue ceiling: 1 024 SIMDs x 64 lanes per wave-instruction / 4 cycles x clock (the int32 / v_mad_*64 rate, tools/ubench*)
 SIMDS, LANES, CYCLES_PER_VALU, CLOCK_GHZ = 1024, 64, 4.0, 2.4
-# measured ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip, profiles/r01_ubench2_fmul_15x27.log)
-VALU_PEAK_GMULS = 61.2
-VALU_PEAK_2WAVE_GMULS = 56.7
+# measured ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip, profiles/r01_ubench2_fmul_15x27.log), scaled by
+# the multiply-add count of the 14x28-limb core the pairing kernels use since round 4 (2 x 196 against 2 x 225; tools/ubench_core28.hip)
+VALU_PEAK_GMULS = 61.2 * 225 / 196
+VALU_PEAK_2WAVE_GMULS = 56.7 * 225 / 196
 FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate: the nominal work unit of `valu.nominal`
 R_ORDER = 52435875175126190479447740508185965837690552500527637822603658699938581184513
 
@@ -992,7 +993,7 @@ def main():
         line = {
             "metric": "BLS12-381 pairings/sec (batch verify)", "value": round(value, 1), "unit": "pairings/s",
             "n_gpus": total_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (15 x 27-bit limbs, int64 accumulate)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (14 x 28-bit limbs in the pairing / hash / curve kernels, 15 x 27 in the latency programs; int64 accumulate)",
             "data": "synthetic",
             "launch": "torchrun: one process per GPU" if torchrun else "single process: %d device(s) behind the C ABI (blsmi_init_devices)" % ndev,
             "devices": total_gpus, "rccl_ranks": world if E.use_dist else 0,

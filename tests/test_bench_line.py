@@ -26,7 +26,7 @@ def _cpu(unit):
 def _detail():
     """a detail object shaped like a full one-GPU run, padded well beyond what real runs produce"""
     d = {"metric": "BLS12-381 pairings/sec (batch verify)", "value": 3204526.7, "unit": "pairings/s", "n_gpus": 1, "steps": 10, "warmup": 2, "ms_per_step": 20.451,
-         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (15 x 27-bit limbs, int64 accumulate)", "data": "synthetic",
+         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (14 x 28-bit limbs in the pairing / hash / curve kernels, 15 x 27 in the latency programs; int64 accumulate)", "data": "synthetic",
          "launch": "single process: 1 device(s) behind the C ABI (blsmi_init_devices)", "devices": 1, "rccl_ranks": 0, "library": "blsmi 0.5 gfx950:sramecc+:xnack- CUs=256 devices=1 shards=1",
          "config": {"workload": "w" * 500, "pairings_per_gpu": 65536, "parallelism": "shard1", "layout": "lane pair per tuple (one Fq2 coefficient per lane), 2 waves/SIMD"},
          "self_check": {"rows_per_device": 72, "against": "z" * 300, "passed": True},
