@@ -274,7 +274,7 @@ std::atomic<size_t> g_lat_max{8192};    // BLSMI_LAT_MAX, blsmi_set_latency_thre
 // Three layouts by batch size (pairings and verifies alike; tools/midsize.py): one tuple per WAVE up to min(g_lat_max, g_quad_min) tuples,
 // one per lane QUAD up to g_quad_max (16 384 tuples = one wave on every SIMD), one per lane PAIR beyond (65 536 fill the chip twice over).
 std::atomic<size_t> g_quad_max{16384};  // BLSMI_QUAD_MAX, blsmi_set_quad_threshold (0: no quad kernels)
-std::atomic<size_t> g_quad_min{6656};   // BLSMI_QUAD_MIN: the quad kernels take over from the latency path here already (7.0 ms flat against 1 ms per 1 024 tuples)
+std::atomic<size_t> g_quad_min{5632};   // BLSMI_QUAD_MIN: the quad kernels take over from the latency path here already (pairings: 5.9 ms flat against 1 ms per 1 024 tuples; verifies 8.7 against 1.5)
 inline bool use_quad(size_t n) { return g_pair_layout && n > std::min(g_lat_max.load(), g_quad_min.load()) && n <= g_quad_max; }
 inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
 inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }

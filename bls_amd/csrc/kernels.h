@@ -56,6 +56,7 @@ __global__ void k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n);
 __global__ void k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_hash_g1_finish(const u8* pts, u8* out, size_t n);
 __global__ void k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g2_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
