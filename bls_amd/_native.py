@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 # translation units of libblsmi.so: the host side + one unit per kernel family, compiled in parallel
-_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_hash.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "k_lat.hip", "k_util.hip"]
+_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_fq12_single.hip", "k_hash.hip", "k_wire.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "k_lat.hip", "k_util.hip"]
 LAT_BIN = os.path.join(CSRC, "lat_programs.z")            # level programs of the latency path (gen_lat.py), zlib-compressed, embedded into blsmi.hip.o
 BUILD_DIR = os.path.join(CSRC, "build")
 # -Werror=pass-failed: a kernel that misses its declared waves-per-SIMD (a shared device function that outgrew the register budget)
@@ -21,7 +21,12 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 # The lane-pair / lane-quad pairing kernels compute in 14 x 28-bit limbs (fp.cuh: BLSMI_LIMBS28; 196 instead of 225 multiply-adds per
 # product), every other unit in 15 x 27; buffers that cross between kernels keep the 27-bit form.  BLSMI_BUILD_LIMBS27=1 builds those
 # units in 15 x 27 as well (A/B).
-_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_hash_pair.hip", "k_hash.hip", "k_curve.hip", "k_msm_pair.hip")
+_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_hash_pair.hip", "k_hash.hip", "k_wire.hip", "k_curve.hip", "k_msm_pair.hip")
+
+
+# rough compile cost in seconds (scheduling order only)
+_COST = {"k_fe_single.hip": 45, "k_hash.hip": 40, "k_curve.hip": 50, "k_pairing_quad.hip": 45, "k_pairing_single.hip": 40, "k_pairing_pair.hip": 32, "k_wire.hip": 30,
+         "k_fq12_single.hip": 30, "k_fe_pair.hip": 17, "k_hash_pair.hip": 17, "k_prepared_pair.hip": 16, "blsmi.hip": 5, "k_msm_pair.hip": 13, "k_lat.hip": 8, "k_util.hip": 7}
 
 
 def _unit_flags(u):
@@ -80,28 +85,49 @@ def build(force=False, verbose=False):
     if not os.path.exists(consts28) or os.path.getmtime(gen) > os.path.getmtime(consts28):
         subprocess.check_call(["python3", gen, "--limbs28"])
     genlat = os.path.join(CSRC, "gen_lat.py")
+    latgen = None                                          # the level programs take ~7 s to generate and only blsmi.hip needs them: generated BESIDE the other units' compilation
     if not os.path.exists(LAT_BIN) or os.path.getmtime(genlat) > os.path.getmtime(LAT_BIN):
-        subprocess.check_call(["python3", genlat])
+        latgen = subprocess.Popen(["python3", genlat])
     genmul = os.path.join(CSRC, "gen_lat_mul.py")
     mulinc = os.path.join(CSRC, "lat_mul.inc")
     if not os.path.exists(mulinc) or os.path.getmtime(genmul) > os.path.getmtime(mulinc):
         subprocess.check_call(["python3", genmul])
-    if not force and not _stale():
+    if latgen is None and not force and not _stale():
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(BUILD_DIR, exist_ok=True)
-    procs = []
-    for u in _UNITS:
-        if not force and not _unit_stale(u):
-            continue
+    # longest units first, as many at a time as there are cores (one hipcc process each): ~55 s from scratch on 8 cores
+    todo = [u for u in sorted(_UNITS, key=lambda x: -_COST.get(x, 20)) if force or u == "blsmi.hip" and latgen is not None or _unit_stale(u)]
+    slots = max(2, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 4))
+    procs, running, failed = [], [], []
+
+    def reap(block):
+        import time
+        while True:
+            for item in list(running):
+                if item[1].poll() is not None:
+                    running.remove(item)
+                    if item[1].returncode != 0:
+                        failed.append(item[0])
+            if not block or len(running) < slots:
+                return
+            time.sleep(0.05)
+    for u in todo:
+        if u == "blsmi.hip" and latgen is not None:          # (its .incbin and lat_programs.h come out of the generator)
+            if latgen.wait() != 0:
+                raise subprocess.CalledProcessError(1, "python3 gen_lat.py")
+        reap(block=True)
         obj = os.path.join(BUILD_DIR, u + ".o")
         cmd = [hipcc] + _FLAGS + _unit_flags(u) + ["-c", "-MD", "-MF", os.path.join(BUILD_DIR, u + ".d"), "-o", obj, os.path.join(CSRC, u)]
         if u == "blsmi.hip":
             cmd.insert(1, '-DBLSMI_LAT_BIN="%s"' % LAT_BIN)
         if verbose:
             print(" ".join(cmd))
-        procs.append((u, subprocess.Popen(cmd)))
-    failed = [u for u, p in procs if p.wait() != 0]
+        p = subprocess.Popen(cmd)
+        procs.append((u, p)); running.append((u, p))
+    for u, p in procs:
+        p.wait()
+    reap(block=False)
     if failed:
         raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
     for u, _ in procs:

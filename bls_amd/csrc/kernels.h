@@ -15,12 +15,13 @@ __global__ void k_debug_prepare_single(const u8* g2, i32* table);
 __global__ void k_debug_lines_to_m384(const i32* table, u64* out);
 // k_fe_single.hip
 __global__ void k_final_exp(const i32* fbuf, u64* out, size_t n, int mode);
-__global__ void k_fq12_from_m384(const u64* in, i32* fbuf, size_t n);
 __global__ void k_final_exp_is_one(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+__global__ void k_final_exp_equal(const i32* a, const i32* b, i32* ok);
+// k_fq12_single.hip
+__global__ void k_fq12_from_m384(const u64* in, i32* fbuf, size_t n);
 __global__ void k_fq12_prod_level(const i32* src, i32* dst, size_t n, size_t half);
 __global__ void k_fq12_aos_to_soa(const i32* aos, i32* soa, size_t n);
 __global__ void k_fq12_one(i32* f);
-__global__ void k_final_exp_equal(const i32* a, const i32* b, i32* ok);
 __global__ void k_debug_fq12(int op, const u64* a, const u64* b, u64* out, size_t n);
 // k_pairing_pair.hip
 __global__ void k_debug_pairl(int op, const u64* a, const u64* b, u64* out, size_t n);
@@ -67,6 +68,7 @@ __global__ void k_hash_g2_redo(const u8* msgs, const u64* off, const u8* good, u
 __global__ void k_tai_g2_wave(const u8* msgs32, const u8* domain, u8* pts, size_t n);
 __global__ void k_hash_g2_domain_redo(const u8* msgs32, const u8* domain, const u8* good, u8* out, size_t n);
 __global__ void k_write_generators(u8* g1, u8* g2);
+// k_wire.hip
 __global__ void k_g1_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);
 __global__ void k_g1_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* err, size_t n);
 __global__ void k_g2_decompress(const u8* in, int check, u8* out, u8* out_inf, u8* err, size_t n);

@@ -4,7 +4,7 @@ import os
 import re
 
 D = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls_amd", "csrc")
-FILES = ["k_pairing_single.hip", "k_fe_single.hip", "k_pairing_pair.hip", "pair_kernels.inc", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_lat.hip", "k_hash.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "msm.inc"]
+FILES = ["k_pairing_single.hip", "k_fe_single.hip", "k_fq12_single.hip", "k_pairing_pair.hip", "pair_kernels.inc", "k_pairing_quad.hip", "k_prepared_pair.hip", "k_lat.hip", "k_hash.hip", "k_wire.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "msm.inc"]
 PAT = re.compile(r"^(KERNEL2|KERNEL_PAIR|KERNEL_QUAD|KERNEL_LAT|KERNEL|__global__ void __launch_bounds__\([^)]*\))\s+(k_\w+)\(([^)]*)\)\s*\{", re.M)
 
 out = """// kernels.h -- declarations of the kernels defined in the k_*.hip translation units, for the host side (blsmi.hip).
