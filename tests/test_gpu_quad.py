@@ -106,3 +106,15 @@ def test_quad_layout_at_its_design_size(eng):
     assert bad.size == 0, bad[:8]
     for i in (0, 1, 15, 16, 4097, n - 17, n - 1):
         assert np.array_equal(got[i], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]), i
+
+
+def test_soak_slice_three_layouts_two_limb_representations():
+    """a 20-second slice of tools/soak6.py: random batch sizes, special scalars, points outside the subgroup and corrupted verify tuples
+    through the wave (15 x 27-bit limbs), quad and pair (14 x 28-bit) paths -- same Fq12 bits, same verdicts, samples against the oracle"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["SOAK_SEED"] = "4242"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak6.py"), "20"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "representations agree" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
