@@ -832,6 +832,7 @@ def flat12(f):
 
 
 BUF_RAW3 = 8       # LOAD: element e of the raw device representation (15 int32 limbs, structure-of-arrays with n = 1) at buffer 3
+BUF_RAW2 = 14      # LOAD: the same at buffer 2
 BUF_M384_0 = 9     # LOAD: element e of the Fq wire format (6 little-endian uint64, Montgomery 2^384) at buffer 0
 BUF_SOA3 = 10      # LOAD: coordinate e of Jacobian record w of a structure-of-arrays buffer of `stride` records (buffer 3, stride = its
                    # stride argument): element = e | w << 3 | (1 << 11 for 6-coordinate records), w < 256; a record flagged infinite reads as (0, 1, 0)
@@ -862,6 +863,7 @@ def build_program(kind):
              'pairing1' -- inputs P (buf 0), Q (buf 1); output FE(ML(P, Q)) as 12 Fq
              'aggtail'  -- the tail of VerifyAggregate: P (buf 0), Q (buf 1) and an Fq12 R in the device representation (buf 3);
                            verdict = FE(ML(-P, Q) * R) == 1, i.e. e(P, Q) == FE(R) with ONE final exponentiation
+             'aggtail2' / 'miller1rawn' -- that tail in two pieces (see below)
              'finalexp1' -- input an Fq12 in the wire format (buf 0); output FE(f) as 12 Fq (pairing.go:79-129)
              'miller1raw' -- inputs P (buf 0), Q (buf 1); output a Miller value of (P, Q) in the device representation
              'miller1x' -- inputs P (buf 0), Q (buf 1); output MillerLoop(P, Q), the reference's value (pairing.go:16-75), as 12 Fq"""
@@ -885,10 +887,19 @@ def build_program(kind):
         f = pr.final_exp(pr.T.mul12(pr.miller([(P, Qa)]), R))
         b.out = ("check1", flat12(pr.T.lin12(f, True)))
         return b
-    if kind == "miller1raw":
+    if kind == "aggtail2":
+        # the same verdict with the signature side's Miller loop taken out: S = a Miller value of (-P, Q) (program 'miller1rawn', run on a
+        # side stream WHILE the tuple side is hashed and paired), R as above: verdict = FE(R * S) == 1
+        R = pr.T.lin12(unflat12([b.inp(BUF_RAW3, e) for e in range(12)]), True)
+        Sv = pr.T.lin12(unflat12([b.inp(BUF_RAW2, e) for e in range(12)]), True)
+        f = pr.final_exp(pr.T.mul12(R, Sv))
+        b.out = ("check1", flat12(pr.T.lin12(f, True)))
+        return b
+    if kind in ("miller1raw", "miller1rawn"):
         # MillerLoop(P, Q) for the product tree of VerifyAggregate, left in the device representation.  Its value differs from
         # the reference's Miller value by a factor in Fq2* (projective lines), which every final exponentiation downstream removes.
-        P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        # 'miller1rawn': of (-P, Q), the signature side of the aggregate's comparison
+        P = (b.inp(0, 0), b.inp(0, 1) if kind == "miller1raw" else -b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         b.out = ("outraw12", flat12(pr.T.lin12(pr.miller([(P, Qa)]), True)))
         return b
     if kind == "miller1x":
@@ -1340,7 +1351,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "finalexp1", "miller1raw", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
+    for name in ("verify2", "pairing1", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -198,8 +198,8 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             const u32 bsel = tx[0] & 15u, el = (tx[0] >> 4) & 0xfffu;
             FpS y = fp_zero();
             if (lane < njobs) {
-                if (bsel == 8) {                                                   // device representation: raw limbs, SoA with n = 1, at buffer 3
-                    const i32* raw = reinterpret_cast<const i32*>(b3 + s3 * t) + el * NL;
+                if (bsel == 8 || bsel == 14) {                                     // device representation: raw limbs, SoA with n = 1, at buffer 3 (8) / buffer 2 (14)
+                    const i32* raw = reinterpret_cast<const i32*>(bsel == 8 ? b3 + s3 * t : b2 + s2 * t) + el * NL;
 #pragma unroll
                     for (int i = 0; i < NL; i++) y.v[i] = raw[i];
                 } else if (bsel == 12 || bsel == 13) {                              // a coordinate of a projective point: 12 = from the affine wire format, 13 = SoA raw

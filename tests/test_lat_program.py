@@ -19,7 +19,7 @@ sys.setrecursionlimit(100000)
 
 @pytest.fixture(scope="module")
 def progs():
-    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "aggtail2", "miller1rawn", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
 
 
 def _pt(xs):
@@ -73,6 +73,11 @@ def test_final_exponentiation_and_aggregate_tail_programs(progs):
         R = P.miller_loop([(P.G1_GEN, P.g2_prepare(Q1))])
         inputs = dict(qin); inputs[G.BUF_RAW3] = P.fq12_flat(R)
         out = G.simulate(progs["aggtail"], inputs)
+        assert (out == [1] + [0] * 11) is want
+        # the tail in two pieces (one-context calls): S = a Miller value of (-P, Q) from the side stream, then FE(R * S) == 1
+        Sv = G.simulate(progs["miller1rawn"], qin)
+        assert P.fq12_flat(P.final_exponentiation(G.unflat12(Sv))) == P.fq12_flat(P.final_exponentiation(P.miller_loop([(P.affine_neg(P.F1, Pa), P.g2_prepare(Qa))])))
+        out = G.simulate(progs["aggtail2"], {G.BUF_RAW3: P.fq12_flat(R), G.BUF_RAW2: Sv})
         assert (out == [1] + [0] * 11) is want
 
 
