@@ -109,6 +109,27 @@ template <class F> BLSMI_DEV Jac<F> jac_add_i(const Jac<F>& g, const Jac<F>& o) 
 // for the pairing kernels, behind 3.5 TB/s of argument traffic).
 template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g) { return jac_double_i(g); }
 template <class F> __device__ __noinline__ Jac<F> jac_add_affine(const Jac<F>& g, const Aff<F>& o) { return jac_add_affine_i(g, o); }
+// acc += o for loops that add MANY points into one accumulator (the MSM's bucket pass): the same mixed addition with its special cases
+// (an infinite operand, equal x) BRANCHED out to the out-of-line function instead of selected at the end.  jac_add_affine_i keeps g, o
+// and r alive to its last line for those selects -- 112 of a G1 lane's registers before any temporary, 50 spilled in the bucket kernel
+// (6.3 GB of scratch written per 2^20-point MSM, rocprofv3 WRITE_SIZE) -- here every coordinate dies at its last use.  The rare path
+// is taken by whole lanes only when one of their operands is special.
+template <class F> BLSMI_DEV void jac_acc_affine(Jac<F>& g, const Aff<F>& o) {
+    const F z1z1 = f_store(f_sqr(g.z));
+    const F h = f_store(f_sub(f_mul(o.x, z1z1), g.x));
+    const F rr0 = f_store(f_sub(f_mul(f_mul(o.y, g.z), z1z1), g.y));
+    if (__builtin_expect((g.inf != 0) | (o.inf != 0) | f_is_zero(h), 0)) { g = jac_add_affine(g, o); return; }
+    const F hh = f_store(f_sqr(h));
+    const F z3 = f_store(f_sub(f_sub(f_sqr(f_add(g.z, h)), z1z1), hh));
+    const F i = f_store(f_muls<4>(hh));
+    const F j = f_store(f_mul(h, i));
+    const F v = f_store(f_mul(g.x, i));
+    const F yj = f_store(f_dbl(f_mul(g.y, j)));
+    const F rr = f_store(f_dbl(rr0));
+    g.z = z3;
+    g.x = f_store(f_sub(f_sub(f_sub(f_sqr(rr), j), v), v));
+    g.y = f_store(f_sub(f_mul(f_sub(v, g.x), rr), yj));
+}
 template <class F> __device__ __noinline__ Jac<F> jac_add(const Jac<F>& g, const Jac<F>& o) { return jac_add_i(g, o); }
 
 // g1.go:322-340 / g2.go:365-386
