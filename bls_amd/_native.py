@@ -26,7 +26,7 @@ _LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pa
 
 # rough compile cost in seconds (scheduling order only)
 _COST = {"k_fe_single.hip": 45, "k_hash.hip": 40, "k_curve.hip": 50, "k_pairing_quad.hip": 45, "k_pairing_single.hip": 40, "k_pairing_pair.hip": 32, "k_wire.hip": 30,
-         "k_fq12_single.hip": 30, "k_fe_pair.hip": 17, "k_hash_pair.hip": 17, "k_prepared_pair.hip": 16, "blsmi.hip": 5, "k_msm_pair.hip": 13, "k_lat.hip": 8, "k_util.hip": 7}
+         "k_fq12_single.hip": 30, "k_fe_pair.hip": 17, "k_hash_pair.hip": 17, "k_prepared_pair.hip": 16, "blsmi.hip": 5, "k_msm_pair.hip": 13, "k_lat.hip": 8, "k_util.hip": 20}
 
 
 def _unit_flags(u):

@@ -1139,12 +1139,14 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     DBuf raw, rec, hist, offs, cursor, idx, buckets, ch0, ch1, dmax, cls, perm;
     HIPCHK(raw.alloc(sizeof(i32) * RAWW * n, s)); HIPCHK(rec.alloc(32 * n, s));
     HIPCHK(hist.alloc(sizeof(u32) * nb, s)); HIPCHK(offs.alloc(sizeof(u32) * nb, s)); HIPCHK(cursor.alloc(sizeof(u32) * nb, s)); HIPCHK(dmax.alloc(sizeof(u32), s));
-    // one-pass scatter into fixed-capacity buckets (msm.inc: k_msm_scatter_cap); BLSMI_MSM_CAP=0 keeps the exact histogram + scan + scatter
-    static const bool cap_mode = []{ const char* v = getenv("BLSMI_MSM_CAP"); return !(v && v[0] == '0'); }();
-    const size_t mean = (per_win_items + B1 - 1) / B1;
-    // three times the mean: the top window of a 127-bit sub-scalar has only 2^15 digit values, i.e. twice the mean in half of its buckets
-    const u32 cap = cap_mode && nb * (3 * mean + 32) < ((size_t)1 << 32) ? (u32)(3 * mean + 32) : 0;
-    HIPCHK(idx.alloc(sizeof(u32) * std::max(per_win_items * nbw, nb * (size_t)cap), s)); HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
+    // grouping the 16 n items by bucket: a device radix sort (msm.inc: k_msm_items, k_util.hip); BLSMI_MSM_SORT=0 (read per call: the tests
+    // cross-check the two) takes the exact histogram + scan + atomic scatter instead
+    const bool sort_mode = []{ const char* v = getenv("BLSMI_MSM_SORT"); return !(v && v[0] == '0'); }();
+    const size_t nitems = (size_t)16 * n;
+    DBuf skey[2], sval[2];
+    if (sort_mode) { for (int i = 0; i < 2; i++) { HIPCHK(skey[i].alloc(sizeof(u32) * nitems, s)); HIPCHK(sval[i].alloc(sizeof(u32) * nitems, s)); } }
+    else HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s));
+    HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
     HIPCHK(ch0.alloc(sizeof(i32) * jw * 2 * nct, s)); HIPCHK(ch1.alloc(sizeof(i32) * jw * 2 * nct, s));   // the fold's arrays: at most 2 nct records on either side
     HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
     HIPCHK(hipMemsetAsync(hist.p, 0, sizeof(u32) * nb, s));
@@ -1155,8 +1157,8 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     else hipLaunchKernelGGL(k_msm_recode_g2, dim3(nblocks(n)), dim3(WG), 0, s, d_scalars, rec.as<u8>(), n);
     u32 biggest = 0;
     size_t slice_stride = per_win_items;                                   // a bucket's items: idx + (bucket >> 16) * slice_stride + offs[bucket]
-    auto exact_passes = [&](bool with_hist) -> int {
-        if (with_hist) {
+    auto exact_passes = [&]() -> int {
+        {
             prof_mark("k_msm_hist_glv");
             hipLaunchKernelGGL(k_msm_hist_glv, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, hist.as<u32>());
             prof_mark("k_msm_max");
@@ -1170,14 +1172,22 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
         slice_stride = per_win_items;
         return BLSMI_OK;
     };
-    if (cap) {
-        prof_mark("k_msm_scatter_cap");
-        hipLaunchKernelGGL(k_msm_scatter_cap, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, sh, cap, hist.as<u32>(), idx.as<u32>());
-        prof_mark("k_msm_max");
-        hipLaunchKernelGGL(k_msm_max_cap, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)hist.as<u32>(), nb, cap, offs.as<u32>(), dmax.as<u32>());
+    const u32* items = nullptr;                                            // the bucket pass reads items + (bucket >> 16) * slice_stride + offs[bucket]
+    if (sort_mode) {
+        prof_mark("k_msm_items");
+        hipLaunchKernelGGL(k_msm_items, dim3(nblocks(n)), dim3(WG), 0, s, (const u8*)rec.as<u8>(), n, nbw, sh, skey[0].as<u32>(), sval[0].as<u32>());
+        prof_mark("rocprim:radix_sort");
+        u32* kk[2] = {skey[0].as<u32>(), skey[1].as<u32>()}; u32* vv[2] = {sval[0].as<u32>(), sval[1].as<u32>()};
+        u32 *ks = nullptr, *vs = nullptr;
+        int bits = 17; while (((size_t)1 << bits) <= nb) bits++;            // buckets 0 .. nb - 1 and the sentinel nb
+        if (blsmi_util::sort_pairs_async(kk, vv, nitems, bits, s, [](size_t b) { return tl_ctx->arena.alloc(b); }, &ks, &vs) != 0) { (void)hipGetLastError(); return BLSMI_E_HIP; }
+        prof_mark("k_msm_runs");
+        HIPCHK(hipMemsetAsync(offs.p, 0, sizeof(u32) * nb, s)); HIPCHK(hipMemsetAsync(cursor.p, 0, sizeof(u32) * nb, s));
+        hipLaunchKernelGGL(k_msm_runs, dim3(nblocks(nitems)), dim3(WG), 0, s, (const u32*)ks, nitems, (u32)nb, offs.as<u32>(), cursor.as<u32>());
+        hipLaunchKernelGGL(k_msm_run_lengths, dim3(nblocks(nb)), dim3(WG), 0, s, (const u32*)offs.as<u32>(), (const u32*)cursor.as<u32>(), nb, hist.as<u32>(), dmax.as<u32>());
         HIPCHK(hipMemcpyAsync(&biggest, dmax.p, sizeof biggest, hipMemcpyDeviceToHost, s));
-        slice_stride = 0;
-    } else { const int rc = exact_passes(true); if (rc) return rc; }
+        items = vs; slice_stride = 0;
+    } else { const int rc = exact_passes(); if (rc) return rc; }
     prof_mark("k_msm_class_*");
     const unsigned cb = (unsigned)((nb + 255) / 256);
     hipLaunchKernelGGL(k_msm_class_hist, dim3(cb), dim3(256), 0, s, (const u32*)hist.as<u32>(), nb, cls.as<u32>());
@@ -1194,10 +1204,10 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     prof_mark(nullptr);
     HIPCHK(hipStreamSynchronize(s));
     if (biggest > 2048) return BLSMI_E_SKEW;
-    if (cap && biggest > cap) { const int rc = exact_passes(false); if (rc) return rc; }   // a bucket outgrew its slots (the counts are exact all the same): the two exact passes
+    if (!sort_mode) items = idx.as<u32>();
     prof_mark(W == 3 ? "k_g1_msm_bucket_raw" : "k_g2_msm_bucket_raw_pair");
-    if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), slice_stride, nb);
-    else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), (const u32*)idx.as<u32>(), (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), slice_stride, nb);
+    if (W == 3) hipLaunchKernelGGL(k_g1_msm_bucket_raw, dim3(nblocks(nb)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), items, (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), slice_stride, nb);
+    else hipLaunchKernelGGL(k_g2_msm_bucket_raw_pair, dim3((unsigned)((nb + PT - 1) / PT)), dim3(WG), 0, s, (const i32*)raw.as<i32>(), items, (const u32*)offs.as<u32>(), (const u32*)hist.as<u32>(), (const u32*)perm.as<u32>(), buckets.as<i32>(), slice_stride, nb);
     // running sums per chunk WITHOUT the per-lane multiplication, then the fold that carries the odd-element sums along (msm.inc):
     // one addition deep per level; out come, per window, X, L and O_0 .. O_{m-1}
     const bool pairk = W == 6 && g_pair_layout;                            // G2: a lane pair per chunk / per sum, two waves per SIMD

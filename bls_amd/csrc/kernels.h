@@ -138,8 +138,9 @@ __global__ void k_msm_recode_g2(const u8* scalars, u8* rec, size_t n);
 __global__ void k_msm_rawpts_g2(const u8* pts, i32* raw, size_t n);
 __global__ void k_msm_hist_glv(const u8* rec, size_t n, int nbw, u32* hist);
 __global__ void k_msm_scatter_glv(const u8* rec, size_t n, int nbw, int sh, u32* cursor, u32* idx);
-__global__ void k_msm_scatter_cap(const u8* rec, size_t n, int nbw, int sh, u32 cap, u32* count, u32* idx);
-__global__ void k_msm_max_cap(const u32* count, size_t nb, u32 cap, u32* offs, u32* out);
+__global__ void k_msm_items(const u8* rec, size_t n, int nbw, int sh, u32* keys, u32* items);
+__global__ void k_msm_runs(const u32* keys, size_t m, u32 nb, u32* first, u32* last);
+__global__ void k_msm_run_lengths(const u32* first, const u32* last, size_t nb, u32* hist, u32* out);
 __global__ void k_g1_msm_bucket_raw(const i32* raw, const u32* idx, const u32* offs, const u32* hist, const u32* perm, i32* buckets, size_t per_win, size_t nb);
 __global__ void k_g1_msm_chunk2(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct);
 __global__ void k_g2_msm_chunk2(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct);

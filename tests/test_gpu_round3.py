@@ -503,11 +503,12 @@ def test_device_duplicate_table_and_its_fallback(force):
 
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
-def test_msm_bucket_overflowing_its_slots_takes_the_exact_passes(group):
-    """The one-pass scatter gives every bucket three times the mean population + 32 slots (n = 2^17: 44 for G1, 56 for G2); 300 EQUAL scalars put 300
-    items into the same bucket of every window -- beyond its slots, below the skew limit of 2 048 -- so the call must go through the exact
-    histogram + scan + scatter.  Same point as the oracle gives through the scalar identity."""
+def test_msm_with_a_crowded_bucket_on_both_grouping_paths(group):
+    """The MSM groups its 16 n (bucket, point) items with a device radix sort (default) or, with BLSMI_MSM_SORT=0, with the exact histogram + scan +
+    atomic scatter.  300 EQUAL scalars put 300 items into the same bucket of every window (mean population 4 at n = 2^17; below the skew limit of
+    2 048): both paths must give the point the oracle gives through the scalar identity."""
     from bls_amd import engine as eng
+    import ctypes
     eng.init(0)
     n = 1 << 17
     rng = np.random.default_rng(56)
@@ -518,21 +519,27 @@ def test_msm_bucket_overflowing_its_slots_takes_the_exact_passes(group):
     gen = RC.g1_generator() if group == "g1" else RC.g2_generator()
     bpts, _ = (eng.g1_mul_batch if group == "g1" else eng.g2_mul_batch)(gen * base, bk.reshape(-1), base)
     pts = np.tile(bpts, (n // base, 1))
-    lib = eng._lib()
-    lib.blsmi_set_profiling(1)
-    got = (eng.g1_msm if group == "g1" else eng.g2_msm)(pts.reshape(-1), k.reshape(-1), n)
-    import ctypes
-    buf = ctypes.create_string_buffer(8192)
-    lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
-    names = buf.value.decode()
-    if os.environ.get("BLSMI_MSM_CAP", "1") != "0":
-        assert "k_msm_scatter_cap" in names and "k_msm_scatter_glv" in names and "k_msm_scan" in names, names   # the one-pass scatter ran, then the exact passes
     acc = 0
     kk = k.reshape(n // base, base, 32)
     for j in range(base):
         col = sum(int.from_bytes(kk[i, j].tobytes(), "big") for i in range(n // base))
         acc = (acc + int.from_bytes(bk[j].tobytes(), "big") * col) % P.R_ORDER
-    assert got == (RC.g1_mul if group == "g1" else RC.g2_mul)(gen, acc.to_bytes(32, "big"))
+    want = (RC.g1_mul if group == "g1" else RC.g2_mul)(gen, acc.to_bytes(32, "big"))
+    lib = eng._lib()
+    saved = os.environ.get("BLSMI_MSM_SORT")
+    try:
+        for mode, marks in (("1", ("rocprim:radix_sort", "k_msm_runs")), ("0", ("k_msm_hist_glv", "k_msm_scan", "k_msm_scatter_glv"))):
+            os.environ["BLSMI_MSM_SORT"] = mode                                # read per call (blsmi.hip: msm_bucket_glv_dev)
+            lib.blsmi_set_profiling(1)
+            got = (eng.g1_msm if group == "g1" else eng.g2_msm)(pts.reshape(-1), k.reshape(-1), n)
+            buf = ctypes.create_string_buffer(8192)
+            lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
+            names = buf.value.decode()
+            assert all(m in names for m in marks), (mode, names)
+            assert got == want, mode
+    finally:
+        if saved is None: os.environ.pop("BLSMI_MSM_SORT", None)
+        else: os.environ["BLSMI_MSM_SORT"] = saved
 
 
 def test_page_locked_host_buffers(eng):
