@@ -86,7 +86,10 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_fold_pair(const i32* src, i32*
     if (t0 < total) pair_soa_store(dst, half * nwin, t, par, r);
 }
 // lane-pair forms of the multiplication-free running-sum pass and of its fold (msm.inc)
-__global__ void __launch_bounds__(WG, 2) k_g2_msm_chunk2_pair(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct) {
+#ifndef BLSMI_CHUNK_WAVES
+#define BLSMI_CHUNK_WAVES 1         // 2^15 chunk pairs = 1 024 waves: one per SIMD anyway, so the whole register file (msm.inc: k_g1_msm_chunk2)
+#endif
+__global__ void __launch_bounds__(WG, BLSMI_CHUNK_WAVES) k_g2_msm_chunk2_pair(const i32* buckets, i32* out, int c, int K, size_t nb, size_t nct) {
     const int par = threadIdx.x & 1;
     const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
     const size_t t = t0 < nct ? t0 : nct - 1;
