@@ -918,6 +918,14 @@ def build_program(kind):
         f = unflat12([b.inp(BUF_M384_0, e) for e in range(12)])
         b.out = ("out12", flat12(pr.T.lin12(pr.final_exp(f), True)))
         return b
+    if kind == "verify1s":
+        # Verify with the signature side's Miller loop taken out (small calls: it runs on a side stream while the message is hashed, program
+        # 'miller1rawn'): inputs P0 (buf 0), Q0 (buf 1) and S = a Miller value of (-P1, Q1), record t of the SoA buffer 3; verdict = FE(ML(P0, Q0) * S) == 1
+        P0 = (b.inp(0, 0), b.inp(0, 1)); Q0 = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
+        Sv = pr.T.lin12(unflat12([b.inp(BUF_SOA12, e) for e in range(12)]), True)
+        f = pr.final_exp(pr.T.mul12(pr.miller([(P0, Q0)]), Sv))
+        b.out = ("check1", flat12(pr.T.lin12(f, True)))
+        return b
     if kind == "verify2":
         P0 = (b.inp(0, 0), b.inp(0, 1)); Q0 = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         P1 = (b.inp(2, 0), -b.inp(2, 1)); Q1 = ((b.inp(3, 0), b.inp(3, 1)), (b.inp(3, 2), b.inp(3, 3)))
@@ -1351,7 +1359,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "pairing1", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
+    for name in ("verify2", "verify1s", "pairing1", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -203,3 +203,47 @@ def test_verify_aggregate_common_with_resident_keys(eng):
             assert eng.verify_aggregate_common_dev(group, d_k.data_ptr(), nk, m32, aggd, domain=bytes(8)) is False
             if nk <= 8:
                 assert RC.g1pubs.verify_aggregate_common_with_domain(aggd, pks, m32, dom) is True
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_small_verify_calls_with_the_signature_side_on_a_side_stream(eng, group):
+    """Calls of up to 64 tuples run the signature side's Miller loop on a side stream beside the hash (programs miller1rawn + verify1s), larger
+    latency-path calls the two-pair program (verify2): the verdict table of g2pubs/bls.go:159-162 / g1pubs/bls.go:165-168 -- wrong message, wrong
+    key, negated signature, flagged and all-zero (infinity) records -- is the oracle's on both sides of the boundary, from host buffers and
+    from resident ones, and a call's profile names the program it took."""
+    import ctypes
+    import torch
+    from test_gpu_verify import _tuples
+    msgs, pks, sigs, expect = _tuples(group, 66, 77)
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    for i in (0, 3, 7, 11):
+        assert o.verify(msgs[i], pks[i], sigs[i]) == expect[i]
+    fn = eng.g2pubs_verify_batch if group == "g2pubs" else eng.g1pubs_verify_batch
+    sb = len(sigs[0])
+    lib = eng._lib()
+    for n, prog in ((1, "k_lat:verify1s"), (2, "k_lat:verify1s"), (64, "k_lat:verify1s"), (65, "k_lat:verify2"), (66, "k_lat:verify2")):
+        lib.blsmi_set_profiling(1)
+        ok, _ = fn(msgs[:n], b"".join(pks[:n]), b"".join(sigs[:n]))
+        buf = ctypes.create_string_buffer(4096); lib.blsmi_last_profile(buf, ctypes.c_size_t(4096)); lib.blsmi_set_profiling(0)
+        assert prog in buf.value.decode(), (n, buf.value)
+        assert list(ok) == expect[:n], n
+        # a flagged tuple, and a signature given as the all-zero record: verdict 0, the neighbours keep theirs
+        flags = [0] * n; flags[0] = 2
+        s2 = list(sigs[:n])
+        if n > 1: s2[1] = bytes(sb)
+        ok, _ = fn(msgs[:n], b"".join(pks[:n]), b"".join(s2), flags)
+        assert not ok[0] and (n == 1 or not ok[1]) and list(ok[2:]) == expect[2:n], n
+    # resident inputs on the caller's own stream (the side stream waits for that stream's work on the signatures)
+    dev = torch.device("cuda", 0)
+    for n in (5, 64, 65):
+        mbuf, moff = eng._msgs(msgs[:n])
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            d_m = torch.from_numpy(mbuf.copy()).to(dev, non_blocking=True)
+            d_o = torch.from_numpy(moff.view(np.int64).copy()).to(dev, non_blocking=True)
+            d_p = torch.from_numpy(np.frombuffer(b"".join(pks[:n]), dtype=np.uint8).copy()).to(dev, non_blocking=True)
+            d_s = torch.from_numpy(np.frombuffer(b"".join(sigs[:n]), dtype=np.uint8).copy()).to(dev, non_blocking=True)
+            d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+            eng.verify_batch_dev(group, d_m.data_ptr(), d_o.data_ptr(), d_p.data_ptr(), d_s.data_ptr(), 0, d_ok.data_ptr(), n, stream=st.cuda_stream)
+        st.synchronize()
+        assert [bool(x) for x in d_ok.cpu().tolist()] == expect[:n], n

@@ -19,7 +19,7 @@ sys.setrecursionlimit(100000)
 
 @pytest.fixture(scope="module")
 def progs():
-    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "aggtail", "aggtail2", "miller1rawn", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "verify1s", "aggtail", "aggtail2", "miller1rawn", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
 
 
 def _pt(xs):
@@ -58,6 +58,11 @@ def test_verify_program_matches_compare_two_pairings(progs):
     Q1b = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, a + 1))
     f = P.final_exponentiation(P.miller_loop([(P0, P.g2_prepare(Q0)), (P.affine_neg(P.F1, P1), P.g2_prepare(Q1b))]))
     assert run(P0, Q0, P1, Q1b) == P.fq12_flat(f) != [1] + [0] * 11
+    # the same verdicts with the second pair's Miller loop run apart (programs miller1rawn + verify1s: small calls, side stream)
+    for q1, want in ((Q1, True), (Q1b, False)):
+        Sv = G.simulate(progs["miller1rawn"], {0: [P1[0], P1[1]], 1: [q1[0][0], q1[0][1], q1[1][0], q1[1][1]]})
+        out = G.simulate(progs["verify1s"], {0: [P0[0], P0[1]], 1: [Q0[0][0], Q0[0][1], Q0[1][0], Q0[1][1]], G.BUF_SOA12: Sv})
+        assert (out == [1] + [0] * 11) is want
 
 
 def test_final_exponentiation_and_aggregate_tail_programs(progs):
