@@ -207,7 +207,7 @@ def test_verify_aggregate_common_with_resident_keys(eng):
 
 @pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
 def test_small_verify_calls_with_the_signature_side_on_a_side_stream(eng, group):
-    """Calls of up to 64 tuples run the signature side's Miller loop on a side stream beside the hash (programs miller1rawn + verify1s), larger
+    """Calls of up to 48 (g2pubs) / 320 (g1pubs) tuples run the signature side's Miller loop on a side stream beside the hash (programs miller1rawn + verify1s), larger
     latency-path calls the two-pair program (verify2): the verdict table of g2pubs/bls.go:159-162 / g1pubs/bls.go:165-168 -- wrong message, wrong
     key, negated signature, flagged and all-zero (infinity) records -- is the oracle's on both sides of the boundary, from host buffers and
     from resident ones, and a call's profile names the program it took."""
@@ -221,7 +221,13 @@ def test_small_verify_calls_with_the_signature_side_on_a_side_stream(eng, group)
     fn = eng.g2pubs_verify_batch if group == "g2pubs" else eng.g1pubs_verify_batch
     sb = len(sigs[0])
     lib = eng._lib()
-    for n, prog in ((1, "k_lat:verify1s"), (2, "k_lat:verify1s"), (64, "k_lat:verify1s"), (65, "k_lat:verify2"), (66, "k_lat:verify2")):
+    lim = 48 if group == "g2pubs" else 320
+    big = _tuples(group, 322, 78) if group == "g1pubs" else None
+    cases = [(1, "k_lat:verify1s"), (2, "k_lat:verify1s"), (48, "k_lat:verify1s"), (49 if lim == 48 else 66, "k_lat:verify2" if lim == 48 else "k_lat:verify1s")]
+    if big:
+        got, _ = fn(big[0][:320], b"".join(big[1][:320]), b"".join(big[2][:320])); assert list(got) == big[3][:320]
+        got, _ = fn(big[0][:321], b"".join(big[1][:321]), b"".join(big[2][:321])); assert list(got) == big[3][:321]
+    for n, prog in cases:
         lib.blsmi_set_profiling(1)
         ok, _ = fn(msgs[:n], b"".join(pks[:n]), b"".join(sigs[:n]))
         buf = ctypes.create_string_buffer(4096); lib.blsmi_last_profile(buf, ctypes.c_size_t(4096)); lib.blsmi_set_profiling(0)
@@ -235,7 +241,7 @@ def test_small_verify_calls_with_the_signature_side_on_a_side_stream(eng, group)
         assert not ok[0] and (n == 1 or not ok[1]) and list(ok[2:]) == expect[2:n], n
     # resident inputs on the caller's own stream (the side stream waits for that stream's work on the signatures)
     dev = torch.device("cuda", 0)
-    for n in (5, 64, 65):
+    for n in (5, 48, 49, 66):
         mbuf, moff = eng._msgs(msgs[:n])
         st = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(st):
