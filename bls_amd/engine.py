@@ -468,6 +468,34 @@ def hash_g2_with_domain_batch(msgs32, domain8):
     return out
 
 
+# ---- sign: sk_i * H(m_i) in one call (the hash points stay on the device) ---------------------------
+def _sign(fn, name, ob, n, head, sks):
+    k = _u8(sks, 32 * n)
+    out = np.zeros((n, ob), dtype=np.uint8); inf = np.zeros(n, dtype=np.uint8)
+    _check(fn(*head, _p8(k), _p8(out.reshape(-1)), _p8(inf), C.c_size_t(n)), name)
+    return out, inf
+
+
+def g2pubs_sign_batch(msgs, sks):
+    """blsmi_g2pubs_sign_batch: n x 96-byte signatures sk_i * HashG1(m_i) (g2pubs/bls.go:132-135) and their infinity flags"""
+    buf, off = _msgs(msgs)
+    return _sign(_lib().blsmi_g2pubs_sign_batch, "blsmi_g2pubs_sign_batch", 96, len(msgs), (_p8(buf), off.ctypes.data_as(_u64p)), sks)
+
+
+def g1pubs_sign_batch(msgs, sks):
+    """blsmi_g1pubs_sign_batch: n x 192-byte signatures sk_i * HashG2(m_i) (g1pubs/bls.go:132-135)"""
+    buf, off = _msgs(msgs)
+    return _sign(_lib().blsmi_g1pubs_sign_batch, "blsmi_g1pubs_sign_batch", 192, len(msgs), (_p8(buf), off.ctypes.data_as(_u64p)), sks)
+
+
+def g1pubs_sign_with_domain_batch(msgs32, domain8, sks):
+    """blsmi_g1pubs_sign_with_domain_batch: sk_i * HashG2WithDomain(m_i, domain) (g1pubs/bls.go:138-141)"""
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n)
+    d = _u8(domain8, 8)
+    return _sign(_lib().blsmi_g1pubs_sign_with_domain_batch, "blsmi_g1pubs_sign_with_domain_batch", 192, n, (_p8(buf), _p8(d)), sks)
+
+
 # ---- verify ----------------------------------------------------------------------------------------
 def _verify_batch(fn, pkb, sgb, msgs, pks, sigs, inf_flags):
     n = len(msgs)

@@ -133,8 +133,7 @@ def PrivToPubBatch(secret_scalars):
 def SignBatch(msgs, secret_scalars):
     """sigma_i = sk_i * HashG2(m_i) (Sign, g1pubs/bls.go:132-135); scalars are 32-byte big-endian."""
     n = len(msgs)
-    h = engine.hash_g2_batch(msgs)
-    out, inf = engine.g2_mul_batch(h.reshape(-1), b"".join(secret_scalars), n)
+    out, inf = engine.g1pubs_sign_batch(msgs, b"".join(secret_scalars))    # one call: hash, then multiply, on the device
     return [Signature(Point(None if inf[i] else out[i].tobytes(), SIG_GROUP)) for i in range(n)]
 
 
@@ -166,6 +165,5 @@ def VerifyAggregateWithDomain(sig, pubKeys, msgs32, domain8):
 
 def SignWithDomainBatch(msgs32, secret_scalars, domain8):
     n = len(msgs32)
-    h = engine.hash_g2_with_domain_batch(msgs32, domain8)
-    out, inf = engine.g2_mul_batch(h.reshape(-1), b"".join(secret_scalars), n)
+    out, inf = engine.g1pubs_sign_with_domain_batch(msgs32, domain8, b"".join(secret_scalars))
     return [Signature(Point(None if inf[i] else out[i].tobytes(), SIG_GROUP)) for i in range(n)]

@@ -163,6 +163,5 @@ def PrivToPubBatch(secret_scalars):
 def SignBatch(msgs, secret_scalars):
     """sigma_i = sk_i * HashG1(m_i) (Sign, g2pubs/bls.go:132-135); scalars are 32-byte big-endian."""
     n = len(msgs)
-    h = engine.hash_g1_batch(msgs)
-    out, inf = engine.g1_mul_batch(h.reshape(-1), b"".join(secret_scalars), n)
+    out, inf = engine.g2pubs_sign_batch(msgs, b"".join(secret_scalars))    # one call: hash, then multiply, on the device
     return [Signature(Point(None if inf[i] else out[i].tobytes(), SIG_GROUP)) for i in range(n)]

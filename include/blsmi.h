@@ -145,7 +145,7 @@ int blsmi_g2_mul_batch(const uint8_t *pts /* n*192 */, const uint8_t *scalars /*
  * level program has a fixed instruction sequence and complete group formulas but still addresses an LDS table by the
  * scalar's digits.  They exist to
  * generate and check test/bench inputs and for public scalars; secret keys belong on the upstream pure-Go module
- * (Sign / PrivToPub stay there in the Go shim). */
+ * (the one-tuple Sign / PrivToPub stay there in the Go shim). */
 int blsmi_g1_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
 int blsmi_g2_mul_generator_batch(const uint8_t *scalars /* n*32 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
 /* sum of n points (tree reduction on the device; equals the reference's sequential Jacobian sum
@@ -184,6 +184,17 @@ int blsmi_g2_msm_dev_ex(const void *d_pts, const void *d_scalars, size_t n, void
 int blsmi_hash_g1_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, uint8_t *out /* n*96 */, size_t n);
 int blsmi_hash_g2_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, uint8_t *out /* n*192 */, size_t n);
 int blsmi_hash_g2_with_domain_batch(const uint8_t *msgs32 /* n*32 */, const uint8_t domain[8], uint8_t *out /* n*192 */, size_t n);
+
+/* ---- Sign for n (message, secret key) pairs in one call: sig_i = sk_i * H(msg_i) (g2pubs/bls.go:132-135; g1pubs/bls.go:132-135,
+ * SignWithDomain :138-141): the hash points stay on the device between the two steps.  sks: n*32 bytes, big-endian scalars (FR as
+ * the Go API serialises it); out_inf[i] = 1 when sk_i = 0 mod r (the signature is the point at infinity, written as the all-zero
+ * record).  Like the scalar multiplications above these are NOT side-channel hardened, and the secret scalars cross the PCIe bus and
+ * live in a device temporary for the duration of the call: bulk signing of test / bench inputs and of keys that may leave the host
+ * (the shim's SignBatch); a deployment that must keep its keys in host memory stays on the upstream Sign, and
+ * blsmi_prefer_cpu(BLSMI_SHAPE_SIGN, n) says when a small call is faster there anyway. */
+int blsmi_g2pubs_sign_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, const uint8_t *sks /* n*32 */, uint8_t *out_sigs /* n*96 */, uint8_t *out_inf /* n */, size_t n);
+int blsmi_g1pubs_sign_batch(const uint8_t *msgs, const uint64_t *off /* n+1 */, const uint8_t *sks /* n*32 */, uint8_t *out_sigs /* n*192 */, uint8_t *out_inf /* n */, size_t n);
+int blsmi_g1pubs_sign_with_domain_batch(const uint8_t *msgs32 /* n*32 */, const uint8_t domain[8], const uint8_t *sks /* n*32 */, uint8_t *out_sigs /* n*192 */, uint8_t *out_inf /* n */, size_t n);
 
 /* ---- g2pubs: PublicKey in G2 (192 B affine), Signature in G1 (96 B affine), H: msg -> G1 ------
  * verify_batch: ok[i] = g2pubs.Verify(msg_i, pk_i, sig_i) (g2pubs/bls.go:159-162) as one byte per

@@ -17,7 +17,11 @@ package g1pubs
 */
 import "C"
 
-import "unsafe"
+import (
+	"unsafe"
+
+	"github.com/phoreproject/bls"
+)
 
 func init() {
 	if rc := C.blsmi_init_devices(0); rc != 0 {
@@ -203,4 +207,75 @@ func VerifySerializedBatch(msgs [][]byte, pubs [][48]byte, sigs [][96]byte) []bo
 		out[i] = ok[i] != 0
 	}
 	return out
+}
+
+// g2FromBytes rebuilds a G2 point from the 192 affine bytes the library returns (x.c0, x.c1, y.c0, y.c1, 48 bytes big-endian each:
+// G2Affine.SerializeBytes, g2.go:172-186).
+func g2FromBytes(b []byte) *bls.G2Affine {
+	var c [4][48]byte
+	for j := range c {
+		copy(c[j][:], b[48*j:48*j+48])
+	}
+	fq := func(x [48]byte) bls.FQ { return bls.FQReprToFQ(bls.FQReprFromBytes(x)) }
+	return bls.NewG2Affine(bls.NewFQ2(fq(c[0]), fq(c[1])), bls.NewFQ2(fq(c[2]), fq(c[3])))
+}
+
+func secretBytes(keys []*SecretKey) []byte {
+	sk := make([]byte, 0, 32*len(keys))
+	for i := range keys {
+		kb := keys[i].Serialize() // 32 bytes big-endian
+		sk = append(sk, kb[:]...)
+	}
+	return sk
+}
+
+func sigsFromBytes(sg, inf []byte) []*Signature {
+	out := make([]*Signature, len(inf))
+	for i := range out {
+		if inf[i] != 0 {
+			out[i] = NewSignatureFromG2(bls.G2AffineZero.Copy())
+		} else {
+			out[i] = NewSignatureFromG2(g2FromBytes(sg[192*i : 192*i+192]))
+		}
+	}
+	return out
+}
+
+// SignBatch is the batch form of Sign (g1pubs/bls.go:132-135): out[i] = keys[i] * HashG2(msgs[i]), one library call.  Small batches stay
+// on the upstream CPU path (blsmi_prefer_cpu); the secret scalars cross the PCIe bus otherwise.
+func SignBatch(msgs [][]byte, keys []*SecretKey) []*Signature {
+	n := len(msgs)
+	if n == 0 {
+		return nil
+	}
+	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_SIGN, C.size_t(n)) != 0 {
+		out := make([]*Signature, n)
+		for i := range msgs {
+			out[i] = Sign(msgs[i], keys[i])
+		}
+		return out
+	}
+	m, off := packMsgs(msgs)
+	sg := make([]byte, 192*n)
+	inf := make([]byte, n)
+	if rc := C.blsmi_g1pubs_sign_batch(u8(m), &off[0], u8(secretBytes(keys)), u8(sg), u8(inf), C.size_t(n)); rc != 0 {
+		panic("blsmi: g1pubs sign_batch failed")
+	}
+	return sigsFromBytes(sg, inf)
+}
+
+// SignWithDomainBatch: out[i] = SignWithDomain(msgs[i], keys[i], domain) (g1pubs/bls.go:138-141).
+func SignWithDomainBatch(msgs [][32]byte, keys []*SecretKey, domain [8]byte) []*Signature {
+	n := len(msgs)
+	if n == 0 {
+		return nil
+	}
+	sg := make([]byte, 192*n)
+	inf := make([]byte, n)
+	rc := C.blsmi_g1pubs_sign_with_domain_batch((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u8(secretBytes(keys)), u8(sg), u8(inf), C.size_t(n))
+	if rc != 0 {
+		panic("blsmi: g1pubs sign_with_domain_batch failed")
+	}
+	return sigsFromBytes(sg, inf)
 }

@@ -5,7 +5,7 @@
 // Drop this file into github.com/phoreproject/bls/g2pubs and build with `-tags blsmi`; the upstream
 // implementations of Verify, VerifyAggregate and VerifyAggregateCommon (g2pubs/bls.go:159-162, 240-270,
 // 275-278) move behind `// +build !blsmi`.  Everything else in bls.go (types, Sign, PrivToPub,
-// serialisation, the aggregation helpers) stays as it is.  The C prototypes are include/blsmi.h;
+// serialisation, the aggregation helpers) stays as it is; SignBatch below is an addition for bulk signing.  The C prototypes are include/blsmi.h;
 // tests/test_shim.py checks every C.blsmi_* call below against it (name and arity).
 package g2pubs
 
@@ -19,6 +19,8 @@ import "C"
 import (
 	"runtime"
 	"unsafe"
+
+	"github.com/phoreproject/bls"
 )
 
 func init() {
@@ -242,4 +244,43 @@ func Trim() uint64 {
 	var freed C.size_t
 	C.blsmi_trim(0, &freed)
 	return uint64(freed)
+}
+
+// SignBatch is the batch form of Sign (g2pubs/bls.go:132-135): out[i] = Sign(msgs[i], keys[i]) = keys[i] * HashG1(msgs[i]), one library
+// call for the n signatures (hash and multiplication both on the device).  The secret scalars cross the PCIe bus; a lone Sign is faster on
+// the upstream CPU path (blsmi_prefer_cpu), which is what this function takes for small n.
+func SignBatch(msgs [][]byte, keys []*SecretKey) []*Signature {
+	n := len(msgs)
+	out := make([]*Signature, n)
+	if n == 0 {
+		return out
+	}
+	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_SIGN, C.size_t(n)) != 0 {
+		for i := range msgs {
+			out[i] = Sign(msgs[i], keys[i])
+		}
+		return out
+	}
+	m, off := packMsgs(msgs)
+	sk := make([]byte, 0, 32*n)
+	for i := range keys {
+		kb := keys[i].Serialize() // g2pubs/bls.go:115-117: 32 bytes big-endian
+		sk = append(sk, kb[:]...)
+	}
+	sg := make([]byte, 96*n)
+	inf := make([]byte, n)
+	if rc := C.blsmi_g2pubs_sign_batch(u8(m), &off[0], u8(sk), u8(sg), u8(inf), C.size_t(n)); rc != 0 {
+		panic("blsmi: g2pubs sign_batch failed")
+	}
+	for i := range out {
+		if inf[i] != 0 {
+			out[i] = NewSignatureFromG1(bls.G1AffineZero.Copy())
+			continue
+		}
+		var xb, yb [48]byte
+		copy(xb[:], sg[96*i:96*i+48])
+		copy(yb[:], sg[96*i+48:96*i+96])
+		out[i] = NewSignatureFromG1(bls.NewG1Affine(bls.FQReprToFQ(bls.FQReprFromBytes(xb)), bls.FQReprToFQ(bls.FQReprFromBytes(yb))))
+	}
+	return out
 }

@@ -38,6 +38,14 @@ def main():
     h = eng.hash_g1_batch(packed)
     sigs, _ = eng.g1_mul_batch(h.reshape(-1), sk * (n // nk), n)
     agg = eng.g1_sum(sigs.reshape(-1), n)
+    # the fused Sign entry point over the same split batch (later shards rebase their message offsets): the two-step signatures, byte for byte;
+    # and with ragged messages against the oracle
+    fs, _ = eng.g2pubs_sign_batch(packed, sk * (n // nk))
+    ck["fused_sign_split_equals_hash_then_multiply"] = bool(np.array_equal(fs, sigs))
+    nr = 3 * 8192 + 77
+    ragged = [(b"r%d" % i) * (1 + i % 5) for i in range(nr)]
+    fr, _ = eng.g1pubs_sign_batch(ragged, (sk * (nr // nk + 1))[:32 * nr])
+    ck["fused_sign_ragged_split_oracle_rows"] = all(fr[i].tobytes() == RC.g1pubs.sign(ragged[i], sk[32 * (i % nk):32 * (i % nk) + 32]) for i in (0, 8191, 8192, 16500, nr - 1))
     allpk = np.ascontiguousarray(np.tile(pks, (n // nk, 1))).reshape(-1)
     l0 = leases()
     ck["aggregate_true"] = eng.g2pubs_verify_aggregate(packed, allpk, agg) is True

@@ -253,3 +253,42 @@ def test_small_verify_calls_with_the_signature_side_on_a_side_stream(eng, group)
             eng.verify_batch_dev(group, d_m.data_ptr(), d_o.data_ptr(), d_p.data_ptr(), d_s.data_ptr(), 0, d_ok.data_ptr(), n, stream=st.cuda_stream)
         st.synchronize()
         assert [bool(x) for x in d_ok.cpu().tolist()] == expect[:n], n
+
+
+def test_fused_sign_batches_match_the_oracle(eng):
+    """blsmi_g{2,1}pubs_sign_batch / sign_with_domain_batch: sig_i = sk_i * H(m_i) in ONE call (g2pubs/bls.go:132-135, g1pubs/bls.go:132-141) --
+    the reference's signatures byte for byte on the small-call path and on the throughput kernels, ragged and empty messages, the zero key
+    (signature at infinity, flagged), and every signature verifies under its PrivToPub key through the batch verify."""
+    xs = P.XORShift(907)
+    dom = bytes(range(8))
+    for n in (1, 5, 700):
+        sks = [sk_bytes(xs) for _ in range(n)]
+        msgs = [(b"m%d" % i) * (i % 7) for i in range(n)]                      # lengths 0, 2, 4, ... (message 0 is empty)
+        m32 = [bytes([i & 255, i >> 8]) * 16 for i in range(n)]
+        if n > 1:
+            sks[1] = bytes(32)                                                 # sk = 0: the point at infinity
+        s2, i2 = eng.g2pubs_sign_batch(msgs, b"".join(sks))
+        s1, i1 = eng.g1pubs_sign_batch(msgs, b"".join(sks))
+        sd, idm = eng.g1pubs_sign_with_domain_batch(m32, dom, b"".join(sks))
+        check = range(n) if n <= 5 else (0, 1, 2, 63, 64, 65, 333, n - 1)
+        for i in check:
+            zero = n > 1 and i == 1
+            assert bool(i2[i]) == zero and bool(i1[i]) == zero and bool(idm[i]) == zero, (n, i)
+            if zero:
+                assert not s2[i].any() and not s1[i].any() and not sd[i].any()
+                continue
+            assert s2[i].tobytes() == RC.g2pubs.sign(msgs[i], sks[i]), (n, i)
+            assert s1[i].tobytes() == RC.g1pubs.sign(msgs[i], sks[i]), (n, i)
+            assert sd[i].tobytes() == RC.g1pubs.sign_with_domain(m32[i], sks[i], dom), (n, i)
+        # every signature verifies under its own key (the whole batch; the zero key's tuple is rejected: infinity on both sides)
+        pk2, _ = eng.g2_mul_generator_batch(b"".join(sks), n)
+        ok, _ = eng.g2pubs_verify_batch(msgs, pk2.reshape(-1), s2.reshape(-1))
+        want = [not (n > 1 and i == 1) for i in range(n)]
+        assert [bool(x) for x in ok] == want
+        pk1, _ = eng.g1_mul_generator_batch(b"".join(sks), n)
+        ok = eng.g1pubs_verify_with_domain_batch(m32, dom, pk1.reshape(-1), sd.reshape(-1))
+        assert [bool(x) for x in ok] == want
+    # argument errors
+    lib = eng._lib()
+    assert lib.blsmi_g2pubs_sign_batch(None, None, None, None, None, 3) != 0
+    assert lib.blsmi_g2pubs_sign_batch(None, None, None, None, None, 0) == 0
