@@ -967,7 +967,7 @@ BLSMI_API int blsmi_g2_mul_batch_dev_ex(const void* d_pts, const void* d_scalars
 
 // tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
 template <int PB, int W, class K0, class K1, class K2>
-static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, size_t n, u8* d_out, i32* d_out_inf, hipStream_t s) {
+static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, size_t n, u8* d_out, i32* d_out_inf, hipStream_t s, bool sync = true) {
     const size_t words = (size_t)W * NL + 1;
     size_t half = (n + 1) / 2;
     DBuf b0, b1;
@@ -995,7 +995,7 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
         hipLaunchKernelGGL(k_good_to_flag, dim3(1), dim3(WG), 0, s, (const u8*)good.as<u8>(), d_out_inf);
         prof_mark(nullptr);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s));
+        if (sync) HIPCHK(hipStreamSynchronize(s));                        // (the temporaries live in the call's arena: an unsynchronised caller orders its own readers)
         return BLSMI_OK;
     }
     prof_mark(W == 3 ? "k_g1_sum0" : "k_g2_sum0");
@@ -1013,7 +1013,7 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
     hipLaunchKernelGGL(kfinal, dim3(1), dim3(WG), 0, s, (const i32*)src, d_out, d_out_inf);
     prof_mark(nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
+    if (sync) HIPCHK(hipStreamSynchronize(s));
     return BLSMI_OK;
 }
 template <int PB, int W, class K0, class K1, class K2>

@@ -131,6 +131,8 @@ KERNEL k_flag_zero_records(const u8* pks, int pk_words, const u8* sigs, int sig_
 }
 // verdict bytes -> bits, LSB first: bitmap[b] holds tuples 8b .. 8b+7 (the layout of the bitmap all-reduce; `bitmap` points
 // at this shard's first byte, shards start on multiples of 8 tuples)
+// an int32 infinity flag (the sums' verdict) as the flag byte of a one-tuple verify
+KERNEL k_flag_to_byte(const i32* flag, u8* out) { if (blockIdx.x == 0 && threadIdx.x == 0) *out = *flag ? 1 : 0; }
 KERNEL k_pack_bitmap(const u8* ok, u8* bitmap, size_t n) {
     const size_t b = (size_t)blockIdx.x * WG + threadIdx.x;
     if (8 * b >= n) return;

@@ -76,6 +76,7 @@ __global__ void k_g2_decompress_waves(const u8* in, u8* out, u8* out_inf, u8* er
 __global__ void k_apply_subgroup(const u8* in_subgroup, u8* out, int rec_words, const u8* out_inf, u8* err, size_t n);
 __global__ void k_merge_flags(const u8* inf_pk, const u8* err_pk, const u8* inf_sig, const u8* err_sig, u8* flags, size_t n);
 __global__ void k_flag_zero_records(const u8* pks, int pk_words, const u8* sigs, int sig_words, const u8* in_flags, u8* flags, int* any, size_t n);
+__global__ void k_flag_to_byte(const i32* flag, u8* out);
 __global__ void k_pack_bitmap(const u8* ok, u8* bitmap, size_t n);
 __global__ void k_g1_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
 __global__ void k_g2_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
