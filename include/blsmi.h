@@ -104,7 +104,7 @@ int blsmi_set_latency_threshold(size_t max_tuples);
  * Same results bit for bit on all three paths. */
 int blsmi_set_quad_threshold(size_t max_tuples);
 /* When should a lone call stay on the upstream CPU path?  A call with few elements costs the dependent depth of ONE wave walking the
- * whole computation -- about 0.7 ms for a Miller loop, 1.4 ms for a pairing, a signature or a G2 preparation, 2.2 ms for a Verify --
+ * whole computation -- about 0.7 ms for a Miller loop, 1.4 ms for a pairing, a signature or a G2 preparation, 2.0 ms for a Verify --
  * whatever n is, up to a few thousand elements.  Where one CPU core needs less than that for the whole call (BLSSign 0.45 ms,
  * G2AffineToPrepared 0.19 ms, a Jacobian addition 6.5 us: bench.py `reference_shapes`), the shim should not cross the boundary.
  * blsmi_prefer_cpu(shape, n) returns 1 in exactly those cases (n * cpu time per operation < device latency of a lone call), else 0:
