@@ -47,10 +47,11 @@ __global__ void __launch_bounds__(WG, 2) k_g2_msm_bucket_raw_pair(const i32* raw
     const size_t t = perm[jj];
     const u32 cnt = j < nb ? hist[t] : 0;
     const u32* slice = idx + (t >> 16) * per_win + offs[t];
-    P2::G2JacP acc = jac_zero<P2::Fp2S>();
+    Xyzz<P2::Fp2S> xacc = xyzz_zero<P2::Fp2S>();
     // (no software prefetch here: with the gathers served from cache the kernel is 5 % faster at most -- issue-bound -- and the 28 registers of
     // a pending point bring 27 spills back)
-    for (u32 k = 0; k < cnt; k++) jac_acc_affine(acc, raw_item_g2_pair(raw, slice[k], par));          // inlined, special cases branched out: no spills
+    for (u32 k = 0; k < cnt; k++) xyzz_acc_affine(xacc, raw_item_g2_pair(raw, slice[k], par));        // XYZZ accumulator (curve.cuh), inlined, special cases branched out
+    const P2::G2JacP acc = xyzz_to_jac(xacc);
     if (j < nb) {
         soa_store(buckets, nb, t, 0 + par, acc.x.c); soa_store(buckets, nb, t, 2 + par, acc.y.c); soa_store(buckets, nb, t, 4 + par, acc.z.c);
         if (!par) buckets[(size_t)6 * NL * nb + t] = acc.inf;
