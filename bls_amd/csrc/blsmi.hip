@@ -1141,8 +1141,8 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     HIPCHK(hist.alloc(sizeof(u32) * nb, s)); HIPCHK(offs.alloc(sizeof(u32) * nb, s)); HIPCHK(cursor.alloc(sizeof(u32) * nb, s)); HIPCHK(dmax.alloc(sizeof(u32), s));
     // grouping the 16 n items by bucket: a device radix sort (msm.inc: k_msm_items, k_util.hip); BLSMI_MSM_SORT=0 (read per call: the tests
     // cross-check the two) takes the exact histogram + scan + atomic scatter instead
-    const bool sort_mode = []{ const char* v = getenv("BLSMI_MSM_SORT"); return !(v && v[0] == '0'); }();
     const size_t nitems = (size_t)16 * n;
+    const bool sort_mode = nitems < ((size_t)1 << 31) && []{ const char* v = getenv("BLSMI_MSM_SORT"); return !(v && v[0] == '0'); }();   // (the sort counts its items in an int: 2^27 points and beyond take the exact passes)
     DBuf skey[2], sval[2];
     if (sort_mode) { for (int i = 0; i < 2; i++) { HIPCHK(skey[i].alloc(sizeof(u32) * nitems, s)); HIPCHK(sval[i].alloc(sizeof(u32) * nitems, s)); } }
     else HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s));
