@@ -907,6 +907,19 @@ def build_program(kind):
         P = (b.inp(0, 0), b.inp(0, 1)); Qa = ((b.inp(1, 0), b.inp(1, 1)), (b.inp(1, 2), b.inp(1, 3)))
         b.out = ("out12", flat12(pr.T.lin12(pr.miller([(P, Qa)], exact=True), True)))
         return b
+    if kind == "powc12raw":
+        # M^(1 - x), 1 - x = 1 + |x| = 0xd201000000010001: a large g2pubs VerifyAggregate pairs the hash points BEFORE their cofactor
+        # clearing and raises the product of its Miller values to the cofactor multiplier once (verify_host.inc); M is an arbitrary Fq12
+        # element (no final exponentiation yet), so plain squarings: 64 + 6 products.  Input and output in the device representation.
+        a = pr.T.lin12(unflat12([b.inp(BUF_RAW3, e) for e in range(12)]), True)
+        r = a
+        c = X_ABS + 1
+        for i in range(c.bit_length() - 2, -1, -1):
+            r = pr.T.lin12(pr.T.sqr12(r), True)
+            if (c >> i) & 1:
+                r = pr.T.lin12(pr.T.mul12(r, a), True)
+        b.out = ("outraw12", flat12(r))
+        return b
     if kind == "mul12raw":
         # one node of the Fq12 product tree of VerifyAggregate: record t times record t + half of an SoA buffer (a missing partner
         # reads as 1), both in the device representation, result in the device representation
@@ -1359,7 +1372,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "verify1s", "pairing1", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
+    for name in ("verify2", "verify1s", "pairing1", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "powc12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -292,3 +292,58 @@ def test_fused_sign_batches_match_the_oracle(eng):
     lib = eng._lib()
     assert lib.blsmi_g2pubs_sign_batch(None, None, None, None, None, 3) != 0
     assert lib.blsmi_g2pubs_sign_batch(None, None, None, None, None, 0) == 0
+
+
+def test_large_g2pubs_aggregate_with_the_cofactor_moved_through_the_pairing(eng):
+    """From 65 536 messages a g2pubs VerifyAggregate (g2pubs/bls.go:240-270) hashes WITHOUT the cofactor clearing of hash.go:306-309 and raises
+    the product of its Miller values to 1 - x once (program powc12raw; tests/test_lat_program.py has the identity on the oracle).  Verdicts --
+    valid, one wrong key, one wrong message, a tampered aggregate -- equal those of the cleared-hash path (BLSMI_AGG_COFACTOR_POW=0, read
+    per call), from host buffers and from resident ones; below the threshold the program is not used."""
+    import ctypes
+    import hashlib
+    import os
+    import torch
+    n = 65536 + 4096 + 7
+    nk = 64
+    sk = [hashlib.sha256(b"powc-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk)]
+    pks, _ = eng.g2_mul_generator_batch(b"".join(sk), nk)
+    msgs = [b"aggregate message %d" % i for i in range(n)]
+    packed = eng.PackedMsgs(msgs)
+    sks = (b"".join(sk) * (n // nk + 1))[:32 * n]
+    sigs, _ = eng.g2pubs_sign_batch(packed, sks)
+    assert sigs[12345].tobytes() == RC.g2pubs.sign(msgs[12345], sk[12345 % nk])
+    agg = eng.g1_sum(sigs.reshape(-1), n)
+    allpk = np.ascontiguousarray(np.tile(pks, (n // nk + 1, 1))[:n]).reshape(-1)
+    bad_pk = allpk.copy(); j = 40000; bad_pk[192 * j:192 * (j + 1)] = pks[(j + 1) % nk]
+    bad_msgs = list(msgs); bad_msgs[777] = b"another message"
+    agg2 = eng.g1_sum(sigs[:n - 1].reshape(-1), n - 1)
+    lib = eng._lib()
+
+    def run(m, p, a):
+        lib.blsmi_set_profiling(1)
+        v = eng.g2pubs_verify_aggregate(m, p, a)
+        buf = ctypes.create_string_buffer(8192); lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
+        return v, buf.value.decode()
+    saved = os.environ.get("BLSMI_AGG_COFACTOR_POW")
+    try:
+        for mode in ("1", "0"):
+            os.environ["BLSMI_AGG_COFACTOR_POW"] = mode
+            v, prof = run(packed, allpk, agg)
+            assert v is True and ("k_lat:powc12raw" in prof) == (mode == "1"), (mode, prof)
+            assert run(packed, bad_pk, agg)[0] is False
+            assert run(bad_msgs, allpk, agg)[0] is False
+            assert run(packed, allpk, agg2)[0] is False
+            # resident inputs
+            dev = torch.device("cuda", 0)
+            d_m = torch.from_numpy(packed.buf.copy()).to(dev); d_o = torch.from_numpy(packed.off.view(np.int64).copy()).to(dev)
+            d_p = torch.from_numpy(allpk).to(dev); d_b = torch.from_numpy(bad_pk).to(dev)
+            assert eng.verify_aggregate_dev("g2pubs", d_m.data_ptr(), d_o.data_ptr(), d_p.data_ptr(), agg, n) is True
+            assert eng.verify_aggregate_dev("g2pubs", d_m.data_ptr(), d_o.data_ptr(), d_b.data_ptr(), agg, n) is False
+        os.environ["BLSMI_AGG_COFACTOR_POW"] = "1"
+        m2 = 65535
+        a3 = eng.g1_sum(sigs[:m2].reshape(-1), m2)
+        v, prof = run(msgs[:m2], allpk[:192 * m2], a3)
+        assert v is True and "k_lat:powc12raw" not in prof
+    finally:
+        if saved is None: os.environ.pop("BLSMI_AGG_COFACTOR_POW", None)
+        else: os.environ["BLSMI_AGG_COFACTOR_POW"] = saved

@@ -19,7 +19,7 @@ sys.setrecursionlimit(100000)
 
 @pytest.fixture(scope="module")
 def progs():
-    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "verify1s", "aggtail", "aggtail2", "miller1rawn", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
+    return {k: G.schedule(G.build_program(k)) for k in ("pairing1", "verify2", "verify1s", "aggtail", "aggtail2", "powc12raw", "miller1rawn", "finalexp1", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2")}
 
 
 def _pt(xs):
@@ -84,6 +84,28 @@ def test_final_exponentiation_and_aggregate_tail_programs(progs):
         assert P.fq12_flat(P.final_exponentiation(G.unflat12(Sv))) == P.fq12_flat(P.final_exponentiation(P.miller_loop([(P.affine_neg(P.F1, Pa), P.g2_prepare(Qa))])))
         out = G.simulate(progs["aggtail2"], {G.BUF_RAW3: P.fq12_flat(R), G.BUF_RAW2: Sv})
         assert (out == [1] + [0] * 11) is want
+
+
+def test_cofactor_power_program_and_the_identity_it_rests_on(progs):
+    """powc12raw: M -> M^(1 - x) for an arbitrary Fq12 element.  A large g2pubs VerifyAggregate pairs S_i = the hash point BEFORE its cofactor
+    clearing (hash.go:306-309: H = [1 - x] S) and raises the product once: FE(ML(S, Q))^(1 - x) == FE(ML(H, Q)) for S on E(Fq) OUTSIDE the
+    subgroup (the reduced pairing is bilinear in that argument modulo r E(Fq)), so FE(prod ML(S_i, Q_i)^(1 - x) * ML(-sig, G2)) == 1 is the reference's verdict."""
+    xs = P.XORShift(31)
+    c = P.BLS_X + 1
+    f = P.miller_loop([(P.G1_GEN, P.g2_prepare(P.G2_GEN))])
+    assert G.simulate(progs["powc12raw"], {G.BUF_RAW3: P.fq12_flat(f)}) == P.fq12_flat(P.fq12_pow(f, c))
+    for trial in range(2):
+        m = b"\x01" + b"cofactor-%d" % trial
+        pp = P.jac_to_affine(P.F1, P.jac_add_affine(P.F1, P.to_jac(P.F1, P.swu_g1_helper(P.hp(m, 0))), P.swu_g1_helper(P.hp(m, 1))))
+        S = P.iso11(pp)
+        assert P.jac_to_affine(P.F1, P.affine_mul(P.F1, S, P.R_ORDER)) is not None        # S is NOT in the subgroup
+        H = P.clear_h(S)
+        assert H == P.hash_g1(m[1:])
+        Qa = P.jac_to_affine(P.F2, P.affine_mul(P.F2, P.G2_GEN, P.rand_fr(xs)))
+        prep = P.g2_prepare(Qa)
+        ms = P.miller_loop([(S, prep)])
+        powed = G.unflat12(G.simulate(progs["powc12raw"], {G.BUF_RAW3: P.fq12_flat(ms)}))
+        assert P.final_exponentiation(powed) == P.final_exponentiation(P.miller_loop([(H, prep)]))
 
 
 def _f2(v):
