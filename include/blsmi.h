@@ -256,7 +256,10 @@ int blsmi_g2pubs_verify_aggregate_prepared_dev(const void *d_msgs, const void *d
 
 /* Multi-GPU VerifyAggregate: each rank computes the product of its shard's Miller loops
  * prod_i ML(H(m_i), pk_i) (no final exponentiation) as one Fq12 in the wire format; the ranks all-gather
- * the 576-byte partials, multiply them (blsmi_fq12_product) and finish with one final exponentiation. */
+ * the 576-byte partials, multiply them (blsmi_fq12_product) and finish with one final exponentiation.  The value is
+ * meaningful only under that final exponentiation: it is a Miller value of the product, not a fixed representative
+ * (projective line functions; from 65 536 messages a g2pubs shard pairs its hash points before their cofactor clearing
+ * and raises its product to the cofactor multiplier instead). */
 int blsmi_g2pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */, int *bad /* may be NULL: 1 if a key is infinity */);
 int blsmi_g1pubs_aggregate_partial(const uint8_t *msgs, const uint64_t *off, const uint8_t *pks, size_t n, uint64_t *out_fq12 /* 72 */, int *bad);
 int blsmi_fq12_product(const uint64_t *in_fq12 /* n*72 */, size_t n, uint64_t *out_fq12 /* 72 */);

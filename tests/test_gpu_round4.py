@@ -339,7 +339,18 @@ def test_large_g2pubs_aggregate_with_the_cofactor_moved_through_the_pairing(eng)
             d_p = torch.from_numpy(allpk).to(dev); d_b = torch.from_numpy(bad_pk).to(dev)
             assert eng.verify_aggregate_dev("g2pubs", d_m.data_ptr(), d_o.data_ptr(), d_p.data_ptr(), agg, n) is True
             assert eng.verify_aggregate_dev("g2pubs", d_m.data_ptr(), d_o.data_ptr(), d_b.data_ptr(), agg, n) is False
+        # partial products across "ranks" (bls_amd/dist.py's exchange, in process): a shard of 65 536 messages takes the new path, the rest of
+        # the messages the cleared one; their product finishes to the same verdict
         os.environ["BLSMI_AGG_COFACTOR_POW"] = "1"
+        g2gen = np.frombuffer(RC.g2_generator(), dtype=np.uint8)
+        for keys, want in ((allpk, True), (bad_pk, False)):
+            pa, ba = eng.aggregate_partial("g2pubs", msgs[:65536], keys[:192 * 65536])
+            pb, bb = eng.aggregate_partial("g2pubs", msgs[65536:], keys[192 * 65536:])
+            assert not ba and not bb
+            rhs = eng.fq12_product(np.concatenate([np.asarray(pa, dtype=np.uint64).reshape(-1), np.asarray(pb, dtype=np.uint64).reshape(-1)]))
+            lhs = eng.miller_loop_batch(agg, g2gen, 1)[0]
+            fe = eng.final_exponentiation_batch(np.stack([lhs, np.asarray(rhs, dtype=np.uint64).reshape(-1)]))
+            assert bool(np.array_equal(fe[0], fe[1])) is want
         m2 = 65535
         a3 = eng.g1_sum(sigs[:m2].reshape(-1), m2)
         v, prof = run(msgs[:m2], allpk[:192 * m2], a3)
