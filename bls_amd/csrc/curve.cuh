@@ -135,18 +135,17 @@ template <class F> __device__ __noinline__ Jac<F> jac_add(const Jac<F>& g, const
 // The bucket accumulator of the MSM in XYZZ coordinates: (X, Y, ZZ, ZZZ) with x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2.  A bucket only ever
 // ADDS affine points, and the mixed addition there is 8 multiplications + 2 squarings (madd-2008-s) where the Jacobian one is 7 + 4 and
 // needs Z1^2, Z1^3 recomputed every time: 4 904 against 5 254 instructions per G1 addition (-7 %), -4.5 % for G2 (an Fq2 square costs 0.73
-// of a product).  Same group element; the bucket leaves as a Jacobian triple (xyzz_to_jac: Z = ZZ ZZZ, 6 + 2 once per bucket).  Special
+// of a product).  Same group element; the bucket leaves as the Jacobian triple (X ZZ, Y ZZZ, ZZ) -- two multiplications (xyzz_to_jac).  Special
 // cases (an infinite operand, equal x) branch out as in jac_acc_affine, through the Jacobian out-of-line function.
 template <class F> struct Xyzz { F x, y, zz, zzz; i32 inf; };
 template <class F> BLSMI_DEV Xyzz<F> xyzz_zero() {
     Xyzz<F> p; p.x = field_consts<F>::zero(); p.y = field_consts<F>::one(); p.zz = field_consts<F>::zero(); p.zzz = field_consts<F>::zero(); p.inf = -1; return p;
 }
-template <class F> BLSMI_DEV Jac<F> xyzz_to_jac(const Xyzz<F>& g) {      // Z = ZZ ZZZ: X Z^2 / ZZ = X ZZ ZZZ^2,  Y Z^3 / ZZZ = Y ZZ^3 ZZZ^2
-    const F u = f_store(f_mul(g.zz, f_sqr(g.zzz)));
+template <class F> BLSMI_DEV Jac<F> xyzz_to_jac(const Xyzz<F>& g) {      // Z = ZZ: X' / Z^2 = X ZZ / ZZ^2 = x,  Y' / Z^3 = Y ZZZ / ZZ^3 = Y ZZZ / ZZZ^2 = y
     Jac<F> r;
-    r.x = f_store(f_mul(g.x, u));
-    r.y = f_store(f_mul(f_mul(g.y, f_sqr(g.zz)), u));
-    r.z = f_store(f_mul(g.zz, g.zzz));
+    r.x = f_store(f_mul(g.x, g.zz));
+    r.y = f_store(f_mul(g.y, g.zzz));
+    r.z = g.zz;
     r.inf = g.inf;
     return r;
 }
