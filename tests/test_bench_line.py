@@ -47,7 +47,7 @@ def _detail():
                                         "prepared_keys": {"ms": 119.49, "signatures_per_s": 8775000.0, "tables_GB": 25.9, "roofline": _roof("k_miller1x2_prep_pair"), "note": "n" * 300}},
          "g1pubs_aggregate_bench": {"signatures": 1 << 18, "ms": 56.14, "signatures_per_s": 4669519.5, "roofline": _roof("k_miller1x2_pair"), "note": "n" * 500, "cpu_baseline": _cpu("signatures/s")},
          "config0": {"workload": "w" * 300, "cpu": dict(_cpu("verifies/s"), wall_s=0.24), "gpu": {"value": 345187.9, "unit": "verifies/s", "ms_one_call": 2.9, "path": "p" * 200},
-                     "verdicts_identical": True, "rejected": 62},
+                     "roofline": _roof("k_lat:verify2"), "verdicts_identical": True, "rejected": 62},
          "inlibrary_bench": {"devices": 1, "shards": 1, "tuples_per_call": 65536, "pairings_per_s": 2.5e6, "g2pubs_verifies_per_s": 2.1e6, "g1pubs_verifies_per_s": 1.8e6, "rccl_ranks": 0},
          "mid_batches": {"pairings_per_s": {str(n): 1234567.8 for n in (8192, 16384, 32768, 65536)}, "note": "n" * 300},
          "reference_shapes": {"x" * 20 + str(i): {"gpu_ms": 1.37, "cpu_ms": 2.9, "note": "n" * 100} for i in range(12)}}
@@ -76,7 +76,7 @@ def test_line_is_under_4k_and_carries_the_contract():
         assert {"value", "unit", "ms", "roofline", "cpu_baseline"} <= set(e)
         assert e["roofline"]["kernel"] and e["roofline"]["frac"] and e["cpu_baseline"]["value"]
     assert cfg["3"]["value"] == 7042302.3 and cfg["3"]["host_buffers_ms"] == 153.84 and cfg["3"]["prepared_keys_ms"] == 119.49
-    assert cfg["0"]["cpu_baseline"]["value"] == 34585.34 and cfg["0"]["verdicts_identical"] is True
+    assert cfg["0"]["cpu_baseline"]["value"] == 34585.34 and cfg["0"]["verdicts_identical"] is True and cfg["0"]["roofline"]["kernel"] == "k_lat:verify2"
 
 
 def test_line_survives_missing_and_failed_legs():
@@ -116,7 +116,7 @@ def test_bench_command_prints_one_parsable_line():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["value"] > 0
     assert sorted(j["configs"]) == ["0", "1", "2", "3", "4"], j.get("leg_errors")
     assert "leg_errors" not in j, j["leg_errors"]
-    for k in ("3", "4"):
+    for k in ("0", "3", "4"):
         assert j["configs"][k]["cpu_baseline"]["value"] > 0 and j["configs"][k]["roofline"]["kernel"]
     detail = json.load(open(os.path.join(ROOT, j["detail"])))
     assert detail["value"] == j["value"] and "reference_shapes" in detail
