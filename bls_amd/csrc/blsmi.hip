@@ -58,7 +58,7 @@ std::mutex g_mu;
 std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
-char g_version[200] = "blsmi 0.5 (uninitialised)";
+char g_version[200] = "blsmi 0.6 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
@@ -327,7 +327,7 @@ int ensure_init_list(const int* devs, int ndev) {
     HIPCHK(hipSetDevice(g_dev[0].id));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g_dev[0].id));
-    snprintf(g_version, sizeof g_version, "blsmi 0.5 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_alias ? " ALIASED-DEVICES(test hook: host-staged collectives)" : g_have_comm ? " rccl" : "");
+    snprintf(g_version, sizeof g_version, "blsmi 0.6 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_alias ? " ALIASED-DEVICES(test hook: host-staged collectives)" : g_have_comm ? " rccl" : "");
     g_ready = true;
     return BLSMI_OK;
 }
@@ -632,6 +632,50 @@ BLSMI_API int blsmi_host_free(void* p) {
     return BLSMI_OK;
 }
 
+// ---- point formats at the host boundary (blsmi 0.6: the *_jac entry points) --------------------------------------------------
+// A Go caller holds its keys and signatures as *bls.G2Projective / *bls.G1Projective (g2pubs/bls.go:13-15, 53-55): x, y, z, each FQ
+// 6 LE u64 Montgomery(2^384) limbs (fq.go:11-13, fqrepr.go:14) -- 144 bytes (G1) / 288 bytes (G2), contiguous.  The *_jac entry points
+// take those bytes as they lie (one memcpy per point in the shim) and run ToAffine + SerializeBytes on the device (k_wire.hip:
+// k_g?_jac_to_affine), after which every path is the affine one.  fmt bit 0: the public keys, bit 1: the signatures arrive that way.
+namespace {
+constexpr int FMT_PK_JAC = 1, FMT_SIG_JAC = 2, FMT_JAC = 3;
+inline size_t rec_bytes(size_t wire_bytes, bool jac) { return jac ? wire_bytes / 2 * 3 : wire_bytes; }
+// n in-memory records on the device -> n wire records (the all-zero record for z == 0) and, if asked, their infinity flags
+int jac_to_wire_dev(size_t wire_bytes, const void* d_jac, void* d_out, void* d_inf, size_t n, hipStream_t s) {
+    if (n == 0) return BLSMI_OK;
+    const bool mark = tl_ctx && s == tl_ctx->stream;                       // (profile marks are events on the context's main stream)
+    if (mark) prof_mark(wire_bytes == 96 ? "k_g1_jac_to_affine" : "k_g2_jac_to_affine");
+    if (wire_bytes == 96) hipLaunchKernelGGL(k_g1_jac_to_affine, dim3(nblocks(n)), dim3(WG), 0, s, (const u64*)d_jac, (u8*)d_out, (u8*)d_inf, n);
+    else hipLaunchKernelGGL(k_g2_jac_to_affine, dim3(nblocks(n)), dim3(WG), 0, s, (const u64*)d_jac, (u8*)d_out, (u8*)d_inf, n);
+    if (mark) prof_mark(nullptr);
+    HIPCHK(hipGetLastError());
+    return BLSMI_OK;
+}
+// host copy + conversion of n records of one group: `host` holds wire records (jac == false: plain copy into d_wire) or in-memory
+// records (copied into a temporary of the call, converted into d_wire); everything on s
+int upload_points(size_t wire_bytes, bool jac, const uint8_t* host, void* d_wire, size_t n, hipStream_t s) {
+    if (!jac) { HIPCHK(hipMemcpyAsync(d_wire, host, wire_bytes * n, hipMemcpyHostToDevice, s)); return BLSMI_OK; }
+    DBuf raw; HIPCHK(raw.alloc(rec_bytes(wire_bytes, true) * n));
+    HIPCHK(hipMemcpyAsync(raw.p, host, rec_bytes(wire_bytes, true) * n, hipMemcpyHostToDevice, s));
+    return jac_to_wire_dev(wire_bytes, raw.p, d_wire, nullptr, n, s);
+}
+// Is ONE host-side in-memory record the point at infinity?  z.IsZero() (g1.go:287-289, g2.go:325-327), where a coordinate that is not
+// below q counts as 0 exactly as on the device (device_io.cuh: load_m384_checked).  No field arithmetic: a compare.
+bool jac_host_is_infinity(const uint8_t* rec, size_t wire_bytes) {
+    static const uint64_t Q[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+    const size_t nc = wire_bytes / 96;                                     // FQ per coordinate
+    uint64_t nz = 0;
+    for (size_t e = 0; e < nc; e++) {
+        uint64_t w[6];
+        memcpy(w, rec + 48 * (2 * nc + e), 48);
+        bool below = false;
+        for (int j = 5; j >= 0; j--) { if (w[j] != Q[j]) { below = w[j] < Q[j]; break; } }
+        if (below) for (int j = 0; j < 6; j++) nz |= w[j];
+    }
+    return nz == 0;
+}
+}  // namespace
+
 // ---- pairing ------------------------------------------------------------------------------------
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;
@@ -748,7 +792,7 @@ BLSMI_API int blsmi_pairing_batch_dev(const void* d_g1, const void* d_g2, void* 
     return pairing_dev(d_g1, d_g2, d_out, n, g_stream, 0);
 }
 // host-buffer form: independent tuples, split over the devices by contiguous block, no exchange at all
-static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n, int mode) {
+static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n, int mode, bool jac = false) {
     if (n && (!g1 || !g2 || !out)) return BLSMI_E_ARG;
     if (n == 0) return BLSMI_OK;
     { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc; }
@@ -756,9 +800,11 @@ static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, siz
         const size_t m = hi - lo;
         DBuf a, b, o;
         HIPCHK(a.alloc(96 * m)); HIPCHK(b.alloc(192 * m)); HIPCHK(o.alloc(576 * m));
-        HIPCHK(hipMemcpyAsync(a.p, g1 + 96 * lo, 96 * m, hipMemcpyHostToDevice, g_stream));
-        HIPCHK(hipMemcpyAsync(b.p, g2 + 192 * lo, 192 * m, hipMemcpyHostToDevice, g_stream));
-        int rc = pairing_dev(a.p, b.p, o.p, m, g_stream, mode);
+        int rc = upload_points(96, jac, g1 + rec_bytes(96, jac) * lo, a.p, m, g_stream);
+        if (rc) return rc;
+        rc = upload_points(192, jac, g2 + rec_bytes(192, jac) * lo, b.p, m, g_stream);
+        if (rc) return rc;
+        rc = pairing_dev(a.p, b.p, o.p, m, g_stream, mode);
         if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out + 72 * lo, o.p, 576 * m, hipMemcpyDeviceToHost, g_stream));
         HIPCHK(hipStreamSynchronize(g_stream));
@@ -767,6 +813,32 @@ static int pairing_host(const uint8_t* g1, const uint8_t* g2, uint64_t* out, siz
 }
 BLSMI_API int blsmi_pairing_batch(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n) { return pairing_host(g1, g2, out, n, 0); }
 BLSMI_API int blsmi_miller_loop_batch(const uint8_t* g1, const uint8_t* g2, uint64_t* out, size_t n) { return pairing_host(g1, g2, out, n, 1); }
+// bls.Pairing(p *G1Projective, q *G2Projective) (pairing.go:132-136) on the points as the Go heap holds them: ToAffine on the device
+BLSMI_API int blsmi_pairing_batch_jac(const uint64_t* g1_jac, const uint64_t* g2_jac, uint64_t* out, size_t n) {
+    return pairing_host(reinterpret_cast<const uint8_t*>(g1_jac), reinterpret_cast<const uint8_t*>(g2_jac), out, n, 0, true);
+}
+// G?Projective.ToAffine().SerializeBytes() (g1.go:322-340 + 157-167, g2.go:365-386 + 172-186) for n points: wire records (all zero for
+// the point at infinity) and the infinity flags
+template <int PB>
+static int jac_to_affine_host(const uint64_t* jac, uint8_t* out, uint8_t* out_inf, size_t n) {
+    if (n && (!jac || !out)) return BLSMI_E_ARG;
+    if (n == 0) return BLSMI_OK;
+    { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc; }
+    return run_shards(plan_shards(n, 64), [&](int, size_t lo, size_t hi) -> int {
+        const size_t m = hi - lo, in = rec_bytes(PB, true);
+        DBuf raw, o, fl;
+        HIPCHK(raw.alloc(in * m)); HIPCHK(o.alloc((size_t)PB * m)); HIPCHK(fl.alloc(m));
+        HIPCHK(hipMemcpyAsync(raw.p, reinterpret_cast<const uint8_t*>(jac) + in * lo, in * m, hipMemcpyHostToDevice, g_stream));
+        int rc = jac_to_wire_dev(PB, raw.p, o.p, fl.p, m, g_stream);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(out + (size_t)PB * lo, o.p, (size_t)PB * m, hipMemcpyDeviceToHost, g_stream));
+        if (out_inf) HIPCHK(hipMemcpyAsync(out_inf + lo, fl.p, m, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        return BLSMI_OK;
+    });
+}
+BLSMI_API int blsmi_g1_jac_to_affine_batch(const uint64_t* jac, uint8_t* out, uint8_t* out_inf, size_t n) { return jac_to_affine_host<96>(jac, out, out_inf, n); }
+BLSMI_API int blsmi_g2_jac_to_affine_batch(const uint64_t* jac, uint8_t* out, uint8_t* out_inf, size_t n) { return jac_to_affine_host<192>(jac, out, out_inf, n); }
 BLSMI_API int blsmi_final_exponentiation_batch(const uint64_t* in, uint64_t* out, size_t n) {
     if (n && (!in || !out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
@@ -967,11 +1039,19 @@ BLSMI_API int blsmi_g2_mul_batch_dev_ex(const void* d_pts, const void* d_scalars
 
 // tree reduction of n affine points already on the device; result (affine bytes + inf flag) on the device
 template <int PB, int W, class K0, class K1, class K2>
-static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, size_t n, u8* d_out, i32* d_out_inf, hipStream_t s, bool sync = true) {
+static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, size_t n, u8* d_out, i32* d_out_inf, hipStream_t s, bool sync = true, bool jac = false) {
     const size_t words = (size_t)W * NL + 1;
     size_t half = (n + 1) / 2;
-    DBuf b0, b1;
+    DBuf b0, b1, wire;
     HIPCHK(b0.alloc(sizeof(i32) * words * half)); HIPCHK(b1.alloc(sizeof(i32) * words * ((half + 1) / 2)));
+    // jac: d_pts are the reference's in-memory Jacobian records (144 / 288 bytes, d_inf unused: z == 0 says it).  Many points: level 0 adds
+    // them as they are (k_g?_sum0_jac: no inversion anywhere before the one at the end); few: they become wire records for the level programs
+    if (jac && half <= g_lat_max) {
+        HIPCHK(wire.alloc((size_t)PB * n));
+        int rc = jac_to_wire_dev(PB, d_pts, wire.p, nullptr, n, s);
+        if (rc) return rc;
+        d_pts = wire.as<u8>(); d_inf = nullptr; jac = false;
+    }
     if (half <= g_lat_max) {
         // few points: every addition of the tree as a level program, one per wave (k_lat.hip: sum0 / sum1 / sumfin; complete
         // projective formulas, two product levels per addition) -- ~10 us a level instead of ~70-140
@@ -999,7 +1079,9 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
         return BLSMI_OK;
     }
     prof_mark(W == 3 ? "k_g1_sum0" : "k_g2_sum0");
-    hipLaunchKernelGGL(k0, dim3(nblocks(half)), dim3(WG), 0, s, d_pts, d_inf, b0.as<i32>(), n, half);
+    if (jac && W == 3) hipLaunchKernelGGL(k_g1_sum0_jac, dim3(nblocks(half)), dim3(WG), 0, s, (const u64*)d_pts, b0.as<i32>(), n, half);
+    else if (jac) hipLaunchKernelGGL(k_g2_sum0_jac, dim3(nblocks(half)), dim3(WG), 0, s, (const u64*)d_pts, b0.as<i32>(), n, half);
+    else hipLaunchKernelGGL(k0, dim3(nblocks(half)), dim3(WG), 0, s, d_pts, d_inf, b0.as<i32>(), n, half);
     prof_mark(W == 3 ? "k_g1_sum" : "k_g2_sum");
     i32* src = b0.as<i32>(); i32* dst = b1.as<i32>();
     size_t cur = half;
@@ -1017,24 +1099,45 @@ static int sum_dev(K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_inf, si
     return BLSMI_OK;
 }
 template <int PB, int W, class K0, class K1, class K2>
-static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t* out, int* out_inf) {
-    if (!out || !out_inf || (n && !pts)) return BLSMI_E_ARG;
-    if (n == 0) { memset(out, 0, PB); *out_inf = 1; return BLSMI_OK; }      // empty sum = infinity (g2pubs/bls.go:166, 181)
+static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t* out, int* out_inf, bool jac = false, uint64_t* out_jac = nullptr) {
+    // jac: pts are in-memory Jacobian records (no in_inf); out_jac (may be null): the sum as such a record with z = 1, (0, 1, 0) for infinity
+    if (!out_inf || (!out && !out_jac) || (n && !pts)) return BLSMI_E_ARG;
+    const size_t jb = rec_bytes(PB, true);
+    if (n == 0) {                                                          // empty sum = infinity (g2pubs/bls.go:166, 181)
+        if (out) memset(out, 0, PB);
+        if (out_jac) { static const uint64_t one[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull, 0x77ce585370525745ull, 0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull};
+                       memset(out_jac, 0, jb); memcpy(reinterpret_cast<uint8_t*>(out_jac) + PB / 2, one, 48); }   // FQOne (fq.go:22) in y: G?ProjectiveZero
+        *out_inf = 1; return BLSMI_OK;
+    }
     LOCK_AND_INIT();
-    DBuf dp, di, dout, dflag;
-    HIPCHK(dp.alloc((size_t)PB * n)); HIPCHK(di.alloc(n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32)));
-    HIPCHK(hipMemcpyAsync(dp.p, pts, (size_t)PB * n, hipMemcpyHostToDevice, g_stream));
-    if (in_inf) HIPCHK(hipMemcpyAsync(di.p, in_inf, n, hipMemcpyHostToDevice, g_stream));
-    int rc = sum_dev<PB, W>(k0, k1, kfinal, dp.as<u8>(), in_inf ? di.as<u8>() : nullptr, n, dout.as<u8>(), dflag.as<i32>(), g_stream);
+    DBuf dp, di, dout, dflag, dj;
+    HIPCHK(dp.alloc((jac ? jb : (size_t)PB) * n)); HIPCHK(di.alloc(n)); HIPCHK(dout.alloc(PB)); HIPCHK(dflag.alloc(sizeof(i32))); HIPCHK(dj.alloc(jb));
+    HIPCHK(hipMemcpyAsync(dp.p, pts, (jac ? jb : (size_t)PB) * n, hipMemcpyHostToDevice, g_stream));
+    if (in_inf && !jac) HIPCHK(hipMemcpyAsync(di.p, in_inf, n, hipMemcpyHostToDevice, g_stream));
+    int rc = sum_dev<PB, W>(k0, k1, kfinal, dp.as<u8>(), (in_inf && !jac) ? di.as<u8>() : nullptr, n, dout.as<u8>(), dflag.as<i32>(), g_stream, true, jac);
     if (rc) return rc;
     i32 flag = 0;
-    HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream));
+    if (out_jac) {
+        hipLaunchKernelGGL(k_affine_to_jac, dim3(1), dim3(WG), 0, g_stream, (const u8*)dout.as<u8>(), (const i32*)dflag.as<i32>(), W == 3 ? 1 : 2, dj.as<u64>(), (size_t)1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out_jac, dj.p, jb, hipMemcpyDeviceToHost, g_stream));
+    }
+    if (out) HIPCHK(hipMemcpyAsync(out, dout.p, PB, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
     HIPCHK(hipMemcpyAsync(&flag, dflag.p, sizeof flag, hipMemcpyDeviceToHost, g_stream)); HIPCHK(hipStreamSynchronize(g_stream));
     *out_inf = flag;
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_g1_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[96], int* out_inf) { return sum_host<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, pts, in_inf, n, out, out_inf); }
 BLSMI_API int blsmi_g2_sum(const uint8_t* pts, const uint8_t* in_inf, size_t n, uint8_t out[192], int* out_inf) { return sum_host<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, pts, in_inf, n, out, out_inf); }
+// AggregateSignatures / AggregatePublicKeys (g2pubs/bls.go:165-192, g1pubs/bls.go:177-204) over the points as the Go values hold them, the sum
+// handed back the same way (z = 1): no ToAffine, no SerializeBytes, no FQReprToFQ in the shim
+BLSMI_API int blsmi_g1_sum_jac(const uint64_t* pts_jac, size_t n, uint64_t out_jac[18], int* out_inf) {
+    return sum_host<96, 3>(k_g1_sum0, k_g1_sum, k_g1_sum_final, reinterpret_cast<const uint8_t*>(pts_jac), nullptr, n, nullptr, out_inf, true, out_jac);
+}
+BLSMI_API int blsmi_g2_sum_jac(const uint64_t* pts_jac, size_t n, uint64_t out_jac[36], int* out_inf) {
+    return sum_host<192, 6>(k_g2_sum0, k_g2_sum, k_g2_sum_final, reinterpret_cast<const uint8_t*>(pts_jac), nullptr, n, nullptr, out_inf, true, out_jac);
+}
 template <int PB, int W, class K0, class K1, class K2>
 static int sum_dev_api(K0 k0, K1 k1, K2 kfinal, const void* d_pts, const void* d_in_inf, size_t n, void* d_out, int* out_inf, void* stream) {
     if (!d_out || !out_inf || (n && !d_pts)) return BLSMI_E_ARG;

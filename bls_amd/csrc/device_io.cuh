@@ -91,6 +91,43 @@ BLSMI_DEV FpS load_m384(const u64* p) {
     for (int j = 0; j < 12; j++) w[j] = w32[j];
     return fp_from_mont384_words(w);
 }
+// One FQ of the reference as it lies in the Go heap (fq.go:11-13: 6 LE u64, Montgomery 2^384) -- the coordinates of a
+// bls.G1Projective / G2Projective handed over by the *_jac entry points.  The reference's arithmetic keeps every FQ below q
+// (fq.go:37-45), so a limb image >= q cannot come out of it; one that arrives anyway is read the way FQReprToFQ reads an
+// invalid repr (fq.go:49-56): as 0.  nz accumulates the OR of the (valid) words: nz == 0 <=> the element is 0 (FQ.IsZero);
+// diff accumulates the OR of the differences to `expect` (12 words, or null for 0): diff == 0 <=> the element IS that value.
+BLSMI_DEV FpS load_m384_checked(const u64* p, u32& nz, u32& diff, const u32* expect) {
+    const u32* w32 = reinterpret_cast<const u32*>(p);
+    u32 w[12];
+    u32 borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) {
+        w[j] = w32[j];
+        const u64 d = (u64)w[j] - (u64)C_Q_WORDS[j] - borrow;
+        borrow = (u32)(d >> 32) & 1u;
+    }
+    const u32 valid = 0u - borrow;                                         // all ones iff the integer is below q
+#pragma unroll
+    for (int j = 0; j < 12; j++) { w[j] &= valid; nz |= w[j]; diff |= w[j] ^ (expect ? expect[j] : 0u); }
+    return fp_from_mont384_words(w);
+}
+// A whole in-memory point: x, y, z as NC = 1 (G1Projective, g1.go:252-256) or 2 (G2Projective, g2.go:298-302) FQ each.
+// inf <=> z.IsZero() (g1.go:287-289, g2.go:325-327); *z_is_one (optional) <=> z is exactly FQOne / FQ2One, what ToProjective
+// of a deserialised point leaves (g1.go:59-64) -- ToAffine then has nothing to invert.
+template <class F>
+BLSMI_DEV Jac<F> load_jac_m384(const u64* rec, bool* z_is_one = nullptr) {
+    constexpr int NC = sizeof(F) / sizeof(FpS);
+    Jac<F> j;
+    FpS* c = reinterpret_cast<FpS*>(&j);
+    u32 nz_xy = 0, nz_z = 0, d_xy = 0, d_z = 0;
+#pragma unroll
+    for (int e = 0; e < 2 * NC; e++) c[e] = load_m384_checked(rec + 6 * e, nz_xy, d_xy, nullptr);
+#pragma unroll
+    for (int e = 0; e < NC; e++) c[2 * NC + e] = load_m384_checked(rec + 6 * (2 * NC + e), nz_z, d_z, e == 0 ? C_ONE_M384_WORDS : nullptr);
+    j.inf = nz_z ? 0 : -1;
+    if (z_is_one) *z_is_one = d_z == 0;
+    return j;
+}
 template <int L, int V>
 BLSMI_DEV void store_m384(u64* p, const Fp<L, V>& x) {
     u32 w[12];
@@ -145,6 +182,22 @@ BLSMI_DEV void store_g2(u8* p, const G2Aff& a) {
     store_be48(p, a.x.c0); store_be48(p + 48, a.x.c1); store_be48(p + 96, a.y.c0); store_be48(p + 144, a.y.c1);
 }
 
+// ... and back: an affine point as the in-memory Jacobian record with z = 1 (what G?Affine.ToProjective leaves, g1.go:59-64, g2.go:70-76);
+// the point at infinity as (0, 1, 0), the reference's G?ProjectiveZero (g1.go:275, g2.go:313)
+template <class F>
+BLSMI_DEV void store_jac_m384(u64* rec, const Aff<F>& a) {
+    constexpr int NC = sizeof(F) / sizeof(FpS);
+    u32* w = reinterpret_cast<u32*>(rec);
+    if (a.inf) {
+        for (int i = 0; i < 36 * NC; i++) w[i] = 0;
+        for (int j = 0; j < 12; j++) w[12 * NC + j] = C_ONE_M384_WORDS[j];
+        return;
+    }
+    const FpS* c = reinterpret_cast<const FpS*>(&a);
+#pragma unroll
+    for (int e = 0; e < 2 * NC; e++) store_m384(rec + 6 * e, c[e]);
+    for (int j = 0; j < 12 * NC; j++) w[24 * NC + j] = j < 12 ? C_ONE_M384_WORDS[j] : 0u;
+}
 
 // records of W Fq values in the Fq wire format (6 LE u64, Montgomery 2^384), used by the unit-level debug kernels
 template <int W> struct Rec { FpS e[W]; };

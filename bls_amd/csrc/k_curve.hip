@@ -248,6 +248,19 @@ __device__ void sum_level0_body(const u8* pts, const u8* in_inf, i32* buf, size_
 }
 KERNEL2 k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<FpS, 96>(pts, in_inf, buf, n, half); }
 KERNEL k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half) { sum_level0_body<Fp2S, 192>(pts, in_inf, buf, n, half); }
+// level 0 over the reference's in-memory points (bls.G?Projective records, device_io.cuh: load_jac_m384; the *_jac entry points): the sum of
+// Jacobian points needs no ToAffine at all -- g1.go:400-470 / g2.go:446-516 (AddAssign of two projective points), as AggregatePublicKeys runs it
+template <class F>
+__device__ void sum_level0_jac_body(const u64* pts, i32* buf, size_t n, size_t half) {
+    constexpr int RW = 18 * (sizeof(F) / sizeof(FpS));
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= half) return;
+    Jac<F> r = load_jac_m384<F>(pts + (size_t)RW * t);
+    if (t + half < n) r = jac_add(r, load_jac_m384<F>(pts + (size_t)RW * (t + half)));
+    jac_soa_store(buf, half, t, r);
+}
+KERNEL2 k_g1_sum0_jac(const u64* pts, i32* buf, size_t n, size_t half) { sum_level0_jac_body<FpS>(pts, buf, n, half); }
+KERNEL k_g2_sum0_jac(const u64* pts, i32* buf, size_t n, size_t half) { sum_level0_jac_body<Fp2S>(pts, buf, n, half); }
 template <class F>
 __device__ void sum_level_body(const i32* src, i32* dst, size_t n, size_t half) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;

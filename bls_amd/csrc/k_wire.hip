@@ -161,6 +161,39 @@ KERNEL k_g2_compress(const u8* pts, const u8* in_inf, u8* out, size_t n) {
     o[0] |= 0x80 | (fp2_sign_is_neg(y) ? 0x20 : 0);                        // g2.go:278-284
 }
 
+// ---- the reference's in-memory points at the boundary (blsmi 0.6: the *_jac entry points) ---------------------------------------
+// A Go caller holds *bls.G1Projective / *bls.G2Projective (g2pubs/bls.go:13-15, 53-55): Jacobian coordinates, each FQ 6 LE u64
+// Montgomery(2^384) limbs.  Taking them as they lie saves the shim one ToAffine (an Fq inversion, g1.go:322-340) and one
+// SerializeBytes (two MontReduce + byte swap, g1.go:157-167) per point on a host core -- ~12 us, against 0.36 us of device time
+// per verify.  This kernel is that ToAffine + SerializeBytes: n records of 18 / 36 u64 -> n wire records (the all-zero record for
+// z == 0, which every kernel downstream reads as infinity) + the infinity flags.  A wave whose 64 points all have z == 1
+// (keys and signatures that came through Deserialize*) skips the inversion, like the reference's shortcut g2.go:368.
+template <class F, int PB>
+BLSMI_DEV void jac_to_affine_body(const u64* in, u8* out, u8* out_inf, size_t n) {
+    constexpr int NC = sizeof(F) / sizeof(FpS);
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const size_t tt = t < n ? t : n - 1;
+    bool z_one;
+    const Jac<F> j = load_jac_m384<F>(in + (size_t)18 * NC * tt, &z_one);
+    Aff<F> a;
+    if (__all(z_one || j.inf)) { a.x = j.x; a.y = j.y; a.inf = j.inf; }
+    else a = jac_to_affine(j);
+    if (t < n) {
+        if constexpr (NC == 1) store_g1(out + (size_t)PB * t, a); else store_g2(out + (size_t)PB * t, a);
+        if (out_inf) out_inf[t] = a.inf ? 1 : 0;
+    }
+}
+KERNEL2 k_g1_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n) { jac_to_affine_body<FpS, 96>(in, out, out_inf, n); }
+KERNEL k_g2_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n) { jac_to_affine_body<Fp2S, 192>(in, out, out_inf, n); }
+// the other direction, for results that go back into a Go value (AggregatePublicKeys / AggregateSignatures: one point): wire record
+// + infinity flag -> the in-memory record with z = 1
+KERNEL k_affine_to_jac(const u8* in, const i32* in_inf, int group, u64* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (t >= n) return;
+    if (group == 1) { G1Aff a = load_g1(in + 96 * t); if (in_inf && in_inf[t]) a.inf = -1; store_jac_m384(out + 18 * t, a); }
+    else { G2Aff a = load_g2(in + 192 * t); if (in_inf && in_inf[t]) a.inf = -1; store_jac_m384(out + 36 * t, a); }
+}
+
 KERNEL k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     if (t >= n) return;

@@ -80,6 +80,9 @@ __global__ void k_flag_to_byte(const i32* flag, u8* out);
 __global__ void k_pack_bitmap(const u8* ok, u8* bitmap, size_t n);
 __global__ void k_g1_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
 __global__ void k_g2_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
+__global__ void k_g1_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n);
+__global__ void k_g2_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n);
+__global__ void k_affine_to_jac(const u8* in, const i32* in_inf, int group, u64* out, size_t n);
 __global__ void k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
 __global__ void k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
 __global__ void k_debug_swu_g1(const u64* a, u64* out, size_t n);
@@ -104,6 +107,8 @@ __global__ void k_g1_mul_fixed_wave(const i32* table, const u8* scalars, u8* out
 __global__ void k_g2_mul_fixed_wave(const i32* table, const u8* scalars, u8* out, u8* out_inf, size_t n);
 __global__ void k_g1_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
 __global__ void k_g2_sum0(const u8* pts, const u8* in_inf, i32* buf, size_t n, size_t half);
+__global__ void k_g1_sum0_jac(const u64* pts, i32* buf, size_t n, size_t half);
+__global__ void k_g2_sum0_jac(const u64* pts, i32* buf, size_t n, size_t half);
 __global__ void k_g1_sum(const i32* src, i32* dst, size_t n, size_t half);
 __global__ void k_g2_sum(const i32* src, i32* dst, size_t n, size_t half);
 __global__ void k_g1_sum_final(const i32* src, u8* out, i32* out_inf);

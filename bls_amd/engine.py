@@ -711,3 +711,176 @@ def debug_op(name, a, b=None, lane_pair=False, raw_flag=False, lane_quad=False):
         bp = b.ctypes.data_as(_u64p)
     _check(_lib().blsmi_debug_op(op | (LANE_PAIR if lane_pair else 0) | (LANE_QUAD if lane_quad else 0), a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
     return out, (flag.copy() if raw_flag else flag.astype(bool))
+
+
+# ---- the reference's in-memory points at the boundary (blsmi 0.6, include/blsmi.h "in-memory points") ------------------------
+# bls.G1Projective = 18 x u64, bls.G2Projective = 36 x u64 (x, y, z; each FQ 6 little-endian u64 Montgomery limbs): 144 / 288 bytes.
+G1_JAC_BYTES, G2_JAC_BYTES = 144, 288
+
+
+def _j64(x, nbytes):
+    a = _u8(x, nbytes) if nbytes else np.zeros(8, np.uint8)
+    return a, a.ctypes.data_as(_u64p)
+
+
+def _jac_to_affine(fn, jb, wb, jac, n):
+    a, pa = _j64(jac, jb * n)
+    out = np.zeros(max(1, wb * n), dtype=np.uint8)
+    inf = np.zeros(max(1, n), dtype=np.uint8)
+    _check(fn(pa, _p8(out), _p8(inf), C.c_size_t(n)), "jac_to_affine_batch")
+    return out[:wb * n].tobytes(), inf[:n].astype(bool)
+
+
+def g1_jac_to_affine_batch(jac, n):
+    """G1Projective.ToAffine().SerializeBytes() for n in-memory points -> (n*96 wire bytes, infinity flags)"""
+    return _jac_to_affine(_lib().blsmi_g1_jac_to_affine_batch, 144, 96, jac, n)
+
+
+def g2_jac_to_affine_batch(jac, n):
+    return _jac_to_affine(_lib().blsmi_g2_jac_to_affine_batch, 288, 192, jac, n)
+
+
+def pairing_batch_jac(g1_jac, g2_jac, n):
+    """bls.Pairing on n (G1Projective, G2Projective) pairs as the Go heap holds them -> (n, 72) uint64"""
+    a, pa = _j64(g1_jac, 144 * n)
+    b, pb = _j64(g2_jac, 288 * n)
+    out = np.zeros((n, 72), dtype=np.uint64)
+    _check(_lib().blsmi_pairing_batch_jac(pa, pb, out.ctypes.data_as(_u64p), C.c_size_t(n)), "blsmi_pairing_batch_jac")
+    return out
+
+
+def _sum_jac(fn, jb, pts, n):
+    a, pa = _j64(pts, jb * n)
+    out = np.zeros(jb // 8, dtype=np.uint64)
+    oinf = C.c_int(0)
+    _check(fn(pa, C.c_size_t(n), out.ctypes.data_as(_u64p), C.byref(oinf)), "sum_jac")
+    return out.tobytes(), bool(oinf.value)
+
+
+def g1_sum_jac(pts, n):
+    """sum of n in-memory G1 points -> (the sum as an in-memory point with z = 1, is_infinity)"""
+    return _sum_jac(_lib().blsmi_g1_sum_jac, 144, pts, n)
+
+
+def g2_sum_jac(pts, n):
+    return _sum_jac(_lib().blsmi_g2_sum_jac, 288, pts, n)
+
+
+def _verify_batch_jac(fn, pkb, sgb, msgs, pks, sigs):
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    p, pp = _j64(pks, pkb * n)
+    s, ps = _j64(sigs, sgb * n)
+    ok = np.zeros(n, dtype=np.uint8)
+    bitmap = np.zeros((n + 7) // 8, dtype=np.uint8)
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), pp, ps, _p8(ok), _p8(bitmap), C.c_size_t(n)), "verify_batch_jac")
+    return ok.astype(bool), bitmap
+
+
+def g2pubs_verify_batch_jac(msgs, pks, sigs):
+    return _verify_batch_jac(_lib().blsmi_g2pubs_verify_batch_jac, 288, 144, msgs, pks, sigs)
+
+
+def g1pubs_verify_batch_jac(msgs, pks, sigs):
+    return _verify_batch_jac(_lib().blsmi_g1pubs_verify_batch_jac, 144, 288, msgs, pks, sigs)
+
+
+def g1pubs_verify_with_domain_batch_jac(msgs32, domain8, pks, sigs):
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n)
+    d = _u8(domain8, 8)
+    p, pp = _j64(pks, 144 * n)
+    s, ps = _j64(sigs, 288 * n)
+    ok = np.zeros(n, dtype=np.uint8)
+    _check(_lib().blsmi_g1pubs_verify_with_domain_batch_jac(_p8(buf), _p8(d), pp, ps, _p8(ok), None, C.c_size_t(n)), "verify_with_domain_batch_jac")
+    return ok.astype(bool)
+
+
+def _verify_aggregate_jac(fn, pkb, sgb, msgs, pks, sig):
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    p, pp = _j64(pks, pkb * n)
+    s, ps = _j64(sig, sgb)
+    ok = C.c_int(0)
+    _check(fn(_p8(buf), off.ctypes.data_as(_u64p), pp, ps, C.c_size_t(n), C.byref(ok)), "verify_aggregate_jac")
+    return bool(ok.value)
+
+
+def g2pubs_verify_aggregate_jac(msgs, pks, sig):
+    return _verify_aggregate_jac(_lib().blsmi_g2pubs_verify_aggregate_jac, 288, 144, msgs, pks, sig)
+
+
+def g1pubs_verify_aggregate_jac(msgs, pks, sig):
+    return _verify_aggregate_jac(_lib().blsmi_g1pubs_verify_aggregate_jac, 144, 288, msgs, pks, sig)
+
+
+def g1pubs_verify_aggregate_with_domain_jac(msgs32, domain8, pks, sig):
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n) if n else np.zeros(1, np.uint8)
+    d = _u8(domain8, 8)
+    p, pp = _j64(pks, 144 * n)
+    s, ps = _j64(sig, 288)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g1pubs_verify_aggregate_with_domain_jac(_p8(buf), _p8(d), pp, ps, C.c_size_t(n), C.byref(ok)), "verify_aggregate_with_domain_jac")
+    return bool(ok.value)
+
+
+def _verify_aggregate_common_jac(fn, pkb, sgb, msg, pks, sig, n):
+    m = _u8(bytes(msg) or b"\0")
+    p, pp = _j64(pks, pkb * n)
+    s, ps = _j64(sig, sgb)
+    ok = C.c_int(0)
+    _check(fn(_p8(m), C.c_size_t(len(msg)), pp, ps, C.c_size_t(n), C.byref(ok)), "verify_aggregate_common_jac")
+    return bool(ok.value)
+
+
+def g2pubs_verify_aggregate_common_jac(msg, pks, sig, n):
+    return _verify_aggregate_common_jac(_lib().blsmi_g2pubs_verify_aggregate_common_jac, 288, 144, msg, pks, sig, n)
+
+
+def g1pubs_verify_aggregate_common_jac(msg, pks, sig, n):
+    return _verify_aggregate_common_jac(_lib().blsmi_g1pubs_verify_aggregate_common_jac, 144, 288, msg, pks, sig, n)
+
+
+def g1pubs_verify_aggregate_common_with_domain_jac(msg32, domain8, pks, sig, n):
+    m, d = _u8(msg32, 32), _u8(domain8, 8)
+    p, pp = _j64(pks, 144 * n)
+    s, ps = _j64(sig, 288)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g1pubs_verify_aggregate_common_with_domain_jac(_p8(m), _p8(d), pp, ps, C.c_size_t(n), C.byref(ok)), "verify_aggregate_common_with_domain_jac")
+    return bool(ok.value)
+
+
+class PreparedKeysJac(PreparedKeys):
+    """PreparedKeys made from n in-memory G2 points (blsmi_g2_prepared_create_jac)"""
+
+    def __init__(self, g2_jac, n):  # (does not call the affine constructor)
+        a, pa = _j64(g2_jac, 288 * n)
+        h = C.c_void_p(0)
+        _check(_lib().blsmi_g2_prepared_create_jac(pa, C.c_size_t(n), C.byref(h)), "blsmi_g2_prepared_create_jac")
+        self.ptr, self.n = h.value, n
+
+
+def g2pubs_verify_batch_prepared_jac(msgs, prepared, key_idx, sigs):
+    """g2pubs.Verify x n over prepared keys, the signatures as in-memory G1 points"""
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    ptr = prepared.ptr if isinstance(prepared, PreparedKeys) else prepared
+    s, ps = _j64(sigs, 144 * n)
+    idx = None if key_idx is None else np.ascontiguousarray(key_idx, dtype=np.uint32)
+    ok = np.zeros(n, dtype=np.uint8)
+    _check(_lib().blsmi_g2pubs_verify_batch_prepared_jac(_p8(buf), off.ctypes.data_as(_u64p), C.c_void_p(ptr), None if idx is None else idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                        ps, _p8(ok), None, C.c_size_t(n)), "verify_batch_prepared_jac")
+    return ok.astype(bool)
+
+
+def g2pubs_verify_aggregate_prepared_jac(msgs, prepared, key_idx, sig):
+    n = len(msgs)
+    buf, off = _msgs(msgs)
+    ptr = prepared.ptr if isinstance(prepared, PreparedKeys) else prepared
+    s, ps = _j64(sig, 144)
+    idx = None if key_idx is None else np.ascontiguousarray(key_idx, dtype=np.uint32)
+    ok = C.c_int(0)
+    _check(_lib().blsmi_g2pubs_verify_aggregate_prepared_jac(_p8(buf), off.ctypes.data_as(_u64p), C.c_void_p(ptr), None if idx is None else idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                            ps, C.c_size_t(n), C.byref(ok)), "verify_aggregate_prepared_jac")
+    return bool(ok.value)

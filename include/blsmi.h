@@ -68,7 +68,8 @@ void blsmi_shutdown(void);
  * `int *bad` argument (a caller built against the 5-argument prototype of 0.1 must be rebuilt); 0.3 adds the *_dev forms of
  * mul / sum / msm / verify_aggregate and changes no existing prototype; 0.4 adds the prepared-key entry points.  Check the prefix
  * before binding by hand.  0.5 adds blsmi_trim / blsmi_held_bytes, the *_ex forms of mul / msm (per-call BLSMI_MUL_ANY_POINT),
- * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes. */
+ * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes.  0.6 adds the *_jac forms
+ * (the reference's in-memory Jacobian / Montgomery points at the boundary); no existing prototype changes. */
 const char *blsmi_version(void);
 
 /* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
@@ -253,6 +254,54 @@ int blsmi_g2pubs_verify_aggregate_prepared(const uint8_t *msgs, const uint64_t *
                                            const uint8_t sig[96], size_t n, int *ok);   /* messages, indices and signature in HOST memory */
 int blsmi_g2pubs_verify_aggregate_prepared_dev(const void *d_msgs, const void *d_off, const void *d_prepared, const void *d_key_idx,
                                                const uint8_t sig[96], size_t n, int *ok, void *stream);
+
+/* ---- the reference's in-memory points at the boundary (added in blsmi 0.6) ---------------------------------------------------
+ * The Go types hold their points in Jacobian coordinates and Montgomery limbs: Signature{s *bls.G1Projective}, PublicKey{p *bls.G2Projective}
+ * (g2pubs/bls.go:13-15, 53-55; swapped in g1pubs), G1Projective{x, y, z FQ} (g1.go:252-256), G2Projective{x, y, z FQ2} (g2.go:298-302),
+ * FQ2{c0, c1 FQ} (fq2.go:14-17), FQ{n FQRepr} (fq.go:11-13), FQRepr [6]uint64 little-endian (fqrepr.go:14), Montgomery form R = 2^384.  The
+ * affine entry points above make the shim run ToAffine() -- one Fq inversion per point, g1.go:322-340 -- and SerializeBytes() -- two MontReduce
+ * and a byte swap, g1.go:157-167 -- on a host core for every point: ~12 us each, 30-70x the device's cost of the whole verify.  The *_jac
+ * forms take the struct bytes AS THEY LIE:
+ *     G1 point = 18 x uint64 (x | y | z),            BLSMI_G1_JAC_BYTES = 144
+ *     G2 point = 36 x uint64 (x.c0 | x.c1 | y.c0 | y.c1 | z.c0 | z.c1), BLSMI_G2_JAC_BYTES = 288
+ * i.e. *(*[18]uint64)(unsafe.Pointer(sig.s)) -- one memcpy per point in the shim, nothing else -- and run ToAffine on the device (a wave
+ * whose 64 points all have z == 1, what Deserialize* leaves, skips the inversion like g2.go:368).  z == 0 is the point at infinity
+ * (G1Projective.IsZero g1.go:287-289): such a tuple gets verdict 0, so there are no inf_flags here.  The reference's arithmetic keeps every
+ * FQ below q (fq.go:37-45); a limb image that is NOT below q cannot come out of it and is read as 0, the way FQReprToFQ reads an invalid
+ * repr (fq.go:49-56).  Results are identical, bit for bit, to the affine entry points on ToAffine().SerializeBytes() of the same points.
+ * Arguments other than the points are as in the affine forms. */
+#define BLSMI_G1_JAC_BYTES 144
+#define BLSMI_G2_JAC_BYTES 288
+/* G?Projective.ToAffine().SerializeBytes() for n points: wire records (all zero for infinity), out_inf[i] = 1 for infinity (may be NULL) */
+int blsmi_g1_jac_to_affine_batch(const uint64_t *g1_jac /* n*18 */, uint8_t *out /* n*96 */, uint8_t *out_inf /* n */, size_t n);
+int blsmi_g2_jac_to_affine_batch(const uint64_t *g2_jac /* n*36 */, uint8_t *out /* n*192 */, uint8_t *out_inf /* n */, size_t n);
+/* bls.Pairing(p *G1Projective, q *G2Projective) (pairing.go:132-136) for n pairs; output as blsmi_pairing_batch */
+int blsmi_pairing_batch_jac(const uint64_t *g1_jac /* n*18 */, const uint64_t *g2_jac /* n*36 */, uint64_t *out_fq12 /* n*72 */, size_t n);
+/* AggregateSignatures / AggregatePublicKeys (g2pubs/bls.go:165-192): the sum of n in-memory points, handed back as an in-memory point with
+ * z = 1 -- (0, 1, 0), the reference's G?ProjectiveZero, for the point at infinity (*out_inf = 1; also for n = 0).  The points are added
+ * as they are (Jacobian + Jacobian, g1.go:400-470): no inversion but the one at the end. */
+int blsmi_g1_sum_jac(const uint64_t *g1_jac /* n*18 */, size_t n, uint64_t out_jac[18], int *out_inf);
+int blsmi_g2_sum_jac(const uint64_t *g2_jac /* n*36 */, size_t n, uint64_t out_jac[36], int *out_inf);
+/* g2pubs (PublicKey = G2Projective 36 x u64, Signature = G1Projective 18 x u64) */
+int blsmi_g2pubs_verify_batch_jac(const uint8_t *msgs, const uint64_t *off, const uint64_t *pks /* n*36 */, const uint64_t *sigs /* n*18 */,
+                                  uint8_t *ok /* n, may be NULL */, uint8_t *ok_bitmap /* ceil(n/8), may be NULL */, size_t n);
+int blsmi_g2pubs_verify_aggregate_jac(const uint8_t *msgs, const uint64_t *off, const uint64_t *pks /* n*36 */, const uint64_t sig[18], size_t n, int *ok);
+int blsmi_g2pubs_verify_aggregate_common_jac(const uint8_t *msg, size_t msg_len, const uint64_t *pks /* n*36 */, const uint64_t sig[18], size_t n, int *ok);
+/* g1pubs (PublicKey = G1Projective 18 x u64, Signature = G2Projective 36 x u64) */
+int blsmi_g1pubs_verify_batch_jac(const uint8_t *msgs, const uint64_t *off, const uint64_t *pks /* n*18 */, const uint64_t *sigs /* n*36 */,
+                                  uint8_t *ok, uint8_t *ok_bitmap, size_t n);
+int blsmi_g1pubs_verify_with_domain_batch_jac(const uint8_t *msgs32, const uint8_t domain[8], const uint64_t *pks /* n*18 */, const uint64_t *sigs /* n*36 */,
+                                              uint8_t *ok, uint8_t *ok_bitmap, size_t n);
+int blsmi_g1pubs_verify_aggregate_jac(const uint8_t *msgs, const uint64_t *off, const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
+int blsmi_g1pubs_verify_aggregate_with_domain_jac(const uint8_t *msgs32, const uint8_t domain[8], const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
+int blsmi_g1pubs_verify_aggregate_common_jac(const uint8_t *msg, size_t msg_len, const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
+int blsmi_g1pubs_verify_aggregate_common_with_domain_jac(const uint8_t msg32[32], const uint8_t domain[8], const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
+/* prepared keys (see above) made from, and verified against, in-memory points */
+int blsmi_g2_prepared_create_jac(const uint64_t *g2_jac /* n*36 */, size_t n, void **handle);
+int blsmi_g2pubs_verify_batch_prepared_jac(const uint8_t *msgs, const uint64_t *msg_off, const void *d_prepared, const uint32_t *key_idx /* n, may be NULL */,
+                                           const uint64_t *sigs /* n*18 */, uint8_t *ok, uint8_t *ok_bitmap, size_t n);
+int blsmi_g2pubs_verify_aggregate_prepared_jac(const uint8_t *msgs, const uint64_t *msg_off, const void *d_prepared, const uint32_t *key_idx /* n, may be NULL */,
+                                               const uint64_t sig[18], size_t n, int *ok);
 
 /* Multi-GPU VerifyAggregate: each rank computes the product of its shard's Miller loops
  * prod_i ML(H(m_i), pk_i) (no final exponentiation) as one Fq12 in the wire format; the ranks all-gather
