@@ -52,10 +52,11 @@ BYTES = {"pairing": 864,           # 96 B G1 + 192 B G2 in, 576 B Fq12 out
          "g2pubs_aggregate": 224, "g1pubs_aggregate": 128}   # 32-byte message + key in
 # integer-VALU issue ceiling: 1 024 SIMDs x 64 lanes per wave-instruction / 4 cycles x clock (the int32 / v_mad_*64 rate, tools/ubench*)
 SIMDS, LANES, CYCLES_PER_VALU, CLOCK_GHZ = 1024, 64, 4.0, 2.4
-# measured ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip, profiles/r01_ubench2_fmul_15x27.log), scaled by
-# the multiply-add count of the 14x28-limb core the pairing kernels use since round 4 (2 x 196 against 2 x 225; tools/ubench_core28.hip)
-VALU_PEAK_GMULS = 61.2 * 225 / 196
-VALU_PEAK_2WAVE_GMULS = 56.7 * 225 / 196
+# measured ceiling of the 15x27-limb Montgomery multiplication core (tools/ubench2.hip, profiles/r01_ubench2_fmul_15x27.log), carried to the
+# 14x28-limb core the pairing kernels use since round 4 by the MEASURED time ratio of the two cores (tools/ubench_core28.hip)
+CORE28_OVER_CORE27 = 3236.0 / 3738.2      # measured: lane-pair Fq2 product, two waves per SIMD, dependent chain -- profiles/r04_ubench_core28.log (196 / 225 = 0.871 by MAC count)
+VALU_PEAK_GMULS = 61.2 / CORE28_OVER_CORE27
+VALU_PEAK_2WAVE_GMULS = 56.7 / CORE28_OVER_CORE27
 FQ_MULS_PER_PAIRING = 14600        # SURVEY 8d optimised estimate: the nominal work unit of `valu.nominal`
 R_ORDER = 52435875175126190479447740508185965837690552500527637822603658699938581184513
 
@@ -84,6 +85,45 @@ def profile_counters():
                 "stale": (dig != source_digest()) if dig else True, "kernels": j["kernels"]}
     except (OSError, ValueError, KeyError):
         return {"file": None, "stale": None, "kernels": {}}
+
+
+def isa_mix():
+    """the committed static instruction mix by encoding of the pairing units + the measured cycles per encoding class (tools/isa_mix.py)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_mix.json")))
+    if not files:
+        return None
+    try:
+        j = json.load(open(files[-1])); j["file"] = os.path.relpath(files[-1], ROOT)
+        return j
+    except (OSError, ValueError):
+        return None
+
+
+def valu_mix_floor(ctr, mix, kernel_of_unit, grid, n):
+    """Mix-weighted minimum time of the pairing kernels: sum over encoding classes of executed wave-instructions x measured cycles per
+    instruction of that class (two waves per SIMD), spread over the chip's SIMDs.  Executed counts: SQ_INSTS_VALU (all) and
+    SQ_INSTS_VALU_INT64 (the 64-bit integer ops: the multiply-adds and column shifts) of the committed PMC pass; the remainder is split by
+    the unit's static encoding ratio (tools/isa_mix.py says what that assumes).  Returns {kernel: {...}}, total minimum ms -- or None."""
+    if not mix:
+        return None
+    cyc = mix["cycles_per_wave_instruction_per_simd"]
+    out, total = {}, 0.0
+    for unit, kernel in kernel_of_unit.items():
+        c = counter_of(ctr, kernel, grid)
+        u = mix["units"].get(unit)
+        if "SQ_INSTS_VALU" not in c or not u:
+            return None
+        tot = c["SQ_INSTS_VALU"] * (n / 65536.0)
+        dyn = "SQ_INSTS_VALU_INT64" in c
+        w64 = (c["SQ_INSTS_VALU_INT64"] * (n / 65536.0)) if dyn else tot * u["static_share_w64"]
+        rest = max(0.0, tot - w64)
+        sp = u["non_w64_split"]
+        cycles = w64 * cyc["w64"] + rest * (sp["vop3"] * cyc["vop3"] + sp["lit"] * cyc["lit"] + sp["e32"] * cyc["e32"])
+        ms = cycles / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+        out[kernel] = {"wave_instructions": round(tot), "w64": round(w64), "w64_source": "SQ_INSTS_VALU_INT64" if dyn else "static share (no INT64 counter in the PMC file)",
+                       "w64_share": round(w64 / tot, 4) if tot else None, "mean_cycles_per_instruction": round(cycles / tot, 3) if tot else None, "min_ms": round(ms, 3)}
+        total += ms
+    return out, total
 
 
 def counter_of(ctr, kernel, grid=None):
@@ -190,6 +230,16 @@ def profiled(lib, fn):
     return read_profile(lib)
 
 
+def hbm_traffic(c, scale=1.0):
+    """HBM bytes per launch from one kernel's PMC record: (2 x FETCH_SIZE + WRITE_SIZE) x 1024.  On gfx950 FETCH_SIZE (derived from
+    TCC_EA0_RDREQ, which counts a 128-byte request as 64) reports HALF of the bytes read; WRITE_SIZE is exact.  Calibrated on this chip
+    with a scratch pattern of known size (tools/profile_tcc.sh, profiles/r04_tcc_summary.txt) and prescribed by MI355X_MICROARCH.md.
+    Returns (corrected, raw FETCH_SIZE + WRITE_SIZE as rocprofv3 prints them), or (None, None)."""
+    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+        return None, None
+    return (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * scale, (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * scale
+
+
 def roofline_of(prof, units, bytes_per_unit, ctr, grid_of=None):
     """roofline object of one leg: dominant kernel of `prof`, algorithmic bytes / its duration vs the HBM peak"""
     if not prof:
@@ -205,9 +255,9 @@ def roofline_of(prof, units, bytes_per_unit, ctr, grid_of=None):
         recs = [r for r in ctr["kernels"][dom]["by_grid"].values() if "avg_ns" in r]
         if recs:
             c = min(recs, key=lambda r: abs(r["avg_ns"] / 1e6 - per_launch_ms))
-    traffic = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+    traffic, traffic_raw = hbm_traffic(c)
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 8),
-            "traffic": traffic, "algorithmic_bytes_per_launch": algo, "bytes_per_unit": bytes_per_unit, "units_per_launch": units,
+            "traffic": traffic, "traffic_raw": traffic_raw, "algorithmic_bytes_per_launch": algo, "bytes_per_unit": bytes_per_unit, "units_per_launch": units,
             "kernel_ms": round(per_launch_ms, 4), "kernel_launches": launches,
             "all_kernels_ms": {k: round(v[0], 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:10]},
             "rocprof_avg_ms": round(c["avg_ns"] / 1e6, 4) if "avg_ns" in c else None}
@@ -295,7 +345,9 @@ def cpu_aggregate(engine, group, m=1024):
     pks = [allpk[i * pkb:(i + 1) * pkb].tobytes() for i in range(m)]
     sig = bytes(agg)
     cores = usable_cores()
-    t0 = time.time(); ok1 = o.verify_aggregate(sig, pks[:16], msgs[:16]); per = (time.time() - t0) / 17
+    # one core: a 16-signer prefix (its verdict is False: the signature is the aggregate of all m) costs 16 hashes + 17 pairings = 16 signers' worth
+    # of work plus the signature side's pairing: signatures/s on one core = 16 / its time (the extra pairing makes it ~6 % pessimistic)
+    t0 = time.time(); ok1 = o.verify_aggregate(sig, pks[:16], msgs[:16]); per = (time.time() - t0) / 16
     t0 = time.time()
     with ThreadPoolExecutor(cores) as ex:
         oks = list(ex.map(lambda k: o.verify_aggregate(sig, pks, msgs), range(cores)))
@@ -319,12 +371,13 @@ def _roof_small(r, full=False):
     """the roofline object of a leg, cut to what the contract names (bound, achieved, peak, unit, frac, traffic + the kernel it is about)"""
     if not isinstance(r, dict):
         return None
-    keys = ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch") if full else ("kernel", "kernel_ms", "frac", "traffic")
+    keys = ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "traffic_raw", "algorithmic_bytes_per_launch") if full else ("kernel", "kernel_ms", "frac", "traffic")
     o = _pick(r, keys)
     if isinstance(o.get("kernel_ms"), dict):                                # headline: both pairing kernels -> the dominant one's duration
         o["kernel_ms"] = r["kernel_ms"].get(r.get("kernel"))
-    if isinstance(o.get("traffic"), float):
-        o["traffic"] = int(o["traffic"])
+    for k in ("traffic", "traffic_raw"):
+        if isinstance(o.get(k), float):
+            o[k] = int(o[k])
     return o
 
 
@@ -380,7 +433,7 @@ def compact_line(d, detail_file=None):
     if "cpu_baseline" in d:
         line["cpu_baseline"] = _cpu_small(d["cpu_baseline"], full=True)
     v = d.get("valu") or {}
-    line["valu"] = _pick(v, ("frac", "lane_instructions_per_pairing", "achieved", "peak", "unit"))
+    line["valu"] = _pick(v, ("frac", "frac_mix", "lane_instructions_per_pairing", "achieved", "peak", "unit"))
     line["counters"] = _pick(d.get("counters", {}), ("file", "stale"))
     line["self_check"] = _pick(d.get("self_check", {}), ("rows_per_device", "passed"))
     line["configs"] = compact_configs(d)
@@ -982,17 +1035,33 @@ def main():
         ctr = E.ctr
         roof = roofline_of({k: [v[0] / max(1, v[1]), 1] for k, v in prof.items()}, n, BYTES["pairing"], ctr, lambda k: grid)
         if roof:
-            roof["traffic_unit"] = "bytes per launch: rocprofv3 FETCH_SIZE + WRITE_SIZE (separate --pmc passes) of %s" % ctr["file"]
+            roof["traffic_unit"] = ("bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 from the separate rocprofv3 --pmc passes of %s -- FETCH_SIZE counts half of the bytes read on "
+                                    "gfx950 (calibration: profiles/r04_tcc_summary.txt; MI355X_MICROARCH.md); traffic_raw = FETCH_SIZE + WRITE_SIZE as printed" % ctr["file"])
             roof["kernel_ms"] = {kname["ml"]: round(ml_ms, 3), kname["fe"]: round(fe_ms, 3)}
             tr = {}
             for k in kname.values():
                 c = counter_of(ctr, k, grid)
-                tr[k] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 * (n / 65536.0) if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+                tr[k] = hbm_traffic(c, n / 65536.0)[0]
             roof["traffic_all"] = tr
             roof["note"] = "864 algorithmic bytes per pairing: compute-bound by construction (SURVEY 8d); see valu"
         valu_insts = [counter_of(ctr, kname[k], grid).get("SQ_INSTS_VALU") for k in ("ml", "fe")]
         lane_instr = (sum(valu_insts) * LANES / 65536.0) if all(v is not None for v in valu_insts) else None
         issue_peak = SIMDS * LANES / CYCLES_PER_VALU * CLOCK_GHZ * 1e9       # lane-instructions per second per GPU
+        mix = isa_mix()
+        unit_of = {"k_pairing_pair.hip": kname["ml"], "k_fe_pair.hip": kname["fe"]}
+        mixed = valu_mix_floor(ctr, mix, unit_of, grid, n) if suffix else None
+        if mixed:
+            per_k, floor_ms = mixed
+            meas = {kname["ml"]: ml_ms, kname["fe"]: fe_ms}
+            for k in per_k:
+                per_k[k]["measured_ms"] = round(meas[k], 3)
+                per_k[k]["frac"] = round(per_k[k]["min_ms"] / meas[k], 4) if meas[k] else None
+            mix_obj = {"frac_mix": round(floor_ms / (ml_ms + fe_ms), 4) if (ml_ms + fe_ms) else None, "min_ms": round(floor_ms, 3), "measured_kernel_ms": round(ml_ms + fe_ms, 3),
+                       "kernels": per_k, "cycles_per_class": mix["cycles_per_wave_instruction_per_simd"], "static_mix_file": mix["file"],
+                       "note": "minimum time = sum over encoding classes of executed wave-instructions x measured cycles per class (%s) / %d SIMDs / %.1f GHz; "
+                               "the flat `frac` charges every instruction %.0f cycles" % (mix["cycles_source"], SIMDS, CLOCK_GHZ, CYCLES_PER_VALU)}
+        else:
+            mix_obj = None
         line = {
             "metric": "BLS12-381 pairings/sec (batch verify)", "value": round(value, 1), "unit": "pairings/s",
             "n_gpus": total_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -1012,6 +1081,7 @@ def main():
                      "achieved": None if lane_instr is None else round(per_gpu * lane_instr / 1e12, 3),
                      "peak": round(issue_peak / 1e12, 3), "unit": "T lane-instructions/s per GPU",
                      "frac": None if lane_instr is None else round(per_gpu * lane_instr / issue_peak, 4),
+                     "frac_mix": mix_obj["frac_mix"] if mix_obj else None, "mix": mix_obj,
                      "nominal": {"achieved": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9, 2), "peak": VALU_PEAK_GMULS, "unit": "G Fq-mul/s",
                                  "frac": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_GMULS, 4),
                                  "frac_of_2wave_per_simd_peak": round(per_gpu * FQ_MULS_PER_PAIRING / 1e9 / VALU_PEAK_2WAVE_GMULS, 4),

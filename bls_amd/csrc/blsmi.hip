@@ -55,6 +55,9 @@ namespace {
 // shard on its own host thread; the only exchanges are the pass/fail bitmap (RCCL all-reduce) and, for one n-way
 // VerifyAggregate, the per-device Fq12 partial products (RCCL all-gather) -- DESIGN.md section 5.
 std::mutex g_mu;
+// One split call at a time owns the per-device exchange buffers (Device::coll); a split call occupies every device anyway.  Lock order:
+// g_coll_mu BEFORE g_mu (blsmi_trim only try_locks it while holding g_mu).
+std::mutex g_coll_mu;
 std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
@@ -201,10 +204,13 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    bool load() {
+    bool load(const char* path = nullptr) {
         if (h) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
-        if (!h) { fprintf(stderr, "blsmi: cannot load librccl (%s): multi-GPU sharding needs RCCL\n", dlerror()); return false; }
+        // path: BLSMI_RCCL_PATH (read at initialisation) -- a process without torch (the Go deployment) may have no librccl on its loader
+        // path; tried first when given, and its failure is reported rather than papered over by the defaults
+        if (path && path[0]) { h = dlopen(path, RTLD_NOW | RTLD_GLOBAL); if (!h) { fprintf(stderr, "blsmi: cannot load BLSMI_RCCL_PATH=%s (%s)\n", path, dlerror()); return false; } }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { if (h) break; h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); }
+        if (!h) { fprintf(stderr, "blsmi: cannot load librccl (%s): multi-GPU sharding needs RCCL (BLSMI_RCCL_PATH names a copy)\n", dlerror()); return false; }
 #define BLSMI_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(h, "nccl" #f)); if (!f) { fprintf(stderr, "blsmi: librccl lacks nccl" #f "\n"); return false; }
         BLSMI_SYM(CommInitAll) BLSMI_SYM(CommDestroy) BLSMI_SYM(AllReduce) BLSMI_SYM(AllGather) BLSMI_SYM(GroupStart) BLSMI_SYM(GroupEnd) BLSMI_SYM(GetErrorString)
 #undef BLSMI_SYM
@@ -280,6 +286,47 @@ inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
 inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }
 inline bool mul_subgroup() { return !tl_mul_any && g_mul_subgroup.load(std::memory_order_relaxed); }
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
+// ---- the environment is read ONCE, at initialisation (under g_mu), never from an entry point ---------------------------------------
+// getenv racing a setenv in another thread is undefined (glibc), and a variable read per call silently changes what a concurrent caller
+// gets.  Every BLSMI_* variable is therefore read here and nowhere else; what the A/B tests flip at run time are the three
+// atomics below, through blsmi_set_option.  The variables are listed in include/blsmi.h ("Environment").
+struct EnvCfg {
+    size_t swu_wave_max = 512;          // BLSMI_SWU_WAVE_MAX: the smallest hashes / decompressions run one WAVE per field exponentiation up to here (measured: 0.68 against 0.96 ms at 512 messages, 1.18 against 0.98 at 1 024)
+    bool hash_g1_split = true;          // BLSMI_HASH_G1_SPLIT
+    bool hash_g2_pair = true;           // BLSMI_HASH_G2_PAIR=0 keeps the one-lane HashG2 kernel
+    unsigned hash_g2_pair_redo_every = 0;   // BLSMI_HASH_G2_PAIR_REDO_EVERY (tests: exercise the redo pass)
+    bool cofac2_pair = true;            // BLSMI_COFAC2_PAIR=0 keeps the fused one-lane HashG2WithDomain kernel
+    long long sig_side_max = -1;        // BLSMI_SIG_SIDE_MAX (-1: the per-package defaults)
+    size_t side_max = 131072;           // BLSMI_SIDE_MAX
+    size_t fixed_wave_max = 2048;       // BLSMI_FIXED_WAVE_MAX
+    size_t msm_bucket_min = (size_t)1 << 17;   // BLSMI_MSM_BUCKET_MIN
+    size_t combine_max = 1024; int combine_wait_us = 150, combine_inflight_max = 2; bool combine_debug = false;   // BLSMI_COMBINE_*
+    char rccl_path[512] = {0};          // BLSMI_RCCL_PATH: librccl for a process that has none mapped yet (a Go binary has no torch to bring it)
+} g_env;
+std::atomic<bool> g_agg_cofactor_pow{true};    // BLSMI_AGG_COFACTOR_POW / blsmi_set_option("agg_cofactor_pow")
+std::atomic<bool> g_msm_sort{true};            // BLSMI_MSM_SORT / blsmi_set_option("msm_sort")
+std::atomic<bool> g_dup_force_sort{false};     // BLSMI_DUP_FORCE_SORT / blsmi_set_option("dup_force_sort"): test hook, the duplicate screen's fallback on every call
+void load_env() {                       // caller holds g_mu; runs once per initialisation
+    auto num = [](const char* name, size_t dflt) { const char* v = getenv(name); return v ? (size_t)strtoull(v, nullptr, 10) : dflt; };
+    auto flag = [](const char* name, bool dflt) { const char* v = getenv(name); return v ? atoi(v) != 0 : dflt; };
+    g_env.swu_wave_max = num("BLSMI_SWU_WAVE_MAX", 512);
+    g_env.hash_g1_split = flag("BLSMI_HASH_G1_SPLIT", true);
+    g_env.hash_g2_pair = flag("BLSMI_HASH_G2_PAIR", true);
+    g_env.hash_g2_pair_redo_every = (unsigned)num("BLSMI_HASH_G2_PAIR_REDO_EVERY", 0);
+    g_env.cofac2_pair = flag("BLSMI_COFAC2_PAIR", true);
+    { const char* v = getenv("BLSMI_SIG_SIDE_MAX"); g_env.sig_side_max = v ? atoll(v) : -1LL; }
+    g_env.side_max = num("BLSMI_SIDE_MAX", 131072);
+    g_env.fixed_wave_max = num("BLSMI_FIXED_WAVE_MAX", 2048);
+    g_env.msm_bucket_min = num("BLSMI_MSM_BUCKET_MIN", (size_t)1 << 17);
+    g_env.combine_max = num("BLSMI_COMBINE_MAX", 1024);
+    g_env.combine_wait_us = (int)num("BLSMI_COMBINE_WAIT_US", 150);
+    g_env.combine_inflight_max = std::max(1, (int)num("BLSMI_COMBINE_INFLIGHT", 2));
+    g_env.combine_debug = getenv("BLSMI_COMBINE_DEBUG") != nullptr;
+    { const char* v = getenv("BLSMI_RCCL_PATH"); snprintf(g_env.rccl_path, sizeof g_env.rccl_path, "%s", v ? v : ""); }
+    { const char* v = getenv("BLSMI_AGG_COFACTOR_POW"); g_agg_cofactor_pow = !(v && v[0] == '0'); }
+    { const char* v = getenv("BLSMI_MSM_SORT"); g_msm_sort = !(v && v[0] == '0'); }
+    g_dup_force_sort = getenv("BLSMI_DUP_FORCE_SORT") != nullptr;
+}
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
     if (g_ready) return BLSMI_OK;
@@ -290,6 +337,7 @@ int ensure_init_list(const int* devs, int ndev) {
         if (devs[i] < 0 || devs[i] >= count) return BLSMI_E_ARG;
         for (int j = 0; j < i; j++) if (devs[j] == devs[i] && !g_alias) return BLSMI_E_ARG;
     }
+    load_env();
     const char* lay = getenv("BLSMI_LAYOUT");
     g_pair_layout = !(lay && std::string(lay) == "single");      // default: lane-pair kernels; BLSMI_LAYOUT=single selects one tuple per lane
     if (const char* ns = getenv("BLSMI_STREAMS")) { int v = atoi(ns); g_nctx = v < 1 ? 1 : (v > MAX_CTX ? MAX_CTX : v); }
@@ -314,7 +362,7 @@ int ensure_init_list(const int* devs, int ndev) {
         for (int i = 0; i < ndev; i++) { HIPCHK(hipSetDevice(g_dev[i].id)); HIPCHK(hipStreamCreateWithFlags(&g_dev[i].coll_stream, hipStreamNonBlocking)); }
         g_have_comm = ndev > 1;
     } else if (ndev > 1 || g_force_rccl) {
-        if (!g_rccl.load()) return BLSMI_E_RCCL;
+        if (!g_rccl.load(g_env.rccl_path)) return BLSMI_E_RCCL;
         ncclComm_t comms[MAX_DEV];
         NCCLCHK(g_rccl.CommInitAll(comms, ndev, devs));
         for (int i = 0; i < ndev; i++) {
@@ -583,6 +631,7 @@ BLSMI_API void blsmi_shutdown(void) {
 // keep_bytes_per_context (0: all of them) and the stream-ordered pool's cache.  Contexts serving a call are skipped.  Tables the caller
 // created (blsmi_g2_prepared_create) and the per-device constants are not touched.
 BLSMI_API int blsmi_trim(size_t keep_bytes_per_context, size_t* freed_bytes) {
+    std::unique_lock<std::mutex> coll_lk(g_coll_mu, std::try_to_lock);
     std::unique_lock<std::mutex> lk(g_mu);
     size_t freed = 0;
     if (freed_bytes) *freed_bytes = 0;
@@ -596,9 +645,10 @@ BLSMI_API int blsmi_trim(size_t keep_bytes_per_context, size_t* freed_bytes) {
             if (c.ws.cap > keep_bytes_per_context) { freed += c.ws.cap; c.ws.release(); }
             freed += c.arena.trim(keep_bytes_per_context > c.ws.cap ? keep_bytes_per_context - c.ws.cap : 0);
         }
-        bool any_busy = false;
-        for (int i = 0; i < MAX_CTX; i++) any_busy |= dv.ctx[i].busy;
-        if (!any_busy && dv.coll.cap > keep_bytes_per_context) { freed += dv.coll.cap; dv.coll.release(); }
+        // the exchange buffers belong to whichever split call holds g_coll_mu -- for its whole duration, also in the windows where it holds
+        // no context lease (after coll_reserve_all, during the collectives and the copy of the bitmap: ADVICE r04).  try_lock: a trim that
+        // meets a split call in flight leaves the exchange buffers alone.
+        if (coll_lk.owns_lock() && dv.coll.cap > keep_bytes_per_context) { freed += dv.coll.cap; dv.coll.release(); }
         hipMemPool_t pool;
         if (hipDeviceGetDefaultMemPool(&pool, dv.id) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
     }
@@ -757,6 +807,19 @@ BLSMI_API int blsmi_set_quad_threshold(size_t max_tuples) {
 }
 BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
     g_mul_subgroup.store(on != 0);
+    return BLSMI_OK;
+}
+// Run-time switches of code paths that produce identical results (A/B tests, soaks): name = "agg_cofactor_pow" (large g2pubs aggregates
+// raise their Miller product to 1 - x instead of clearing n hash points), "msm_sort" (device radix sort against the exact histogram passes),
+// "dup_force_sort" (the duplicate screen's host-sort fallback on every call).  value: 0 / 1.  Atomic: a call in flight sees the old or the new
+// value, never a torn one; the verdicts do not depend on them.
+BLSMI_API int blsmi_set_option(const char* name, long long value) {
+    if (!name) return BLSMI_E_ARG;
+    const std::string n(name);
+    if (n == "agg_cofactor_pow") g_agg_cofactor_pow.store(value != 0);
+    else if (n == "msm_sort") g_msm_sort.store(value != 0);
+    else if (n == "dup_force_sort") g_dup_force_sort.store(value != 0);
+    else return BLSMI_E_ARG;
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_set_profiling(int on) {
@@ -930,8 +993,7 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
         // the generator as the common multiplicand (PrivToPub): the device's fixed-base table -- 32 mixed additions, no doublings.
         // Small calls: one scalar per wave (the 32 table entries meet in a tree of additions across the lanes).
         const i32* table = PB == 96 ? g_gens.fixed1 : g_gens.fixed2;
-        static const size_t wave_max = []{ const char* v = getenv("BLSMI_FIXED_WAVE_MAX"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)2048; }();
-        if (m <= wave_max && m <= g_lat_max) {
+        if (m <= g_env.fixed_wave_max && m <= g_lat_max) {
             prof_mark(PB == 96 ? "k_g1_mul_fixed_wave" : "k_g2_mul_fixed_wave");
             if (PB == 96) hipLaunchKernelGGL(k_g1_mul_fixed_wave, dim3((unsigned)m), dim3(WG), 0, s, table, d_scalars, d_out, d_inf, m);
             else hipLaunchKernelGGL(k_g2_mul_fixed_wave, dim3((unsigned)m), dim3(WG), 0, s, table, d_scalars, d_out, d_inf, m);
@@ -1242,10 +1304,10 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     DBuf raw, rec, hist, offs, cursor, idx, buckets, ch0, ch1, dmax, cls, perm;
     HIPCHK(raw.alloc(sizeof(i32) * RAWW * n, s)); HIPCHK(rec.alloc(32 * n, s));
     HIPCHK(hist.alloc(sizeof(u32) * nb, s)); HIPCHK(offs.alloc(sizeof(u32) * nb, s)); HIPCHK(cursor.alloc(sizeof(u32) * nb, s)); HIPCHK(dmax.alloc(sizeof(u32), s));
-    // grouping the 16 n items by bucket: a device radix sort (msm.inc: k_msm_items, k_util.hip); BLSMI_MSM_SORT=0 (read per call: the tests
-    // cross-check the two) takes the exact histogram + scan + atomic scatter instead
+    // grouping the 16 n items by bucket: a device radix sort (msm.inc: k_msm_items, k_util.hip); BLSMI_MSM_SORT=0 at start-up or
+    // blsmi_set_option("msm_sort", 0) (the tests cross-check the two) takes the exact histogram + scan + atomic scatter instead
     const size_t nitems = (size_t)16 * n;
-    const bool sort_mode = nitems < ((size_t)1 << 31) && []{ const char* v = getenv("BLSMI_MSM_SORT"); return !(v && v[0] == '0'); }();   // (the sort counts its items in an int: 2^27 points and beyond take the exact passes)
+    const bool sort_mode = nitems < ((size_t)1 << 31) && g_msm_sort.load(std::memory_order_relaxed);   // (the sort counts its items in an int: 2^27 points and beyond take the exact passes)
     DBuf skey[2], sval[2];
     if (sort_mode) { for (int i = 0; i < 2; i++) { HIPCHK(skey[i].alloc(sizeof(u32) * nitems, s)); HIPCHK(sval[i].alloc(sizeof(u32) * nitems, s)); } }
     else HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s));
@@ -1357,7 +1419,7 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
 template <int PB, int W, class KM, class K0, class K1, class K2>
 static int msm_dev_core(const MsmKernels& mk, KM kmul, K0 k0, K1 k1, K2 kfinal, const u8* d_pts, const u8* d_scalars, size_t n, u8* d_out, i32* d_flag, hipStream_t s,
                         const std::function<int()>& points_arrive = {}) {
-    static const size_t bucket_min = []{ const char* v = getenv("BLSMI_MSM_BUCKET_MIN"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)1 << 17; }();
+    const size_t bucket_min = g_env.msm_bucket_min;
     int rc = BLSMI_E_SKEW;
     bool arrived = !points_arrive;                                         // the host form hands over its copy of the points: issued at the latest before the first kernel that reads them
     auto arrive_once = [&]() -> int { if (arrived) return BLSMI_OK; arrived = true; return points_arrive(); };

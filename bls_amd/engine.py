@@ -98,6 +98,11 @@ def set_quad_threshold(max_tuples):
     _check(_lib().blsmi_set_quad_threshold(C.c_size_t(int(max_tuples))), "blsmi_set_quad_threshold")
 
 
+def set_option(name, value):
+    """run-time switch between code paths with identical results: "agg_cofactor_pow", "msm_sort", "dup_force_sort" (include/blsmi.h)"""
+    _check(_lib().blsmi_set_option(name.encode(), C.c_longlong(int(value))), "blsmi_set_option(%s)" % name)
+
+
 def set_mul_assume_subgroup(on=True):
     """scalar multiplications through the curve endomorphisms (multiplicands in the prime-order subgroup; the default) or,
     with on=False, the plain windowed ladder that serves every curve point"""

@@ -10,7 +10,7 @@ pairing and hash operation runs in the HIP kernels of libblsmi.so (no CPU fallba
 plus VerifyBatch, the batch form the one-tuple-per-call Go API lacks.
 """
 from . import engine
-from ._groups import DeserializeError, Point, point_sum  # noqa: F401
+from ._groups import DeserializeError, Point, all_in_memory, point_sum  # noqa: F401
 
 SIG_GROUP, PK_GROUP = 2, 1
 
@@ -23,7 +23,7 @@ class Signature:
         return self.s.serialize()
 
     def Copy(self):
-        return Signature(Point(self.s.raw, SIG_GROUP))
+        return Signature(self.s.copy())
 
     def Aggregate(self, other):               # g1pubs/bls.go:174-177
         self.s = point_sum([self.s, other.s], SIG_GROUP)
@@ -33,9 +33,13 @@ class Signature:
             return False
         if self.s.infinity or any(p.p.infinity for p in pubKeys):
             return False                       # the reference panics in MillerLoop on infinity; defined as false here
+        if all_in_memory([p.p for p in pubKeys] + [self.s]):   # the points as the Go values hold them: ToAffine on the device
+            return engine.g1pubs_verify_aggregate_jac(msgs, b"".join(p.p.jac for p in pubKeys), self.s.jac)
         return engine.g1pubs_verify_aggregate(msgs, b"".join(p.p.raw for p in pubKeys), self.s.raw)
 
     def VerifyAggregateCommon(self, pubKeys, msg):
+        if all_in_memory([p.p for p in pubKeys] + [self.s]):   # key sum and Verify in one library call, Jacobian points summed as they are
+            return engine.g1pubs_verify_aggregate_common_jac(msg, b"".join(p.p.jac for p in pubKeys), self.s.jac, len(pubKeys))
         return Verify(msg, AggregatePublicKeys(pubKeys), self)
 
 
@@ -47,7 +51,7 @@ class PublicKey:
         return self.p.serialize()
 
     def Copy(self):
-        return PublicKey(Point(self.p.raw, PK_GROUP))
+        return PublicKey(self.p.copy())
 
     def Equals(self, other):
         return self.p == other.p
@@ -62,6 +66,16 @@ def NewSignatureFromG2(raw192):
 
 def NewPublicKeyFromG1(raw96):
     return PublicKey(Point(raw96, PK_GROUP))
+
+
+def NewSignatureFromG2Projective(jac288):
+    """a Signature holding its point the way the reference's does (g1pubs/bls.go:13-15): the 288 bytes of a *bls.G2Projective"""
+    return Signature(Point(None, SIG_GROUP, jac=jac288))
+
+
+def NewPublicKeyFromG1Projective(jac144):
+    """g1pubs/bls.go:53-55: the 144 bytes of a *bls.G1Projective"""
+    return PublicKey(Point(None, PK_GROUP, jac=jac144))
 
 
 def DeserializeSignature(b96):
@@ -95,6 +109,9 @@ def VerifyBatch(msgs, pubs, sigs):
         raise ValueError("length mismatch")
     if n == 0:
         return []
+    if all_in_memory([p.p for p in pubs] + [s.s for s in sigs]):
+        ok, _ = engine.g1pubs_verify_batch_jac(msgs, b"".join(p.p.jac for p in pubs), b"".join(s.s.jac for s in sigs))
+        return [bool(x) for x in ok]
     flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
     ok, _ = engine.g1pubs_verify_batch(msgs, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
     return [bool(x) for x in ok]
@@ -142,6 +159,8 @@ def VerifyWithDomainBatch(msgs32, pubs, sigs, domain8):
     n = len(msgs32)
     if n == 0:
         return []
+    if all_in_memory([p.p for p in pubs] + [s.s for s in sigs]):
+        return [bool(x) for x in engine.g1pubs_verify_with_domain_batch_jac(msgs32, domain8, b"".join(p.p.jac for p in pubs), b"".join(s.s.jac for s in sigs))]
     flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
     ok = engine.g1pubs_verify_with_domain_batch(msgs32, domain8, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
     return [bool(x) for x in ok]
@@ -152,6 +171,8 @@ def VerifyWithDomain(m32, pub, sig, domain8):
 
 
 def VerifyAggregateCommonWithDomain(sig, pubKeys, msg32, domain8):
+    if all_in_memory([p.p for p in pubKeys] + [sig.s]):
+        return engine.g1pubs_verify_aggregate_common_with_domain_jac(msg32, domain8, b"".join(p.p.jac for p in pubKeys), sig.s.jac, len(pubKeys))
     return VerifyWithDomain(msg32, AggregatePublicKeys(pubKeys), sig, domain8)
 
 
@@ -160,6 +181,8 @@ def VerifyAggregateWithDomain(sig, pubKeys, msgs32, domain8):
         return False
     if sig.s.infinity or any(p.p.infinity for p in pubKeys):
         return False
+    if all_in_memory([p.p for p in pubKeys] + [sig.s]):
+        return engine.g1pubs_verify_aggregate_with_domain_jac(msgs32, domain8, b"".join(p.p.jac for p in pubKeys), sig.s.jac)
     return engine.g1pubs_verify_aggregate_with_domain(msgs32, domain8, b"".join(p.p.raw for p in pubKeys), sig.s.raw)
 
 

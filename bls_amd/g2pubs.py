@@ -11,7 +11,7 @@ plus VerifyBatch, the batch form the one-tuple-per-call Go API lacks, and Prepar
 through G2AffineToPrepared (g2.go:639-801) ONCE into tables resident on the device instead of on every Verify (pairing.go:140-147).
 """
 from . import engine
-from ._groups import DeserializeError, Point, point_sum  # noqa: F401
+from ._groups import DeserializeError, Point, all_in_memory, point_sum  # noqa: F401
 
 SIG_GROUP, PK_GROUP = 1, 2
 
@@ -24,7 +24,7 @@ class Signature:
         return self.s.serialize()
 
     def Copy(self):
-        return Signature(Point(self.s.raw, SIG_GROUP))
+        return Signature(self.s.copy())
 
     def Aggregate(self, other):               # g2pubs/bls.go:174-177
         self.s = point_sum([self.s, other.s], SIG_GROUP)
@@ -34,9 +34,13 @@ class Signature:
             return False
         if self.s.infinity or any(p.p.infinity for p in pubKeys):
             return False                       # the reference panics in MillerLoop on infinity; defined as false here
+        if all_in_memory([p.p for p in pubKeys] + [self.s]):   # the points as the Go values hold them: ToAffine on the device
+            return engine.g2pubs_verify_aggregate_jac(msgs, b"".join(p.p.jac for p in pubKeys), self.s.jac)
         return engine.g2pubs_verify_aggregate(msgs, b"".join(p.p.raw for p in pubKeys), self.s.raw)
 
     def VerifyAggregateCommon(self, pubKeys, msg):
+        if all_in_memory([p.p for p in pubKeys] + [self.s]):   # key sum and Verify in one library call, Jacobian points summed as they are
+            return engine.g2pubs_verify_aggregate_common_jac(msg, b"".join(p.p.jac for p in pubKeys), self.s.jac, len(pubKeys))
         return Verify(msg, AggregatePublicKeys(pubKeys), self)
 
 
@@ -48,7 +52,7 @@ class PublicKey:
         return self.p.serialize()
 
     def Copy(self):
-        return PublicKey(Point(self.p.raw, PK_GROUP))
+        return PublicKey(self.p.copy())
 
     def Equals(self, other):
         return self.p == other.p
@@ -63,6 +67,16 @@ def NewSignatureFromG1(raw96):
 
 def NewPublicKeyFromG2(raw192):
     return PublicKey(Point(raw192, PK_GROUP))
+
+
+def NewSignatureFromG1Projective(jac144):
+    """a Signature holding its point the way the reference's does (g2pubs/bls.go:13-15): the 144 bytes of a *bls.G1Projective"""
+    return Signature(Point(None, SIG_GROUP, jac=jac144))
+
+
+def NewPublicKeyFromG2Projective(jac288):
+    """g2pubs/bls.go:53-55: the 288 bytes of a *bls.G2Projective"""
+    return PublicKey(Point(None, PK_GROUP, jac=jac288))
 
 
 def DeserializeSignature(b48):
@@ -96,6 +110,9 @@ def VerifyBatch(msgs, pubs, sigs):
         raise ValueError("length mismatch")
     if n == 0:
         return []
+    if all_in_memory([p.p for p in pubs] + [s.s for s in sigs]):
+        ok, _ = engine.g2pubs_verify_batch_jac(msgs, b"".join(p.p.jac for p in pubs), b"".join(s.s.jac for s in sigs))
+        return [bool(x) for x in ok]
     flags = [(1 if p.p.infinity else 0) | (2 if s.s.infinity else 0) for p, s in zip(pubs, sigs)]
     ok, _ = engine.g2pubs_verify_batch(msgs, b"".join(p.p.bytes_or_zero() for p in pubs), b"".join(s.s.bytes_or_zero() for s in sigs), flags)
     return [bool(x) for x in ok]
@@ -106,7 +123,10 @@ class PreparedKeys:
 
     def __init__(self, pubs):
         self.n = len(pubs)
-        self._h = engine.PreparedKeys(b"".join(p.p.bytes_or_zero() for p in pubs), self.n)   # all-zero record = infinity: verdict False
+        if all_in_memory([p.p for p in pubs]):
+            self._h = engine.PreparedKeysJac(b"".join(p.p.jac for p in pubs), self.n)         # z == 0 = infinity: verdict False
+        else:
+            self._h = engine.PreparedKeys(b"".join(p.p.bytes_or_zero() for p in pubs), self.n)   # all-zero record = infinity: verdict False
 
     def Close(self):
         self._h.close()
@@ -125,6 +145,8 @@ def VerifyBatchPrepared(msgs, keys, key_idx, sigs):
         return []
     if any(not 0 <= int(k) < keys.n for k in key_idx):
         raise IndexError("key index out of range")
+    if all_in_memory([s.s for s in sigs]):
+        return [bool(x) for x in engine.g2pubs_verify_batch_prepared_jac(msgs, keys._h, key_idx, b"".join(s.s.jac for s in sigs))]
     flags = [2 if s.s.infinity else 0 for s in sigs]
     ok, _ = engine.g2pubs_verify_batch_prepared(msgs, keys._h, key_idx, b"".join(s.s.bytes_or_zero() for s in sigs), flags)
     return [bool(x) for x in ok]

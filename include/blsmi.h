@@ -48,7 +48,8 @@ int blsmi_init(int device);
  * per device).  Smaller calls go to the least busy device.  Must be the first call (or repeat the same ndev).
  * Environment: BLSMI_SHARDS (logical shards, default ndev; more shards than devices share devices),
  * BLSMI_SHARD_MIN (smallest batch that is split, default 8192), BLSMI_FORCE_RCCL=1 (build the communicator even
- * for one device).  librccl is loaded with dlopen only when ndev > 1 (or forced): BLSMI_E_RCCL if that fails. */
+ * for one device).  librccl is loaded with dlopen only when ndev > 1 (or forced) -- BLSMI_RCCL_PATH names the file to load when the
+ * process' loader path has none (a Go binary; under torch one is already mapped) --: BLSMI_E_RCCL if that fails. */
 int blsmi_init_devices(int ndev);
 /* TEST HOOK, not a deployment mode.  With BLSMI_DEVICE_ALIAS=0,0[,0,0] in the environment blsmi_init_devices builds that many LOGICAL
  * devices -- each with its own context pool, streams, generator tables and exchange buffer, as on an N-GPU node -- on the physical GPUs
@@ -113,6 +114,18 @@ int blsmi_set_quad_threshold(size_t max_tuples);
 enum { BLSMI_SHAPE_PAIRING = 0, BLSMI_SHAPE_MILLER_LOOP = 1, BLSMI_SHAPE_FINAL_EXP = 2, BLSMI_SHAPE_G2_PREPARE = 3, BLSMI_SHAPE_VERIFY = 4,
        BLSMI_SHAPE_SIGN = 5, BLSMI_SHAPE_VERIFY_DOMAIN = 6, BLSMI_SHAPE_POINT_ADD = 7 };
 int blsmi_prefer_cpu(int shape, size_t n);
+/* Environment.  Every BLSMI_* variable is read ONCE, when the library initialises (the first entry point, blsmi_init or blsmi_init_devices),
+ * never from an entry point afterwards: changing the environment of a running process changes nothing (and getenv racing setenv is undefined
+ * behaviour in a threaded host).  Deployment: BLSMI_STREAMS (call contexts per device, 4), BLSMI_SHARDS, BLSMI_SHARD_MIN, BLSMI_FORCE_RCCL,
+ * BLSMI_RCCL_PATH (the librccl to dlopen when several devices are driven -- a Go binary has no torch that maps one), BLSMI_ARENA_KEEP_MB,
+ * BLSMI_LAT_MAX / BLSMI_QUAD_MAX / BLSMI_QUAD_MIN (layout hand-overs; also blsmi_set_latency_threshold / _quad_threshold), BLSMI_MUL_GENERIC,
+ * BLSMI_COMBINE_MAX / _WAIT_US / _INFLIGHT / _DEBUG (merging of concurrent one-tuple Verify calls).  A/B switches between code paths with
+ * identical results: BLSMI_LAYOUT, BLSMI_GEN_LINES, BLSMI_HASH_G1_SPLIT, BLSMI_HASH_G2_PAIR, BLSMI_HASH_G2_PAIR_REDO_EVERY, BLSMI_COFAC2_PAIR,
+ * BLSMI_SWU_WAVE_MAX, BLSMI_SIG_SIDE_MAX, BLSMI_SIDE_MAX, BLSMI_FIXED_WAVE_MAX, BLSMI_MSM_BUCKET_MIN, and the three that can ALSO be
+ * switched while running (atomically; a call in flight sees the old or the new value), through blsmi_set_option(name, 0 / 1):
+ *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0).
+ * Test hook: BLSMI_DEVICE_ALIAS (above).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
+int blsmi_set_option(const char *name, long long value);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
 /* General form: with profiling on, every entry point records HIP events on its launch stream between its major kernels.  This
  * returns the calling thread's log since it last asked, as "kernel=ms;kernel=ms;..." in launch order (a name repeats when a

@@ -1086,6 +1086,10 @@ API void rc_g2_double(const u64 p[36], u64 out[36]) { g2_jac a, r; memcpy(&a, p,
 API void rc_g2_add(const u64 p[36], const u64 q[36], u64 out[36]) { g2_jac a, b, r; memcpy(&a, p, 288); memcpy(&b, q, 288); g2_add(&r, &a, &b); memcpy(out, &r, 288); }
 /* Jacobian -> affine big-endian bytes; returns 1 if infinity (bytes zeroed) */
 API int rc_g1_jac_to_affine_bytes(const u64 p[18], u8 out[96]) { g1_jac a; g1_aff r; memcpy(&a, p, 144); g1_to_affine(&r, &a); if (r.inf) { memset(out, 0, 96); return 1; } g1_write_affine(out, &r); return 0; }
+/* n points in one call (bench.py `marshal`: what the affine entry points cost a Go shim per point -- ToAffine g1.go:322-340 / g2.go:365-386 + SerializeBytes) */
+API void rc_g1_jac_to_affine_bytes_batch(const u64 *p, u8 *out, size_t n) { for (size_t i = 0; i < n; i++) rc_g1_jac_to_affine_bytes(p + 18 * i, out + 96 * i); }
+API int rc_g2_jac_to_affine_bytes(const u64 p[36], u8 out[192]);
+API void rc_g2_jac_to_affine_bytes_batch(const u64 *p, u8 *out, size_t n) { for (size_t i = 0; i < n; i++) rc_g2_jac_to_affine_bytes(p + 36 * i, out + 192 * i); }
 API int rc_g2_jac_to_affine_bytes(const u64 p[36], u8 out[192]) { g2_jac a; g2_aff r; memcpy(&a, p, 288); g2_to_affine(&r, &a); if (r.inf) { memset(out, 0, 192); return 1; } g2_write_affine(out, &r); return 0; }
 
 /* scalar multiplication: affine BE in, scalar 32-byte BE, affine BE out; returns 1 if result is infinity */

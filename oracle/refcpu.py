@@ -162,6 +162,14 @@ def g2_jac_to_affine_bytes(p):
     return None if inf else out.tobytes()
 
 
+def jac_to_affine_bytes_batch(group, recs, n):
+    """n in-memory Jacobian records -> n wire records, one C call (the per-point host cost of the affine boundary, bench.py `marshal`)"""
+    w, pb = (18, 96) if group == 1 else (36, 192)
+    a = _a64(recs, w * n); out = np.zeros(pb * n, np.uint8)
+    (lib.rc_g1_jac_to_affine_bytes_batch if group == 1 else lib.rc_g2_jac_to_affine_bytes_batch)(_p64(a), _p8(out), C.c_size_t(n))
+    return out
+
+
 # ---- byte-level -----------------------------------------------------------------------------
 def sha256(msg):
     m = _b(msg); out = np.zeros(32, np.uint8)

@@ -36,33 +36,40 @@ func u8(b []byte) *C.uint8_t {
 	return (*C.uint8_t)(unsafe.Pointer(&b[0]))
 }
 
-// packKeys: n*96 B affine public keys (g1.go:157-167) + one flag byte per key (bit 0 = infinity).
-func packKeys(pubs []*PublicKey) (pk, inf []byte) {
-	pk = make([]byte, 0, 96*len(pubs))
-	inf = make([]byte, len(pubs))
+// The points cross the boundary AS THE GO HEAP HOLDS THEM (blsmi 0.6, the *_jac entry points): a *bls.G1Projective is 18 contiguous
+// uint64 -- x, y, z, each FQ 6 little-endian Montgomery limbs (g1.go:252-256, fq.go:11-13, fqrepr.go:14) -- and a *bls.G2Projective 36
+// (g2.go:298-302).  One 144 / 288-byte copy per point: no ToAffine (an Fq inversion, g1.go:322-340 -- run even at z = 1), no
+// SerializeBytes (MontReduce + byte swap, g1.go:157-167) on a host core; the library runs ToAffine on the device.  z == 0 is the point at
+// infinity there (G1Projective.IsZero, g1.go:287-289), so no flag bytes travel either.
+
+// packKeys: n*18 uint64, the public keys' G1Projective structs.
+func packKeys(pubs []*PublicKey) []C.uint64_t {
+	pk := make([]C.uint64_t, 18*len(pubs))
 	for i := range pubs {
-		pa := pubs[i].p.ToAffine() // g1.go:322-340
-		if pa.IsZero() {
-			inf[i] |= 1
-		}
-		pb := pa.SerializeBytes() // all zero for infinity: the library reads that as infinity too
-		pk = append(pk, pb[:]...)
+		copy(pk[18*i:18*i+18], (*[18]C.uint64_t)(unsafe.Pointer(pubs[i].p))[:])
 	}
-	return
+	return pk
 }
 
-// packSigs: n*192 B affine signatures (g2.go:172-186); bit 1 of inf[i] marks infinity.
-func packSigs(sigs []*Signature, inf []byte) (sg []byte) {
-	sg = make([]byte, 0, 192*len(sigs))
+// packSigs: n*36 uint64, the signatures' G2Projective structs.
+func packSigs(sigs []*Signature) []C.uint64_t {
+	sg := make([]C.uint64_t, 36*len(sigs))
 	for i := range sigs {
-		sa := sigs[i].s.ToAffine() // g2.go:365-386
-		if sa.IsZero() {
-			inf[i] |= 2
-		}
-		sb := sa.SerializeBytes()
-		sg = append(sg, sb[:]...)
+		copy(sg[36*i:36*i+36], (*[36]C.uint64_t)(unsafe.Pointer(sigs[i].s))[:])
 	}
-	return
+	return sg
+}
+
+func u64(b []C.uint64_t) *C.uint64_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return &b[0]
+}
+
+// sigWords: the one signature of an aggregate call, in place (plain memory without Go pointers: cgo may read it directly).
+func sigWords(s *Signature) *C.uint64_t {
+	return (*C.uint64_t)(unsafe.Pointer(s.s))
 }
 
 func packMsgs(msgs [][]byte) (m []byte, off []C.uint64_t) {
@@ -85,10 +92,10 @@ func VerifyBatch(msgs [][]byte, pubs []*PublicKey, sigs []*Signature) []bool {
 		return out
 	}
 	m, off := packMsgs(msgs)
-	pk, inf := packKeys(pubs)
-	sg := packSigs(sigs, inf)
+	pk := packKeys(pubs)
+	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	if rc := C.blsmi_g1pubs_verify_batch(u8(m), &off[0], u8(pk), u8(sg), u8(inf), u8(ok), nil, C.size_t(n)); rc != 0 {
+	if rc := C.blsmi_g1pubs_verify_batch_jac(u8(m), &off[0], u64(pk), u64(sg), u8(ok), nil, C.size_t(n)); rc != 0 {
 		panic("blsmi: g1pubs verify_batch failed")
 	}
 	for i := range ok {
@@ -114,11 +121,11 @@ func VerifyWithDomainBatch(msgs [][32]byte, pubs []*PublicKey, sigs []*Signature
 	if n == 0 {
 		return out
 	}
-	pk, inf := packKeys(pubs)
-	sg := packSigs(sigs, inf)
+	pk := packKeys(pubs)
+	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g1pubs_verify_with_domain_batch((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u8(pk), u8(sg), u8(inf), u8(ok), nil, C.size_t(n))
+	rc := C.blsmi_g1pubs_verify_with_domain_batch_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u64(pk), u64(sg), u8(ok), nil, C.size_t(n))
 	if rc != 0 {
 		panic("blsmi: g1pubs verify_with_domain_batch failed")
 	}
@@ -135,10 +142,9 @@ func (s *Signature) VerifyAggregate(pubKeys []*PublicKey, msgs [][]byte) bool {
 		return false
 	}
 	m, off := packMsgs(msgs)
-	pk, _ := packKeys(pubKeys)            // a key at infinity travels as the all-zero record: verdict false
-	sb := s.s.ToAffine().SerializeBytes() // likewise for the signature
+	pk := packKeys(pubKeys) // a key or the signature at infinity (z == 0): verdict false (upstream panics in MillerLoop)
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate(u8(m), &off[0], u8(pk), (*C.uint8_t)(unsafe.Pointer(&sb[0])), C.size_t(len(msgs)), &ok)
+	rc := C.blsmi_g1pubs_verify_aggregate_jac(u8(m), &off[0], u64(pk), sigWords(s), C.size_t(len(msgs)), &ok)
 	return rc == 0 && ok != 0
 }
 
@@ -147,25 +153,23 @@ func (s *Signature) VerifyAggregateCommon(pubKeys []*PublicKey, msg []byte) bool
 	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_POINT_ADD, C.size_t(len(pubKeys))) != 0 {
 		return Verify(msg, AggregatePublicKeys(pubKeys), s) // a handful of keys: sum them on the upstream path
 	}
-	pk, _ := packKeys(pubKeys)
-	sb := s.s.ToAffine().SerializeBytes()
+	pk := packKeys(pubKeys)
 	one := []byte{0}
 	mp := u8(msg)
 	if len(msg) == 0 {
 		mp = u8(one)
 	}
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_common(mp, C.size_t(len(msg)), u8(pk), (*C.uint8_t)(unsafe.Pointer(&sb[0])), C.size_t(len(pubKeys)), &ok)
+	rc := C.blsmi_g1pubs_verify_aggregate_common_jac(mp, C.size_t(len(msg)), u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok)
 	return rc == 0 && ok != 0
 }
 
 // VerifyAggregateCommonWithDomain keeps the upstream signature (g1pubs/bls.go:294).
 func (s *Signature) VerifyAggregateCommonWithDomain(pubKeys []*PublicKey, msg [32]byte, domain [8]byte) bool {
-	pk, _ := packKeys(pubKeys)
-	sb := s.s.ToAffine().SerializeBytes()
+	pk := packKeys(pubKeys)
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_common_with_domain((*C.uint8_t)(unsafe.Pointer(&msg[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u8(pk), (*C.uint8_t)(unsafe.Pointer(&sb[0])), C.size_t(len(pubKeys)), &ok)
+	rc := C.blsmi_g1pubs_verify_aggregate_common_with_domain_jac((*C.uint8_t)(unsafe.Pointer(&msg[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok)
 	return rc == 0 && ok != 0
 }
 
@@ -179,12 +183,40 @@ func (s *Signature) VerifyAggregateWithDomain(pubKeys []*PublicKey, msgs [][32]b
 	if len(msgs) == 0 {
 		return false
 	}
-	pk, _ := packKeys(pubKeys)
-	sb := s.s.ToAffine().SerializeBytes()
+	pk := packKeys(pubKeys)
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_with_domain((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u8(pk), (*C.uint8_t)(unsafe.Pointer(&sb[0])), C.size_t(len(msgs)), &ok)
+	rc := C.blsmi_g1pubs_verify_aggregate_with_domain_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u64(pk), sigWords(s), C.size_t(len(msgs)), &ok)
 	return rc == 0 && ok != 0
+}
+
+// SumPublicKeys is AggregatePublicKeys (g1pubs/bls.go:192-204) for large sets: the points are summed on the device as they are and the sum
+// comes back as a G1Projective (z = 1; the reference's G1ProjectiveZero for the empty or cancelling sum).
+func SumPublicKeys(pubKeys []*PublicKey) *PublicKey {
+	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_POINT_ADD, C.size_t(len(pubKeys))) != 0 {
+		return AggregatePublicKeys(pubKeys)
+	}
+	pk := packKeys(pubKeys)
+	out := new(bls.G1Projective)
+	var inf C.int
+	if rc := C.blsmi_g1_sum_jac(u64(pk), C.size_t(len(pubKeys)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
+		panic("blsmi: g1 sum failed")
+	}
+	return &PublicKey{p: out}
+}
+
+// SumSignatures is AggregateSignatures (g1pubs/bls.go:177-189) the same way.
+func SumSignatures(sigs []*Signature) *Signature {
+	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_POINT_ADD, C.size_t(len(sigs))) != 0 {
+		return AggregateSignatures(sigs)
+	}
+	sg := packSigs(sigs)
+	out := new(bls.G2Projective)
+	var inf C.int
+	if rc := C.blsmi_g2_sum_jac(u64(sg), C.size_t(len(sigs)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
+		panic("blsmi: g2 sum failed")
+	}
+	return &Signature{s: out}
 }
 
 // VerifySerializedBatch: DeserializePublicKey + DeserializeSignature + Verify for n tuples in one device

@@ -51,32 +51,40 @@ func packMsgs(msgs [][]byte) (m []byte, off []C.uint64_t) {
 	return
 }
 
-// packKeys: n*192 B affine public keys (G2Affine.SerializeBytes, g2.go:172-186); bit 0 of inf[i] marks infinity.
-func packKeys(pubs []*PublicKey, inf []byte) (pk []byte) {
-	pk = make([]byte, 0, 192*len(pubs))
+// The points cross the boundary AS THE GO HEAP HOLDS THEM (blsmi 0.6, the *_jac entry points): a *bls.G2Projective is 36 contiguous
+// uint64 -- x, y, z, each FQ2 two FQ, each FQ 6 little-endian Montgomery limbs (g2.go:298-302, fq2.go:14-17, fq.go:11-13, fqrepr.go:14)
+// -- and a *bls.G1Projective 18 (g1.go:252-256).  One 288 / 144-byte copy per point: no ToAffine (an Fq inversion, g2.go:365-386), no
+// SerializeBytes (MontReduce + byte swap, g2.go:172-186) on a host core; the library runs ToAffine on the device.  z == 0 is the point at
+// infinity there (G2Projective.IsZero), so no flag bytes travel either.
+
+// packKeys: n*36 uint64, the public keys' G2Projective structs.
+func packKeys(pubs []*PublicKey) []C.uint64_t {
+	pk := make([]C.uint64_t, 36*len(pubs))
 	for i := range pubs {
-		pa := pubs[i].p.ToAffine() // g2.go:365-386
-		if pa.IsZero() {
-			inf[i] |= 1
-		}
-		pb := pa.SerializeBytes() // all zero for infinity: the library reads that as infinity too
-		pk = append(pk, pb[:]...)
+		copy(pk[36*i:36*i+36], (*[36]C.uint64_t)(unsafe.Pointer(pubs[i].p))[:])
 	}
-	return
+	return pk
 }
 
-// packSigs: n*96 B affine signatures (G1Affine.SerializeBytes, g1.go:157-167); bit 1 of inf[i] marks infinity.
-func packSigs(sigs []*Signature, inf []byte) (sg []byte) {
-	sg = make([]byte, 0, 96*len(sigs))
+// packSigs: n*18 uint64, the signatures' G1Projective structs.
+func packSigs(sigs []*Signature) []C.uint64_t {
+	sg := make([]C.uint64_t, 18*len(sigs))
 	for i := range sigs {
-		sa := sigs[i].s.ToAffine() // g1.go:322-340
-		if sa.IsZero() {
-			inf[i] |= 2
-		}
-		sb := sa.SerializeBytes()
-		sg = append(sg, sb[:]...)
+		copy(sg[18*i:18*i+18], (*[18]C.uint64_t)(unsafe.Pointer(sigs[i].s))[:])
 	}
-	return
+	return sg
+}
+
+func u64(b []C.uint64_t) *C.uint64_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return &b[0]
+}
+
+// sigWords: the one signature of an aggregate call, in place (the struct is plain memory without Go pointers: cgo may read it directly).
+func sigWords(s *Signature) *C.uint64_t {
+	return (*C.uint64_t)(unsafe.Pointer(s.s))
 }
 
 // VerifyBatch is the batch form the one-tuple-per-call API lacks: out[i] = Verify(msgs[i], pubs[i], sigs[i]).
@@ -87,11 +95,10 @@ func VerifyBatch(msgs [][]byte, pubs []*PublicKey, sigs []*Signature) []bool {
 		return out
 	}
 	m, off := packMsgs(msgs)
-	inf := make([]byte, n)
-	pk := packKeys(pubs, inf)
-	sg := packSigs(sigs, inf)
+	pk := packKeys(pubs)
+	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g2pubs_verify_batch(u8(m), &off[0], u8(pk), u8(sg), u8(inf), u8(ok), nil, C.size_t(n))
+	rc := C.blsmi_g2pubs_verify_batch_jac(u8(m), &off[0], u64(pk), u64(sg), u8(ok), nil, C.size_t(n))
 	if rc != 0 {
 		panic("blsmi: g2pubs verify_batch failed")
 	}
@@ -108,41 +115,63 @@ func Verify(m []byte, pub *PublicKey, sig *Signature) bool {
 }
 
 // VerifyAggregate keeps the upstream signature (g2pubs/bls.go:240): length check here, duplicate-message
-// rejection (bls.go:245-261) inside the library.
+// rejection (bls.go:245-261) inside the library.  A key or the signature at infinity: false (upstream panics in MillerLoop).
 func (s *Signature) VerifyAggregate(pubKeys []*PublicKey, msgs [][]byte) bool {
 	if len(pubKeys) != len(msgs) {
 		return false
 	}
 	m, off := packMsgs(msgs)
-	inf := make([]byte, len(pubKeys))
-	pk := packKeys(pubKeys, inf) // a key at infinity travels as the all-zero record: verdict false
-	sa := s.s.ToAffine()
-	if sa.IsZero() {
-		return false
-	}
-	sb := sa.SerializeBytes()
+	pk := packKeys(pubKeys)
 	var ok C.int
-	rc := C.blsmi_g2pubs_verify_aggregate(u8(m), &off[0], u8(pk), (*C.uint8_t)(unsafe.Pointer(&sb[0])), C.size_t(len(msgs)), &ok)
+	rc := C.blsmi_g2pubs_verify_aggregate_jac(u8(m), &off[0], u64(pk), sigWords(s), C.size_t(len(msgs)), &ok)
 	return rc == 0 && ok != 0
 }
 
 // VerifyAggregateCommon keeps the upstream signature (g2pubs/bls.go:275): the key sum stays on the upstream
-// path for small sets (one Jacobian addition is 6.5 us on a CPU core) and goes to the device for large ones.
+// path for small sets (one Jacobian addition is 6.5 us on a CPU core) and goes to the device for large ones,
+// where the keys are added as the Jacobian points they are.
 func (s *Signature) VerifyAggregateCommon(pubKeys []*PublicKey, msg []byte) bool {
 	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_POINT_ADD, C.size_t(len(pubKeys))) != 0 {
 		return Verify(msg, AggregatePublicKeys(pubKeys), s)
 	}
-	inf := make([]byte, len(pubKeys))
-	pk := packKeys(pubKeys, inf)
-	sb := s.s.ToAffine().SerializeBytes()
+	pk := packKeys(pubKeys)
 	one := []byte{0}
 	mp := u8(msg)
 	if len(msg) == 0 {
 		mp = u8(one)
 	}
 	var ok C.int
-	rc := C.blsmi_g2pubs_verify_aggregate_common(mp, C.size_t(len(msg)), u8(pk), (*C.uint8_t)(unsafe.Pointer(&sb[0])), C.size_t(len(pubKeys)), &ok)
+	rc := C.blsmi_g2pubs_verify_aggregate_common_jac(mp, C.size_t(len(msg)), u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok)
 	return rc == 0 && ok != 0
+}
+
+// SumPublicKeys is AggregatePublicKeys (g2pubs/bls.go:180-192) for large sets: the points are summed on the device as they are and the sum
+// comes back as a G2Projective (z = 1; the reference's G2ProjectiveZero for the empty or cancelling sum).
+func SumPublicKeys(pubKeys []*PublicKey) *PublicKey {
+	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_POINT_ADD, C.size_t(len(pubKeys))) != 0 {
+		return AggregatePublicKeys(pubKeys)
+	}
+	pk := packKeys(pubKeys)
+	out := new(bls.G2Projective)
+	var inf C.int
+	if rc := C.blsmi_g2_sum_jac(u64(pk), C.size_t(len(pubKeys)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
+		panic("blsmi: g2 sum failed")
+	}
+	return &PublicKey{p: out}
+}
+
+// SumSignatures is AggregateSignatures (g2pubs/bls.go:165-177) the same way.
+func SumSignatures(sigs []*Signature) *Signature {
+	if C.blsmi_prefer_cpu(C.BLSMI_SHAPE_POINT_ADD, C.size_t(len(sigs))) != 0 {
+		return AggregateSignatures(sigs)
+	}
+	sg := packSigs(sigs)
+	out := new(bls.G1Projective)
+	var inf C.int
+	if rc := C.blsmi_g1_sum_jac(u64(sg), C.size_t(len(sigs)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
+		panic("blsmi: g1 sum failed")
+	}
+	return &Signature{s: out}
 }
 
 // VerifySerializedBatch: DeserializePublicKey + DeserializeSignature + Verify (g2pubs/bls.go:91-98, 33-40,
@@ -177,10 +206,9 @@ type PreparedKeys struct {
 }
 
 func PrepareKeys(pubs []*PublicKey) *PreparedKeys {
-	inf := make([]byte, len(pubs))
-	pk := packKeys(pubs, inf) // all-zero record = infinity: every verdict over that key is false
+	pk := packKeys(pubs) // a key at infinity (z == 0) keeps that mark in its table: every verdict over it is false
 	var h unsafe.Pointer
-	if rc := C.blsmi_g2_prepared_create(u8(pk), C.size_t(len(pubs)), &h); rc != 0 {
+	if rc := C.blsmi_g2_prepared_create_jac(u64(pk), C.size_t(len(pubs)), &h); rc != 0 {
 		panic("blsmi: prepare failed")
 	}
 	k := &PreparedKeys{h, len(pubs)}
@@ -203,11 +231,10 @@ func VerifyBatchPrepared(msgs [][]byte, keys *PreparedKeys, keyIdx []uint32, sig
 		return out
 	}
 	m, off := packMsgs(msgs)
-	inf := make([]byte, n) // any non-zero flag byte makes verdict i false (bit 1: signature at infinity)
-	sg := packSigs(sigs, inf)
+	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g2pubs_verify_batch_prepared(u8(m), &off[0], keys.h, (*C.uint32_t)(unsafe.Pointer(&keyIdx[0])),
-		u8(sg), u8(inf), u8(ok), nil, C.size_t(n))
+	rc := C.blsmi_g2pubs_verify_batch_prepared_jac(u8(m), &off[0], keys.h, (*C.uint32_t)(unsafe.Pointer(&keyIdx[0])),
+		u64(sg), u8(ok), nil, C.size_t(n))
 	if rc != 0 {
 		panic("blsmi: verify_batch_prepared failed")
 	}

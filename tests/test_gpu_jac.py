@@ -365,3 +365,72 @@ def test_large_batch_of_in_memory_points_matches_the_affine_path(eng):
     aff, bm2 = eng.g2pubs_verify_batch(allm, b"".join(pks) * reps, b"".join(sigs) * reps)
     assert bytes(bm) == bytes(bm2) and list(got[:base]) == want and list(got[-base:]) == want
     assert np.array_equal(got.reshape(reps, base), np.tile(np.array(want), (reps, 1)))
+
+
+def test_go_api_mirror_over_in_memory_points(eng):
+    """The host mirrors (bls_amd.g2pubs / g1pubs) with their Signature / PublicKey holding points the way the reference's do
+    (g2pubs/bls.go:13-15, 53-55): the flows of TestSignVerify, TestVerifyAggregate, TestVerifyAggregateCommon and the missing-signature
+    test (g2pubs/bls_test.go:33-114, g1pubs/bls_test.go) -- every verdict also checked against the oracle."""
+    from bls_amd import g1pubs, g2pubs
+    xs = P.XORShift(5170)
+    for M, R, pj, sj, newpk, newsig in ((g2pubs, RC.g2pubs, jac2, jac1, g2pubs.NewPublicKeyFromG2Projective, g2pubs.NewSignatureFromG1Projective),
+                                        (g1pubs, RC.g1pubs, jac1, jac2, g1pubs.NewPublicKeyFromG1Projective, g1pubs.NewSignatureFromG2Projective)):
+        n = 10
+        sks = [sk_bytes(xs) for _ in range(n)]
+        pkw = [R.priv_to_pub(sk) for sk in sks]
+        pubs = [newpk(pj(xs, w)) for w in pkw]
+        # TestSignVerify: each key signs its own message
+        msgs = [b"Hello world! 16 characters %d" % i for i in range(n)]
+        sgw = [R.sign(m, sk) for m, sk in zip(msgs, sks)]
+        sigs = [newsig(sj(xs, w)) for w in sgw]
+        assert all(M.Verify(m, p, s) for m, p, s in zip(msgs, pubs, sigs))
+        assert M.VerifyBatch(msgs, pubs, sigs[1:] + sigs[:1]) == [False] * n
+        assert sigs[0].s.raw == sgw[0] and pubs[3].p.raw == pkw[3]             # ToAffine().SerializeBytes() of a held point
+        assert sigs[0].Serialize() == M.NewSignatureFromG1(sgw[0]).Serialize() if M is g2pubs else sigs[0].Serialize() == M.NewSignatureFromG2(sgw[0]).Serialize()
+        # TestVerifyAggregate: distinct messages, AggregateSignatures over the held points (summed as Jacobian points)
+        agg = M.AggregateSignatures(sigs)
+        assert agg.s.jac is not None and agg.VerifyAggregate(pubs, msgs) is True
+        assert R.verify_aggregate(agg.s.raw, pkw, msgs) is True
+        assert agg.VerifyAggregate(pubs[1:] + pubs[:1], msgs) is False
+        assert agg.VerifyAggregate(pubs, [msgs[1]] + msgs[1:]) is False        # duplicate message
+        assert agg.VerifyAggregate(pubs[:-1], msgs) is False                   # length mismatch (bls.go:241-243)
+        # the missing-signature test (bls_test.go:68-90): the aggregate of all but one signature does not verify
+        part = M.AggregateSignatures(sigs[:-1])
+        assert part.VerifyAggregate(pubs, msgs) is False and part.VerifyAggregate(pubs[:-1], msgs[:-1]) is True
+        # TestVerifyAggregateCommon: one message
+        msg = b"Test message common"
+        csig = [newsig(sj(xs, R.sign(msg, sk))) for sk in sks]
+        cagg = M.AggregateSignatures(csig)
+        assert cagg.VerifyAggregateCommon(pubs, msg) is True
+        assert R.verify_aggregate_common(cagg.s.raw, pkw, msg) is True
+        assert cagg.VerifyAggregateCommon(pubs[:-1], msg) is False
+        apk = M.AggregatePublicKeys(pubs)
+        assert apk.p.jac is not None and M.Verify(msg, apk, cagg) is True
+        # Copy keeps the held form; Aggregate() (bls.go:174-177) adds in place
+        acc = sigs[0].Copy(); acc.Aggregate(sigs[1])
+        assert acc.s.raw == (RC.g1_sum if M is g2pubs else RC.g2_sum)(sgw[0] + sgw[1], 2)
+    # g1pubs WithDomain flows (g1pubs/bls_test.go)
+    dom = b"\x00\x00\x00\x00\x00\x00\x00\x07"
+    n = 6
+    sks = [sk_bytes(xs) for _ in range(n)]
+    pkw = [RC.g1pubs.priv_to_pub(sk) for sk in sks]
+    pubs = [g1pubs.NewPublicKeyFromG1Projective(jac1(xs, w)) for w in pkw]
+    m32 = [RC.sha256(b"d%d" % i) for i in range(n)]
+    sgw = [RC.g1pubs.sign_with_domain(m, sk, dom) for m, sk in zip(m32, sks)]
+    sigs = [g1pubs.NewSignatureFromG2Projective(jac2(xs, w)) for w in sgw]
+    assert g1pubs.VerifyWithDomainBatch(m32, pubs, sigs, dom) == [True] * n
+    assert g1pubs.VerifyWithDomain(m32[0], pubs[0], sigs[1], dom) is False
+    agg = g1pubs.AggregateSignatures(sigs)
+    assert g1pubs.VerifyAggregateWithDomain(agg, pubs, m32, dom) is True
+    assert g1pubs.VerifyAggregateWithDomain(agg, pubs[::-1], m32, dom) is False
+    csig = g1pubs.AggregateSignatures([g1pubs.NewSignatureFromG2Projective(jac2(xs, RC.g1pubs.sign_with_domain(m32[0], sk, dom))) for sk in sks])
+    assert g1pubs.VerifyAggregateCommonWithDomain(csig, pubs, m32[0], dom) is True
+    assert g1pubs.VerifyAggregateCommonWithDomain(csig, pubs[1:], m32[0], dom) is False
+    # prepared keys from held points
+    pk2 = [RC.g2pubs.priv_to_pub(sk) for sk in sks]
+    keys = g2pubs.PrepareKeys([g2pubs.NewPublicKeyFromG2Projective(jac2(xs, w)) for w in pk2])
+    msgs = [b"p%d" % i for i in range(n)]
+    s2 = [g2pubs.NewSignatureFromG1Projective(jac1(xs, RC.g2pubs.sign(m, sk))) for m, sk in zip(msgs, sks)]
+    assert g2pubs.VerifyBatchPrepared(msgs, keys, list(range(n)), s2) == [True] * n
+    assert g2pubs.VerifyBatchPrepared(msgs, keys, [1] + list(range(1, n)), s2) == [False] + [True] * (n - 1)
+    keys.Close()

@@ -504,7 +504,7 @@ def test_device_duplicate_table_and_its_fallback(force):
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
 def test_msm_with_a_crowded_bucket_on_both_grouping_paths(group):
-    """The MSM groups its 16 n (bucket, point) items with a device radix sort (default) or, with BLSMI_MSM_SORT=0, with the exact histogram + scan +
+    """The MSM groups its 16 n (bucket, point) items with a device radix sort (default) or, with blsmi_set_option("msm_sort", 0) / BLSMI_MSM_SORT=0 at start-up, with the exact histogram + scan +
     atomic scatter.  300 EQUAL scalars put 300 items into the same bucket of every window (mean population 4 at n = 2^17; below the skew limit of
     2 048): both paths must give the point the oracle gives through the scalar identity."""
     from bls_amd import engine as eng
@@ -526,10 +526,9 @@ def test_msm_with_a_crowded_bucket_on_both_grouping_paths(group):
         acc = (acc + int.from_bytes(bk[j].tobytes(), "big") * col) % P.R_ORDER
     want = (RC.g1_mul if group == "g1" else RC.g2_mul)(gen, acc.to_bytes(32, "big"))
     lib = eng._lib()
-    saved = os.environ.get("BLSMI_MSM_SORT")
     try:
-        for mode, marks in (("1", ("rocprim:radix_sort", "k_msm_runs")), ("0", ("k_msm_hist_glv", "k_msm_scan", "k_msm_scatter_glv"))):
-            os.environ["BLSMI_MSM_SORT"] = mode                                # read per call (blsmi.hip: msm_bucket_glv_dev)
+        for mode, marks in ((1, ("rocprim:radix_sort", "k_msm_runs")), (0, ("k_msm_hist_glv", "k_msm_scan", "k_msm_scatter_glv"))):
+            eng.set_option("msm_sort", mode)                                   # an atomic the library reads per call (blsmi.hip: msm_bucket_glv_dev); the environment is read at start-up only
             lib.blsmi_set_profiling(1)
             got = (eng.g1_msm if group == "g1" else eng.g2_msm)(pts.reshape(-1), k.reshape(-1), n)
             buf = ctypes.create_string_buffer(8192)
@@ -538,8 +537,7 @@ def test_msm_with_a_crowded_bucket_on_both_grouping_paths(group):
             assert all(m in names for m in marks), (mode, names)
             assert got == want, mode
     finally:
-        if saved is None: os.environ.pop("BLSMI_MSM_SORT", None)
-        else: os.environ["BLSMI_MSM_SORT"] = saved
+        eng.set_option("msm_sort", 1)
 
 
 def test_page_locked_host_buffers(eng):

@@ -297,7 +297,7 @@ def test_fused_sign_batches_match_the_oracle(eng):
 def test_large_g2pubs_aggregate_with_the_cofactor_moved_through_the_pairing(eng):
     """From 65 536 messages a g2pubs VerifyAggregate (g2pubs/bls.go:240-270) hashes WITHOUT the cofactor clearing of hash.go:306-309 and raises
     the product of its Miller values to 1 - x once (program powc12raw; tests/test_lat_program.py has the identity on the oracle).  Verdicts --
-    valid, one wrong key, one wrong message, a tampered aggregate -- equal those of the cleared-hash path (BLSMI_AGG_COFACTOR_POW=0, read
+    valid, one wrong key, one wrong message, a tampered aggregate -- equal those of the cleared-hash path (blsmi_set_option("agg_cofactor_pow", 0); BLSMI_AGG_COFACTOR_POW=0 at start-up, read
     per call), from host buffers and from resident ones; below the threshold the program is not used."""
     import ctypes
     import hashlib
@@ -324,12 +324,11 @@ def test_large_g2pubs_aggregate_with_the_cofactor_moved_through_the_pairing(eng)
         v = eng.g2pubs_verify_aggregate(m, p, a)
         buf = ctypes.create_string_buffer(8192); lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
         return v, buf.value.decode()
-    saved = os.environ.get("BLSMI_AGG_COFACTOR_POW")
     try:
-        for mode in ("1", "0"):
-            os.environ["BLSMI_AGG_COFACTOR_POW"] = mode
+        for mode in (1, 0):
+            eng.set_option("agg_cofactor_pow", mode)
             v, prof = run(packed, allpk, agg)
-            assert v is True and ("k_lat:powc12raw" in prof) == (mode == "1"), (mode, prof)
+            assert v is True and ("k_lat:powc12raw" in prof) == (mode == 1), (mode, prof)
             assert run(packed, bad_pk, agg)[0] is False
             assert run(bad_msgs, allpk, agg)[0] is False
             assert run(packed, allpk, agg2)[0] is False
@@ -341,7 +340,7 @@ def test_large_g2pubs_aggregate_with_the_cofactor_moved_through_the_pairing(eng)
             assert eng.verify_aggregate_dev("g2pubs", d_m.data_ptr(), d_o.data_ptr(), d_b.data_ptr(), agg, n) is False
         # partial products across "ranks" (bls_amd/dist.py's exchange, in process): a shard of 65 536 messages takes the new path, the rest of
         # the messages the cleared one; their product finishes to the same verdict
-        os.environ["BLSMI_AGG_COFACTOR_POW"] = "1"
+        eng.set_option("agg_cofactor_pow", 1)
         g2gen = np.frombuffer(RC.g2_generator(), dtype=np.uint8)
         for keys, want in ((allpk, True), (bad_pk, False)):
             pa, ba = eng.aggregate_partial("g2pubs", msgs[:65536], keys[:192 * 65536])
@@ -356,5 +355,4 @@ def test_large_g2pubs_aggregate_with_the_cofactor_moved_through_the_pairing(eng)
         v, prof = run(msgs[:m2], allpk[:192 * m2], a3)
         assert v is True and "k_lat:powc12raw" not in prof
     finally:
-        if saved is None: os.environ.pop("BLSMI_AGG_COFACTOR_POW", None)
-        else: os.environ["BLSMI_AGG_COFACTOR_POW"] = saved
+        eng.set_option("agg_cofactor_pow", 1)

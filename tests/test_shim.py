@@ -77,10 +77,35 @@ def test_every_c_call_matches_the_header():
         for c in re.findall(r"C\.(BLSMI_[A-Z0-9_]+)", src):
             assert c in consts, "%s uses C.%s, which include/blsmi.h does not define" % (name, c)
     # the verify surface of both packages is bound
-    for fn in ("blsmi_g2pubs_verify_batch", "blsmi_g2pubs_verify_aggregate", "blsmi_g2pubs_verify_aggregate_common", "blsmi_g1pubs_verify_batch",
-               "blsmi_g1pubs_verify_aggregate", "blsmi_g1pubs_verify_aggregate_common", "blsmi_g1pubs_verify_with_domain_batch",
-               "blsmi_g1pubs_verify_aggregate_with_domain", "blsmi_g1pubs_verify_aggregate_common_with_domain", "blsmi_init_devices", "blsmi_prefer_cpu"):
+    # ... through the in-memory-point forms (blsmi 0.6): the shims copy the G?Projective structs, nothing else
+    for fn in ("blsmi_g2pubs_verify_batch_jac", "blsmi_g2pubs_verify_aggregate_jac", "blsmi_g2pubs_verify_aggregate_common_jac", "blsmi_g1pubs_verify_batch_jac",
+               "blsmi_g1pubs_verify_aggregate_jac", "blsmi_g1pubs_verify_aggregate_common_jac", "blsmi_g1pubs_verify_with_domain_batch_jac",
+               "blsmi_g1pubs_verify_aggregate_with_domain_jac", "blsmi_g1pubs_verify_aggregate_common_with_domain_jac", "blsmi_g2_prepared_create_jac",
+               "blsmi_g2pubs_verify_batch_prepared_jac", "blsmi_g1_sum_jac", "blsmi_g2_sum_jac", "blsmi_init_devices", "blsmi_prefer_cpu"):
         assert fn in seen, fn
+
+
+def _go_code(src):
+    """Go source without its comments (// to end of line, /* */ blocks)"""
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return "\n".join(line.split("//")[0] for line in src.splitlines())
+
+
+def test_no_per_point_host_field_arithmetic_in_the_shims():
+    """a verify path that runs ToAffine() (an Fq inversion, g1.go:322-340) and SerializeBytes() (MontReduce + byte swap,
+    g1.go:157-167) per point on a host core caps a Go caller at ~40 k tuples/s per core.  The shims hand over the G?Projective structs as they
+    lie: no ToAffine, no SerializeBytes, no infinity flags anywhere in their code, and every pack* helper is a fixed-size copy."""
+    for path in SHIMS:
+        code = _go_code(open(path).read())
+        assert "ToAffine" not in code and "SerializeBytes" not in code and "IsZero" not in code, path
+        for fn in ("packKeys", "packSigs"):
+            body = re.search(r"func %s\(.*?\n}\n" % fn, code, flags=re.S).group(0)
+            assert re.search(r"copy\(\w+\[(18|36)\*i:(18|36)\*i\+(18|36)\], \(\*\[(18|36)\]C\.uint64_t\)\(unsafe\.Pointer\(\w+\[i\]\.[ps]\)\)\[:\]\)", body), (path, fn)
+            assert "C.blsmi" not in body and "bls." not in body
+        pkg = os.path.basename(os.path.dirname(path))
+        # record sizes: g2pubs keys are G2Projective (36 words) and signatures G1Projective (18); g1pubs the other way round
+        kw, sw = (36, 18) if pkg == "g2pubs" else (18, 36)
+        assert "pk := make([]C.uint64_t, %d*len(pubs))" % kw in code and "sg := make([]C.uint64_t, %d*len(sigs))" % sw in code
 
 
 def test_shims_export_the_references_verify_surface():

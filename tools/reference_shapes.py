@@ -31,6 +31,10 @@ def _best(fn, reps):
     return b
 
 
+def RC_Q():
+    return 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+
 def run(engine, batch=65536):
     from oracle import refcpu as RC                     # the CPU baseline leg (kind "port"): checker code, timed here as the reference's stand-in
     from bls_amd import g1pubs as G1P
@@ -79,6 +83,72 @@ def run(engine, batch=65536):
     S["BLSVerify"] = {"ref": "g2pubs/bls_test.go:244-256", "cpu_ms_per_op": round(t_ver * 1e3, 4),
                       "gpu_ms_single_call": round(_best(lambda: engine.g2pubs_verify_batch([msg], pk, sig), 5) * 1e3, 3),
                       "gpu_batch_ops_per_s": round(nb / _best(lambda: engine.g2pubs_verify_batch(msgs, pks, sigs.reshape(-1)), 2), 1)}
+
+    # ---- the boundary itself: what handing its points over costs a Go caller, per point, on ONE host core ------------
+    # The Go values hold Jacobian / Montgomery points (g2pubs/bls.go:13-15, 53-55).  Affine entry points: the shim runs ToAffine() +
+    # SerializeBytes() per point (g1.go:322-340 + 157-167, g2.go:365-386 + 172-186) -- timed on the C restatement, n points in ONE C call (no
+    # ctypes overhead per point).  In-memory (*_jac) entry points, blsmi 0.6: the shim copies the struct (144 / 288 bytes) and the library runs
+    # ToAffine on the device inside the call.
+    Q = RC_Q()
+    R384 = (1 << 384) % Q
+
+    def _m(v):
+        return (v * R384 % Q).to_bytes(48, "little")
+
+    def to_jac1(w, z):
+        x, y = int.from_bytes(w[:48], "big"), int.from_bytes(w[48:96], "big")
+        return _m(x * z * z % Q) + _m(y * z * z * z % Q) + _m(z)
+
+    def f2(a, b):
+        return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
+
+    def to_jac2(w, z):
+        c = [int.from_bytes(w[48 * i:48 * i + 48], "big") for i in range(4)]
+        z2 = f2(z, z); z3 = f2(z2, z)
+        X, Y = f2((c[0], c[1]), z2), f2((c[2], c[3]), z3)
+        return _m(X[0]) + _m(X[1]) + _m(Y[0]) + _m(Y[1]) + _m(z[0]) + _m(z[1])
+    zs = [int.from_bytes(hashlib.sha256(b"z%d" % i).digest() * 2, "big") % (Q - 1) + 1 for i in range(257)]
+    sg_bytes = sigs.reshape(nb, 96)
+    sgj = np.frombuffer(b"".join(to_jac1(sg_bytes[i].tobytes(), zs[i % 257]) for i in range(nb)), dtype=np.uint8)
+    pk256 = pks.reshape(nb, 192)[:256]
+    pkj256 = b"".join(to_jac2(pk256[i].tobytes(), (zs[i], zs[i + 1])) for i in range(256))
+    pkj = np.frombuffer(pkj256 * (nb // 256), dtype=np.uint8)
+    m = 4096
+    a1 = np.frombuffer(sgj[:144 * m].tobytes(), dtype=np.uint64); a2 = np.frombuffer(pkj[:288 * m].tobytes(), dtype=np.uint64)
+    t_g1 = _best(lambda: RC.jac_to_affine_bytes_batch(1, a1, m), 2) / m
+    t_g2 = _best(lambda: RC.jac_to_affine_bytes_batch(2, a2, m), 2) / m
+    assert RC.jac_to_affine_bytes_batch(1, np.frombuffer(sgj[:144 * 8].tobytes(), dtype=np.uint64), 8).tobytes() == sg_bytes[:8].tobytes()
+    dst1, dst2 = np.empty_like(sgj), np.empty_like(pkj)
+
+    def struct_copies():                                  # what packSigs / packKeys of the shims do: one fixed-size copy per point
+        a = sgj.reshape(nb, 144); b = pkj.reshape(nb, 288)
+        d1 = dst1.reshape(nb, 144); d2 = dst2.reshape(nb, 288)
+        for lo in range(0, nb, 4096):                      # (numpy row-block copies: an upper bound on what a Go copy loop costs per point)
+            d1[lo:lo + 4096] = a[lo:lo + 4096]; d2[lo:lo + 4096] = b[lo:lo + 4096]
+    t_copy = _best(struct_copies, 3) / nb
+    got_j, _ = engine.g2pubs_verify_batch_jac(msgs, pkj, sgj)
+    assert bool(np.all(got_j))
+    t_jac = _best(lambda: engine.g2pubs_verify_batch_jac(msgs, pkj, sgj), 2)
+    t_aff = _best(lambda: engine.g2pubs_verify_batch(msgs, pks, sigs.reshape(-1)), 2)
+    t_dev1 = _best(lambda: engine.g1_jac_to_affine_batch(sgj, nb), 2)
+    t_dev2 = _best(lambda: engine.g2_jac_to_affine_batch(pkj, nb), 2)
+    old_per_tuple = t_aff / nb + t_g1 + t_g2
+    S["marshal"] = {"ref": "what crossing the C ABI costs the caller per point: G?Projective.ToAffine() + SerializeBytes() (g1.go:322-340, 157-167; g2.go:365-386, 172-186) "
+                           "for the affine entry points against one struct copy for the *_jac entry points (blsmi 0.6)",
+                    "cpu_us_per_point_to_affine_bytes": {"g1": round(t_g1 * 1e6, 3), "g2": round(t_g2 * 1e6, 3)},
+                    "jac_host_us_per_tuple_struct_copies": round(t_copy * 1e6, 4),
+                    "jac_to_affine_batch_host_call_points_per_s": {"g1": round(nb / t_dev1, 1), "g2": round(nb / t_dev2, 1)},
+                    "note": "cpu: oracle/refcpu.c on one core, n points per C call; struct copies: 144 + 288 bytes per g2pubs tuple; "
+                            "jac_to_affine_batch: blsmi_g?_jac_to_affine_batch from host buffers (copies in and out included)"}
+    out["end_to_end_host"] = {
+        "what": "g2pubs.VerifyBatch of %d tuples as a Go caller reaches it: host buffers, marshalling included, one call" % nb,
+        "jac_entry_verifies_per_s": round(nb / (t_jac + t_copy * nb), 1),
+        "jac_entry_ms": round(t_jac * 1e3, 3), "jac_marshal_ms_one_core": round(t_copy * nb * 1e3, 3),
+        "affine_entry_verifies_per_s_one_marshalling_core": round(1.0 / old_per_tuple, 1),
+        "affine_entry_ms": round(t_aff * 1e3, 3), "affine_marshal_ms_one_core": round((t_g1 + t_g2) * nb * 1e3, 1),
+        "affine_entry_verifies_per_s_without_marshalling": round(nb / t_aff, 1),
+        "note": "the affine figure adds the measured per-point ToAffine + SerializeBytes of one host core (the shims' packKeys / packSigs before blsmi 0.6 were one "
+                "goroutine) to the measured call; the jac figure adds the measured struct copies to the measured blsmi_g2pubs_verify_batch_jac call"}
 
     def sign_batch(ms, sks):                              # g2pubs.Sign = sk * HashG1(m) (g2pubs/bls.go:132-135): one call, both steps on the device
         return engine.g2pubs_sign_batch(ms, sks)

@@ -43,8 +43,8 @@ while time.time() - t0 < budget:
         p2 = pks.copy(); p2[j] = 0; want = False                                  # a key at infinity (all-zero record)
     verify = E.g2pubs_verify_aggregate if group == "g2pubs" else E.g1pubs_verify_aggregate
     got = []
-    for mode in ("1", "0"):
-        os.environ["BLSMI_AGG_COFACTOR_POW"] = mode
+    for mode in (1, 0):
+        E.set_option("agg_cofactor_pow", mode)
         got.append(verify(m2, p2.reshape(-1), a2))
     assert got[0] == got[1] == want, (group, n, kind, got, want)
     if n <= 64 and kind != 5:
@@ -53,5 +53,5 @@ while time.time() - t0 < budget:
         oracle += 1
     big += n >= 65536
     rounds += 1
-os.environ.pop("BLSMI_AGG_COFACTOR_POW", None)
+E.set_option("agg_cofactor_pow", 1)
 print("soak7 ok: %d rounds (%d at 65 536 messages or more), %d oracle comparisons, %.0f s" % (rounds, big, oracle, time.time() - t0))
