@@ -426,6 +426,8 @@ def compact_line(d, detail_file=None):
     Guaranteed < LINE_LIMIT bytes: optional parts are dropped in a fixed order if a run ever produced more (they stay in the detail file)."""
     line = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                      "launch", "devices", "rccl_ranks", "library"))
+    if d.get("aliased_devices"):
+        line["aliased_devices"] = True
     line["config"] = _pick(d.get("config", {}), ("workload", "pairings_per_gpu", "parallelism", "layout"))
     if len(line["config"].get("workload", "")) > 200:
         line["config"]["workload"] = line["config"]["workload"][:200]
@@ -447,7 +449,10 @@ def compact_line(d, detail_file=None):
         line["mid_batches"] = {"pairings_per_s": mid.get("pairings_per_s"), "verifies_per_s": mid.get("verifies_per_s")}
     il = d.get("inlibrary_bench")
     if isinstance(il, dict) and "error" not in il and il.get("devices", 1) > 1:
-        line["inlibrary"] = _pick(il, ("devices", "rccl_ranks", "tuples_per_call", "pairings_per_s", "g2pubs_verifies_per_s", "g1pubs_verifies_per_s"))
+        line["inlibrary"] = _pick(il, ("devices", "rccl_ranks", "aliased_devices", "tuples_per_call", "pairings_per_s", "g2pubs_verifies_per_s", "g1pubs_verifies_per_s"))
+        ab = d.get("aggregate_bench")
+        if isinstance(ab, dict) and "error" not in ab:
+            line["inlibrary"]["sharded_aggregate"] = _pick(ab, ("signatures", "ms", "signatures_per_s"))
     errs = [k for k, x in d.items() if isinstance(x, dict) and "error" in x]
     if errs:
         line["leg_errors"] = errs
@@ -819,8 +824,12 @@ def inlibrary_bench(E, ndev, n_per_dev=65536, steps=3):
     collective).  PCIe-inclusive by construction."""
     engine = E.engine
     n = ndev * n_per_dev
+    aliased = getattr(E, "alias", False)
     out = {"devices": engine.device_count(), "shards": engine.shard_count(), "tuples_per_call": n, "steps": steps, "rccl_ranks": ndev if ndev > 1 else 0,
-           "collective": "ncclAllReduce(uint8 SUM, disjoint bit ownership) of the %d-byte bitmap inside every verify call" % (n // 8) if ndev > 1 else "none (one device: the call is not split)"}
+           "collective": ("host-staged stand-in of ncclAllReduce under the BLSMI_DEVICE_ALIAS test hook (RCCL refuses two ranks on one GPU): same buffers, same result; rccl_ranks counts the stand-in's ranks" if aliased
+                          else "ncclAllReduce(uint8 SUM, disjoint bit ownership) of the %d-byte bitmap inside every verify call" % (n // 8)) if ndev > 1 else "none (one device: the call is not split)"}
+    if aliased:
+        out["aliased_devices"] = True
     g1, g2 = synth_inputs(engine, n, seed=99)
 
     def best(fn):
@@ -887,7 +896,13 @@ def main():
         print("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
         sys.exit(2)
     single_process_devices = args.gpus if not torchrun else 1            # one process driving N devices through the library
-    if single_process_devices > torch.cuda.device_count():
+    # TEST HOOK (include/blsmi.h: BLSMI_DEVICE_ALIAS=0,0[,...]): N LOGICAL devices on the listed physical GPUs, so that a one-GPU box runs the
+    # N-device plumbing of this script and of the library end to end (tests/test_bench_line.py).  Not a measurement of scaling: the line says so.
+    alias = [int(x) for x in os.environ.get("BLSMI_DEVICE_ALIAS", "").split(",") if x.strip() != ""] if not torchrun else []
+    if alias and single_process_devices > len(alias):
+        print("bench.py: --gpus %d but BLSMI_DEVICE_ALIAS names %d logical device(s)" % (args.gpus, len(alias)), file=sys.stderr)
+        sys.exit(2)
+    if not alias and single_process_devices > torch.cuda.device_count():
         print("bench.py: --gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count()), file=sys.stderr)
         sys.exit(2)
 
@@ -900,7 +915,8 @@ def main():
         E.use_dist = True
     torch.cuda.set_device(local_rank)
     E.dev = torch.device("cuda", local_rank)
-    E.devs = [torch.device("cuda", i) for i in range(single_process_devices)] if not torchrun else [E.dev]
+    E.devs = [torch.device("cuda", alias[i] if alias else i) for i in range(single_process_devices)] if not torchrun else [E.dev]
+    E.alias = bool(alias) and single_process_devices > 1
     if E.use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=E.dev)
@@ -922,6 +938,10 @@ def main():
     bufs = []
     for d in E.devs:
         bufs.append((torch.from_numpy(g1).to(d), torch.from_numpy(g2).to(d), torch.zeros((n, 72), dtype=torch.int64, device=d)))
+    if E.alias:                                                            # aliased devices share one HIP ordinal: tell the library which logical device owns which buffer
+        for i, tensors in enumerate(bufs):
+            for t in tensors:
+                engine.debug_alias_own(t.data_ptr(), t.numel() * t.element_size(), i)
     fence(E)
 
     def step_dev(i):
@@ -1067,8 +1087,9 @@ def main():
             "n_gpus": total_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32 (14 x 28-bit limbs in the pairing / hash / curve kernels, 15 x 27 in the latency programs; int64 accumulate)",
             "data": "synthetic",
-            "launch": "torchrun: one process per GPU" if torchrun else "single process: %d device(s) behind the C ABI (blsmi_init_devices)" % ndev,
-            "devices": total_gpus, "rccl_ranks": world if E.use_dist else 0,
+            "launch": "torchrun: one process per GPU" if torchrun else ("single process: %d device(s) behind the C ABI (blsmi_init_devices)" % ndev) +
+                      (" -- LOGICAL devices on physical GPU(s) %s (BLSMI_DEVICE_ALIAS test hook, host-staged collectives): plumbing check, NO scaling curve was measured" % sorted(set(alias[:ndev])) if E.alias else ""),
+            "devices": total_gpus, "rccl_ranks": world if E.use_dist else 0, "aliased_devices": True if E.alias else None,
             "library": engine.version(),
             "config": {"workload": "configs[1]: %d independent pairings (Miller loop + final exponentiation = bls.Pairing) per GPU per step, inputs resident in HBM, output bit-exact Fq12" % n,
                        "pairings_per_gpu": n, "parallelism": "shard%d" % total_gpus,

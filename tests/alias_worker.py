@@ -83,6 +83,48 @@ def main():
     bits = np.unpackbits(bitmap, bitorder="little")[:nv].astype(bool)
     ck["verify_split_bitmap"] = bool(np.array_equal(bits, expect)) and len(bitmap) == nv // 8
     ck["verify_oracle_sample"] = all(RC.g2pubs.verify(vm[i], vpk[i].tobytes(), vs[i].tobytes()) == bool(expect[i]) for i in (0, 17, 32767, 32768, 17 + 4099, nv - 1))
+    # ---- the same split calls over the reference's in-memory points (blsmi 0.6, *_jac): Jacobian records with z != 1 are cut at the
+    # 288 / 144-byte record boundaries, every shard runs ToAffine on its own device; verdicts and bitmap identical to the affine call
+    from gpu_common import P, jac1, jac2
+    xs = P.XORShift(9090)
+    pkj256 = [jac2(xs, pks[i].tobytes()) for i in range(nk)]
+    sgj_rows = 2048
+    sgj = [jac1(xs, vs[i].tobytes()) for i in range(sgj_rows)]                       # (2 048 distinct signatures; the rest of the batch repeats tuples)
+    idx = np.arange(nv) % sgj_rows
+    jm = eng.PackedMsgs([vm[i] for i in idx])
+    jpk = np.frombuffer(b"".join(pkj256), dtype=np.uint8).reshape(nk, 288)[idx % nk]
+    jex = np.ones(nv, dtype=bool)
+    jpk = np.ascontiguousarray(jpk)
+    for i in range(29, nv, 5003):
+        jpk[i] = np.frombuffer(pkj256[(idx[i] + 7) % nk], dtype=np.uint8); jex[i] = False
+    jsg = np.frombuffer(b"".join(sgj), dtype=np.uint8).reshape(sgj_rows, 144)[idx]
+    l0 = leases()
+    okj, bmj = eng.g2pubs_verify_batch_jac(jm, jpk.reshape(-1), np.ascontiguousarray(jsg).reshape(-1))
+    l1 = leases()
+    ck["jac_verify_split_every_device"] = all(b > a for a, b in zip(l0, l1))
+    ck["jac_verify_split_verdicts_and_bitmap"] = bool(np.array_equal(okj, jex)) and bool(np.array_equal(np.unpackbits(bmj, bitorder="little")[:nv].astype(bool), jex))
+    na = ndev * 16384
+    aggj = jac1(xs, eng.g1_sum(sigs[:na].reshape(-1), na))
+    apkj = np.ascontiguousarray(np.frombuffer(b"".join(pkj256), dtype=np.uint8).reshape(nk, 288)[np.arange(na) % nk])
+    ck["jac_aggregate_split_true"] = eng.g2pubs_verify_aggregate_jac(msgs[:na], apkj.reshape(-1), aggj) is True
+    apkj[na - 3] = np.frombuffer(pkj256[5], dtype=np.uint8)
+    ck["jac_aggregate_split_wrong_key_in_last_shard"] = eng.g2pubs_verify_aggregate_jac(msgs[:na], apkj.reshape(-1), aggj) is False
+    # blsmi_trim from another thread WHILE split calls run: the exchange buffers belong to the split call; verdicts unchanged
+    stop = threading.Event()
+
+    def trimmer():
+        while not stop.is_set():
+            eng.trim(0)
+    tt = threading.Thread(target=trimmer); tt.start()
+    try:
+        good = True
+        for _ in range(3):
+            okt, bmt = eng.g2pubs_verify_batch(eng.PackedMsgs(vm), vpk.reshape(-1), vs.reshape(-1))
+            good = good and bool(np.array_equal(okt, expect)) and bool(np.array_equal(np.unpackbits(bmt, bitorder="little")[:nv].astype(bool), expect))
+            good = good and eng.g2pubs_verify_aggregate(msgs[:na], allpk[:192 * na], eng.g1_sum(sigs[:na].reshape(-1), na)) is True
+    finally:
+        stop.set(); tt.join()
+    ck["trim_during_split_calls"] = good
     # ---- pairings split ndev ways: every shard's first, last and a middle row against the oracle
     npair = ndev * 8192
     g1 = sigs[:npair]; g2 = allpk[:192 * npair].reshape(npair, 192)

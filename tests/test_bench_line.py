@@ -120,3 +120,29 @@ def test_bench_command_prints_one_parsable_line():
         assert j["configs"][k]["cpu_baseline"]["value"] > 0 and j["configs"][k]["roofline"]["kernel"]
     detail = json.load(open(os.path.join(ROOT, j["detail"])))
     assert detail["value"] == j["value"] and "reference_shapes" in detail
+
+
+@pytest.mark.gpu
+def test_two_logical_devices_through_the_bench_command():
+    """Multi-device readiness without the hardware: `python bench.py --gpus 2` as the driver would run it on an N-GPU node,
+    on ONE GPU under the BLSMI_DEVICE_ALIAS test hook -- two logical devices behind the C ABI, the headline step on both, the split host entry
+    points with the bitmap exchange, the sharded 2^20-signature VerifyAggregate with its partial-product exchange.  The line must parse and say
+    that these are logical devices (no scaling curve is claimed)."""
+    env = dict(os.environ)
+    env["BLSMI_DEVICE_ALIAS"] = "0,0"
+    env.pop("BLSMI_SHARDS", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["devices"] == 2 and j["aliased_devices"] is True and "ALIASED-DEVICES" in j["library"] and "devices=2" in j["library"]
+    assert "NO scaling curve" in j["launch"]
+    assert "leg_errors" not in j, j.get("leg_errors")
+    assert abs(j["value"] - 2 * 65536 / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01
+    il = j["inlibrary"]
+    assert il["devices"] == 2 and il["rccl_ranks"] == 2 and il["aliased_devices"] is True and il["tuples_per_call"] == 2 * 65536
+    assert il["pairings_per_s"] > 0 and il["g2pubs_verifies_per_s"] > 0 and il["g1pubs_verifies_per_s"] > 0
+    assert il["sharded_aggregate"]["signatures"] == 1 << 20 and il["sharded_aggregate"]["ms"] > 0
+    detail = json.load(open(os.path.join(ROOT, j["detail"])))
+    assert detail["inlibrary_bench"]["shards"] == 2 and "stand-in" in detail["inlibrary_bench"]["collective"]
