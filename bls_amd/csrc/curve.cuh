@@ -46,6 +46,9 @@ template <class F> BLSMI_DEV Jac<F> jac_double_i(const Jac<F>& g) {
 // g1.go:485-559 / g2.go:532-606 (mixed addition).  Special cases as the reference:
 // g infinite -> o; o infinite -> g; same point -> double; opposite points -> z3 = 0 (infinity).
 template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g);
+// the same, operand BY VALUE -- for the rare equal-points branch inside the inlined additions below: a reference parameter there would
+// make the caller's accumulator an address-taken stack object, written to scratch on the HOT path as well (see xyzz_acc_affine_slow)
+template <class F> __device__ __noinline__ Jac<F> jac_double_v(Jac<F> g);
 template <class F> BLSMI_DEV Jac<F> jac_add_affine_i(const Jac<F>& g, const Aff<F>& o) {
     const F z1z1 = f_store(f_sqr(g.z));
     const F u2 = f_store(f_mul(o.x, z1z1));
@@ -65,7 +68,7 @@ template <class F> BLSMI_DEV Jac<F> jac_add_affine_i(const Jac<F>& g, const Aff<
     r.z = f_store(f_sub(f_sub(f_sqr(f_add(g.z, h)), z1z1), hh));
     r.inf = 0;
     if (h0 & live) {                                                   // rare: same x
-        if (f_is_zero(rr0)) r = jac_double(g);                         // same point (g1.go:506-509)
+        if (f_is_zero(rr0)) r = jac_double_v(g);                         // same point (g1.go:506-509)
         else r.inf = -1;                                               // opposite points: z3 == 0
     }
     r = jac_select(g.inf, to_jac(o), r);                               // g1.go:486-488
@@ -95,7 +98,7 @@ template <class F> BLSMI_DEV Jac<F> jac_add_i(const Jac<F>& g, const Jac<F>& o) 
     r.z = f_store(f_mul(f_sub(f_sub(f_sqr(f_add(g.z, o.z)), z1z1), z2z2), h));
     r.inf = 0;
     if (h0 & live) {
-        if (f_is_zero(rr0)) r = jac_double(g);
+        if (f_is_zero(rr0)) r = jac_double_v(g);
         else r.inf = -1;
     }
     r = jac_select(g.inf, o, r);
@@ -108,17 +111,19 @@ template <class F> BLSMI_DEV Jac<F> jac_add_i(const Jac<F>& g, const Jac<F>& o) 
 // registers (rocprofv3, profiles/r03a: the out-of-line G1 kernels issued one VALU instruction per 8-9 cycles per SIMD against 5
 // for the pairing kernels, behind 3.5 TB/s of argument traffic).
 template <class F> __device__ __noinline__ Jac<F> jac_double(const Jac<F>& g) { return jac_double_i(g); }
+template <class F> __device__ __noinline__ Jac<F> jac_double_v(Jac<F> g) { return jac_double_i(g); }
 template <class F> __device__ __noinline__ Jac<F> jac_add_affine(const Jac<F>& g, const Aff<F>& o) { return jac_add_affine_i(g, o); }
 // acc += o for loops that add MANY points into one accumulator (the MSM's bucket pass): the same mixed addition with its special cases
 // (an infinite operand, equal x) BRANCHED out to the out-of-line function instead of selected at the end.  jac_add_affine_i keeps g, o
 // and r alive to its last line for those selects -- 112 of a G1 lane's registers before any temporary, 50 spilled in the bucket kernel
 // (6.3 GB of scratch written per 2^20-point MSM, rocprofv3 WRITE_SIZE) -- here every coordinate dies at its last use.  The rare path
 // is taken by whole lanes only when one of their operands is special.
+template <class F> __device__ __noinline__ Jac<F> jac_add_affine_v(Jac<F> g, Aff<F> o) { return jac_add_affine_i(g, o); }
 template <class F> BLSMI_DEV void jac_acc_affine(Jac<F>& g, const Aff<F>& o) {
     const F z1z1 = f_store(f_sqr(g.z));
     const F h = f_store(f_sub(f_mul(o.x, z1z1), g.x));
     const F rr0 = f_store(f_sub(f_mul(f_mul(o.y, g.z), z1z1), g.y));
-    if (__builtin_expect((g.inf != 0) | (o.inf != 0) | f_is_zero(h), 0)) { g = jac_add_affine(g, o); return; }
+    if (__builtin_expect((g.inf != 0) | (o.inf != 0) | f_is_zero(h), 0)) { g = jac_add_affine_v(g, o); return; }
     const F hh = f_store(f_sqr(h));
     const F z3 = f_store(f_sub(f_sub(f_sqr(f_add(g.z, h)), z1z1), hh));
     const F i = f_store(f_muls<4>(hh));
@@ -157,15 +162,18 @@ template <class F> BLSMI_DEV Xyzz<F> jac_to_xyzz(const Jac<F>& j) {
     r.inf = j.inf;
     return r;
 }
-template <class F> __device__ __noinline__ void xyzz_acc_affine_slow(Xyzz<F>& g, const Aff<F>& o) {
-    if (g.inf != 0) { g.x = o.x; g.y = o.y; g.zz = field_consts<F>::one(); g.zzz = field_consts<F>::one(); g.inf = o.inf; return; }   // (also o infinite: g stays infinite)
-    if (o.inf != 0) return;
-    g = jac_to_xyzz(jac_add_affine(xyzz_to_jac(g), o));                   // equal x: the same point (doubling) or opposite points (infinity)
+// (operands and result BY VALUE: a reference parameter of an out-of-line function makes the caller's accumulator an address-taken stack
+//  object, and then it lives in scratch memory on the HOT path too -- the bucket pass of the MSM stored and re-loaded its 57-word
+//  accumulator and the 29-word point around every addition: 6.3 GB of scratch writes per 2^20-point launch, profiles/r05a_counters.json)
+template <class F> __device__ __noinline__ Xyzz<F> xyzz_acc_affine_slow(Xyzz<F> g, Aff<F> o) {
+    if (g.inf != 0) { g.x = o.x; g.y = o.y; g.zz = field_consts<F>::one(); g.zzz = field_consts<F>::one(); g.inf = o.inf; return g; }   // (also o infinite: g stays infinite)
+    if (o.inf != 0) return g;
+    return jac_to_xyzz(jac_add_affine(xyzz_to_jac(g), o));                // equal x: the same point (doubling) or opposite points (infinity)
 }
 template <class F> BLSMI_DEV void xyzz_acc_affine(Xyzz<F>& g, const Aff<F>& o) {
     const F p = f_store(f_sub(f_mul(o.x, g.zz), g.x));                    // U2 - X1
     const F r = f_store(f_sub(f_mul(o.y, g.zzz), g.y));                   // S2 - Y1
-    if (__builtin_expect((g.inf != 0) | (o.inf != 0) | f_is_zero(p), 0)) { xyzz_acc_affine_slow(g, o); return; }
+    if (__builtin_expect((g.inf != 0) | (o.inf != 0) | f_is_zero(p), 0)) { g = xyzz_acc_affine_slow(g, o); return; }
     const F pp = f_store(f_sqr(p));
     const F ppp = f_store(f_mul(p, pp));
     const F q = f_store(f_mul(g.x, pp));

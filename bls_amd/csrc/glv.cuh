@@ -161,12 +161,14 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
         tj[j].x = f_store(f_mul(tj[j].x, zi2));
         tj[j].y = f_store(f_mul(f_mul(tj[j].y, zi2), zi));
     }
-    Jac<F> res = jac_zero<F>();
+    // (the accumulator is a local of its own, copied into the returned object at the end: as the returned object itself -- NRVO -- it is the
+    //  caller's memory slot, and every doubling stored it there)
+    Jac<F> acc = jac_zero<F>();
 #pragma unroll 1
     for (int w = G::NWIN - 1; w >= 0; w--) {
         if (w != G::NWIN - 1) {
 #pragma unroll 1
-            for (int d = 0; d < 5; d++) res = jac_double_i(res);
+            for (int d = 0; d < 5; d++) acc = jac_double_i(acc);
         }
 #pragma unroll 1
         for (int s = 0; s < G::NS; s++) {
@@ -176,9 +178,11 @@ __device__ Jac<F> glv_mul(const Aff<F>& p, const u8* scalar) {
             t.z = tj[1].z;                                                  // = 1, and stays 1 under every endomorphism
             const Jac<F> e = glv_endo_s(t, s);
             Aff<F> ea; ea.x = e.x; ea.y = f_select(neg, f_store(f_neg(e.y)), e.y); ea.inf = e.inf;
-            res = jac_add_affine_i(res, ea);
+            acc = jac_add_affine_i(acc, ea);
         }
     }
+    Jac<F> res;
+    res.x = acc.x; res.y = acc.y; res.z = acc.z; res.inf = acc.inf;
     return res;
 }
 
