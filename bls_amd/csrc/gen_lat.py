@@ -42,6 +42,7 @@ RMONT = 1 << (NLIMB * LB)
 
 # job / level kinds (shared with k_lat.hip)
 K_MUL, K_LIN, K_INV, K_LOAD, K_OUT12, K_CHECK1, K_OUTRAW12, K_OUTAFF, K_ISZERO, K_SEL, K_SQR = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+K_REP = 11            # not a level: "the next `len` levels run `count` times" (rolled squaring runs, see Pairing.exp_by_x)
 LANES = 64
 TMAX = 7              # terms per MUL operand (descriptor: 7 + 7 term fields)
 TLIN = 14             # terms of a LIN job (both operand fields)
@@ -53,7 +54,7 @@ CMAX = 15             # |coefficient| of a gathered term
 
 
 class Node:
-    __slots__ = ("id", "kind", "x", "y", "V", "level", "slot", "last", "aux", "reduce", "pin")
+    __slots__ = ("id", "kind", "x", "y", "V", "level", "slot", "last", "aux", "reduce", "pin", "ring")
 
     def __init__(self, nid, kind, x=None, y=None, V=2, aux=None):
         self.id, self.kind, self.x, self.y, self.V, self.aux = nid, kind, x, y, V, aux
@@ -61,6 +62,7 @@ class Node:
         self.last = -1
         self.reduce = False
         self.pin = False
+        self.ring = None                 # (run, iteration, slot index): a job of a ROLLED squaring run -- fixed slot, a level of its own (schedule)
 
 
 class Lin(dict):
@@ -165,7 +167,8 @@ class Builder:
 
     def lin(self, x, force_reduce=False):
         """S = normalise(x): a node again (L = 1)."""
-        x = self.flatten(x)
+        if not getattr(self, "noflatten", False):
+            x = self.flatten(x)
         if len(x) == 1 and not force_reduce:
             (k, c), = x.items()
             if c == 1:
@@ -346,13 +349,16 @@ class Tower:
     def frob12_c(self, p):
         return self.frob12_k[p % 12]
 
-    def cyc_sqr(self, f):
+    def cyc_sqr(self, f, ring=None):
         """Granger-Scott squaring on the cyclotomic subgroup (same element as fq12.go:180-195 there), written with SQUARINGS only,
         so that its product level runs the squaring core (SQR level).  For each Fq4 pair (a, b), with S(x) = 3 x^2:
             3 (a^2 + xi b^2) = (S(a0) - S(a1) + 2 S(b0) - S(b0+b1),   S(a0+a1) - S(a0) - S(a1) + S(b0+b1) - 2 S(b1))
             3 (2ab)          = (S(a0+b0) - S(a0) - S(b0) - S(a1+b1) + S(a1) + S(b1),   S(a0+b1) + S(a1+b0) - S(a0) - S(b1) - S(a1) - S(b0))
         10 squarings of operands with L <= 2 per pair, 30 per squaring; every output is ONE linear job of <= 8 terms, L <= 10."""
         S = self.b.sqr3
+        first_node = len(self.b.nodes)
+        if ring is not None:
+            self.b.noflatten = True                                        # every output is exactly ONE job over this iteration's squares and the previous outputs
         z0, z4, z3 = f[0]; z2, z1, z5 = f[1]
         def fp4(a, b):
             sa0, sa1, sb0, sb1 = S(a[0]), S(a[1]), S(b[0]), S(b[1])
@@ -362,13 +368,30 @@ class Tower:
             B = (s00 - sa0 - sb0 - s11 + sa1 + sb1, s01 + s10 - sa0 - sb1 - sa1 - sb0)
             return A, B                                                    # 3 (a^2 + xi b^2), 3 (2ab)
         a0, a1 = fp4(z0, z1); b0, b1 = fp4(z2, z3); c0, c1 = fp4(z4, z5)
-        L2 = lambda t: self.lin2(t, False)
+        L2 = lambda t: self.lin2(t, bool(ring is not None and ring[2]))
         r00 = L2(self.sub2(a0, self.sc2(z0, 2)))
         r11 = L2(self.add2(a1, self.sc2(z1, 2)))                          # 3 * 2ab + 2 z1
         r01 = L2(self.sub2(b0, self.sc2(z4, 2)))
         r12 = L2(self.add2(b1, self.sc2(z5, 2)))
         r10 = L2(self.add2(self.nr2(c1), self.sc2(z2, 2)))                # 3 xi (2ab) + 2 z2
         r02 = L2(self.sub2(c0, self.sc2(z3, 2)))
+        if ring is not None:
+            # a ROLLED iteration: its 30 squarings and 12 recombinations get fixed slots -- squares: ring 0..29 (dead after this iteration's
+            # recombination level), outputs: ring 30 + 12 (iteration mod 2) + j (ping-pong: iteration i + 1 reads them while it writes its own)
+            self.b.noflatten = False
+            run, it, _ = ring
+            outs = [c for pair in ((r00, r01, r02), (r10, r11, r12)) for q in pair for c in q]
+            out_nodes = []
+            for c in outs:
+                assert len(c) == 1 and list(c.values()) == [1]
+                out_nodes.append(next(iter(c)))
+            new = self.b.nodes[first_node:]
+            sq = [n for n in new if n.kind == "sqr3"]
+            assert len(sq) == 30 and len(out_nodes) == 12 and all(n.kind == "lin" for n in out_nodes)
+            for k, n in enumerate(sq):
+                n.ring = (run, it, k)
+            for j, n in enumerate(out_nodes):
+                n.ring = (run, it, 30 + 12 * (it & 1) + j)
         return ((r00, r01, r02), (r10, r11, r12))
 
     def mul12_sparse5(self, f, l0, l1, l2, l4, l5):
@@ -567,11 +590,29 @@ class Pairing:
         return T.conj12(g)                                          # x < 0 (pairing.go:71-73)
 
     def exp_by_x(self, f, e):                                          # pairing.go:92-98
+        """ROLLED (self.rolled, programs '...r'): a run of n >= 4 squarings between two multiplications -- the zero runs of |x| -- becomes
+        iteration 0, then a LOOP over iterations (1, 2), (3, 4), ... (K_REP: the kernel runs the same four levels (n - 2) // 2 times), then what
+        is left, straight-line.  For the levels to repeat byte for byte the iterations use fixed slots (ping-pong, Tower.cyc_sqr) and a fixed
+        value-reduction pattern: every EVEN iteration reduces its outputs (the straight-line form reduces when the bound demands it, about
+        every fifth squaring).  The last iteration of a run is an ordinary squaring: its outputs live on after the run."""
         T = self.T
         res = f
-        for i in range(e.bit_length() - 2, -1, -1):
-            res = T.cyc_sqr(res)
-            if (e >> i) & 1:
+        bits = [(e >> i) & 1 for i in range(e.bit_length() - 2, -1, -1)]
+        k = 0
+        while k < len(bits):
+            run = 1
+            while bits[k + run - 1] == 0 and k + run < len(bits):
+                run += 1                                               # squarings up to and including the one whose bit is set (or the last)
+            if getattr(self, "rolled", False) and run >= 4:
+                rid = self.nruns = getattr(self, "nruns", 0) + 1
+                for it in range(run - 1):
+                    res = T.cyc_sqr(res, ring=(rid, it, it % 2 == 0))
+                res = T.cyc_sqr(res)
+            else:
+                for _ in range(run):
+                    res = T.cyc_sqr(res)
+            k += run
+            if bits[k - 1]:
                 res = T.mul12(res, f)
         return T.conj12(res)
 
@@ -869,6 +910,9 @@ def build_program(kind):
              'miller1x' -- inputs P (buf 0), Q (buf 1); output MillerLoop(P, Q), the reference's value (pairing.go:16-75), as 12 Fq"""
     b = Builder()
     pr = Pairing(b)
+    if kind == "pairing1r":                                              # pairing1 with its squaring runs ROLLED (K_REP): the A/B partner of pairing1 (DESIGN 3a)
+        pr.rolled = True
+        kind = "pairing1"
     if kind in ("hashfin1", "hashfin2", "cofac2"):
         return build_hash_program(b, pr.T, kind)
     if kind in ("subgrp1", "subgrp2"):
@@ -1194,6 +1238,7 @@ def schedule(b):
     consts = [n for n in nodes if n.kind == "const"]
     for n in consts:
         n.level = -1
+    ring_level, exclusive = {}, {}
     for n in nodes:
         if n.kind == "const":
             continue
@@ -1204,10 +1249,19 @@ def schedule(b):
                 for d in lin:
                     e = max(e, d.level + 1)
         lv = None
-        for i in range(e, len(levels)):
-            if levels[i][0] == k and len(levels[i][1]) < cap[k]:
-                lv = i
-                break
+        if n.ring is not None:                                             # a rolled iteration's jobs: a level of their own (nothing else may join it: the level must repeat byte for byte)
+            tag = (n.ring[0], n.ring[1], k)
+            lv = ring_level.get(tag)
+            if lv is None:
+                levels.append([k, []])
+                lv = len(levels) - 1
+                ring_level[tag] = lv; exclusive[lv] = tag
+            assert lv >= e
+        else:
+            for i in range(e, len(levels)):
+                if i not in exclusive and levels[i][0] == k and len(levels[i][1]) < cap[k]:
+                    lv = i
+                    break
         if lv is None:
             levels.append([k, []])
             lv = len(levels) - 1
@@ -1234,16 +1288,27 @@ def schedule(b):
         for n in tnodes:
             n.slot = nslot + n.pin[1]
         nslot += len(tnodes)
+    ring_nodes = [n for n in nodes if n.ring is not None]
+    if ring_nodes:                                                         # the rolled runs' fixed slots: one block of 54, shared by all runs (they follow one another)
+        ring_base = nslot; nslot += 54
+        by_slot = {}
+        for n in ring_nodes:
+            n.slot = ring_base + n.ring[2]
+            by_slot.setdefault(n.slot, []).append(n)
+        for lst in by_slot.values():                                       # users of one fixed slot must not overlap: written strictly after the previous value's last read
+            lst.sort(key=lambda n: n.level)
+            for a, c in zip(lst, lst[1:]):
+                assert c.level > a.last, ("rolled run: slot reused while live", a.ring, a.level, a.last, c.ring, c.level)
     free = []
     expiring = {}
     for n in nodes:
-        if n.kind != "const" and not n.pin:
+        if n.kind != "const" and not n.pin and n.ring is None:
             expiring.setdefault(n.last, []).append(n)
     for li, (k, jobs) in enumerate(levels):
         for n in expiring.get(li - 1, []):  # values last read in an EARLIER level are dead (a multi-wave workgroup gathers and
             free.append(n.slot)             # stores of one level without a barrier in between: no reuse within the level)
         for n in jobs:
-            if n.pin:
+            if n.pin or n.ring is not None:
                 continue
             if free:
                 n.slot = free.pop()
@@ -1251,6 +1316,19 @@ def schedule(b):
                 n.slot = nslot; nslot += 1
     p = Program()
     p.levels, p.consts, p.nslot, p.out, p.out_nodes, p.nodes = levels, consts, nslot, b.out[0], out_nodes, nodes
+    # loops: per rolled run, iterations 1 .. n - 2 sit in consecutive exclusive levels (SQR, LIN each); (1, 2), (3, 4), ... repeat
+    p.repeats = []
+    runs = {}
+    for lv, (rid, it, k) in exclusive.items():
+        runs.setdefault(rid, {}).setdefault(it, []).append(lv)
+    for rid, its in sorted(runs.items()):
+        nit = max(its) + 1
+        count = (nit - 1) // 2                                             # iterations 1 .. nit - 1 in pairs
+        if count >= 2:
+            start = min(its[1])
+            for j in range(2 * count):
+                assert sorted(its[1 + j]) == [start + 2 * j, start + 2 * j + 1], "rolled run: iteration levels are not consecutive"
+            p.repeats.append((start, 4, count))
     p.nout = b.out[2] if len(b.out) > 2 else len(out_nodes)
     p.table_base = table_base
     p.table_ncoord = {tid: nc for tid, (nc, _) in enumerate(getattr(b, "tables", []))}
@@ -1305,7 +1383,13 @@ def encode(p):
     desc = bytearray()
     NOTERM = 16 << 11                       # coefficient 0, slot 0
     dummy = p.nslot                         # idle lanes write to a spare slot
-    for k, jobs in p.levels:
+    rep_at = {start: (ln, cnt) for start, ln, cnt in getattr(p, "repeats", [])}
+    body = None                             # (first level, length, count, encodings of the first pass) while inside a rolled run
+    for li, (k, jobs) in enumerate(p.levels):
+        if li in rep_at:
+            ln, cnt = rep_at[li]
+            hdr.append((K_REP, ln, cnt, 0))
+            body = [li, ln, cnt, []]
         ntx = nty = 0
         rows = []
         # A LIN level rarely has more than 16 jobs: its jobs are then spread over 4 (or 2) adjacent lanes each, every lane gathers
@@ -1337,14 +1421,27 @@ def encode(p):
             rows.append([n.slot] + xs + [NOTERM] * (7 - len(xs)) + ys + [NOTERM] * (7 - len(ys)) + [flags])
         while len(rows) < LANES:
             rows.append([dummy] + [NOTERM] * 14 + [0])
-        for r in rows:
-            desc += struct.pack("<16H", *r)
         red = 0x80 if (k == K_LIN and any(n.reduce for n in jobs)) else 0   # value reduction is level-wide (always valid, never needed less)
-        hdr.append((k | red, ntx, nty, split if k == K_LIN else len(jobs)))   # last byte: LIN: lanes per job; otherwise the job count
+        h = (k | red, ntx, nty, split if k == K_LIN else len(jobs))           # last byte: LIN: lanes per job; otherwise the job count
+        enc = b"".join(struct.pack("<16H", *r) for r in rows)
+        if body is not None:
+            first, ln, cnt, seen = body
+            j = li - first
+            if j < ln:
+                seen.append((h, enc))                                      # first pass: emitted
+            else:
+                assert (h, enc) == seen[j % ln], "rolled run: level %d differs from its first pass" % li   # later passes: must BE the first pass
+                if j == ln * cnt - 1:
+                    body = None
+                continue
+            if ln * cnt == ln:
+                body = None
+        desc += enc
+        hdr.append(h)
     out_kind = {"check1": K_CHECK1, "out12": K_OUT12, "outraw12": K_OUTRAW12, "outaff": K_OUTAFF, "iszero": K_ISZERO}[p.out]
     blob = bytearray()
     assert len(p.out_nodes) <= 12
-    blob += struct.pack("<8I", 0x54414c42, len(p.levels), p.nslot + 1, len(p.consts), out_kind, p.nout, len(p.out_nodes) - p.nout, 0)
+    blob += struct.pack("<8I", 0x54414c42, len(hdr), p.nslot + 1, len(p.consts), out_kind, p.nout, len(p.out_nodes) - p.nout, 0)   # (levels as stored: a rolled run counts once, plus its K_REP marker)
     blob += struct.pack("<12H", *([n.slot for n in p.out_nodes] + [0] * (12 - len(p.out_nodes)))) + b"\0" * 8
     for h in hdr:
         blob += struct.pack("<4B", *h)
@@ -1354,6 +1451,35 @@ def encode(p):
         blob += struct.pack("<16i", *(mont_limbs(n.aux) + [n.slot]))
     blob += desc
     return bytes(blob)
+
+
+def executed_levels(blob):
+    """the level stream as the kernel EXECUTES it: [(header 4-tuple, the level's 2 048 descriptor bytes)], K_REP loops expanded -- the decoder's view of
+    encode()'s output (tests/test_lat_program.py compares it with the straight-line encoding of the same schedule)"""
+    magic, nhdr, nslot, nconst = struct.unpack_from("<4I", blob, 0)
+    assert magic == 0x54414c42
+    off = 32 + 24 + 8
+    hdr = [struct.unpack_from("<4B", blob, off + 4 * i) for i in range(nhdr)]
+    pos = off + 4 * nhdr
+    pos += (-pos) % 16
+    pos += 64 * nconst
+    out, l, dl = [], 0, 0
+    rep_left, rep_lo, rep_hi, rep_dlo = 0, 0, None, 0
+    while l < nhdr:
+        h = hdr[l]
+        if h[0] & 0x7f == K_REP:
+            rep_left, rep_lo, rep_hi, rep_dlo = h[2], l + 1, l + 1 + h[1], dl
+            l += 1
+            continue
+        out.append((h, blob[pos + 2048 * dl: pos + 2048 * (dl + 1)]))
+        l += 1; dl += 1
+        if rep_hi is not None and l == rep_hi:
+            if rep_left > 1:
+                rep_left -= 1; l, dl = rep_lo, rep_dlo
+            else:
+                rep_hi = None
+    assert pos + 2048 * dl == len(blob), "descriptor rows left over"
+    return out
 
 
 def stats(p):
@@ -1372,7 +1498,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "verify1s", "pairing1", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "powc12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
+    for name in ("verify2", "verify1s", "pairing1", "pairing1r", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "powc12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

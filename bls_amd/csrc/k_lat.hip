@@ -25,6 +25,7 @@
 
 namespace {
 constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8, K_SEL = 9, K_SQR = 10;
+constexpr int K_REP = 11;               // not a level: "the next `len` (bits 8-15) levels run `count` (bits 16-23) times" -- the rolled squaring runs of gen_lat.py (Pairing.exp_by_x)
 constexpr int SLOT_WORDS = 16;
 
 struct LatHeader {                      // gen_lat.py: encode()
@@ -126,8 +127,21 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
     }
     __syncthreads();
     uint4 d0 = desc[(size_t)lane * 2], d1 = desc[(size_t)lane * 2 + 1];
-    for (u32 l = 0; l < nlevels; l++) {
+    // l walks the header words, dl the descriptor blocks (one per LEVEL: a K_REP word has none).  A loop is entered at its K_REP word and
+    // left after `count` passes over [rep_lo, rep_hi); all of this is wave-uniform scalar state.
+    u32 dl = 0, rep_left = 0, rep_lo = 0, rep_hi = 0xffffffffu, rep_dlo = 0;
+    for (u32 l = 0; l < nlevels;) {
         const u32 h = lvl[l];
+        if ((h & 0x7f) == K_REP) {                                             // (the prefetched descriptors are the loop's first level's: dl does not move)
+            rep_left = (h >> 16) & 0xff; rep_lo = l + 1; rep_hi = l + 1 + ((h >> 8) & 0xff); rep_dlo = dl;
+            l++;
+            continue;
+        }
+        u32 nl = l + 1, ndl = dl + 1;                                          // where the wave goes after this level
+        if (nl == rep_hi) {
+            if (rep_left > 1) { rep_left--; nl = rep_lo; ndl = rep_dlo; }
+            else rep_hi = 0xffffffffu;
+        }
         const int kind = h & 0x7f, ntx = (h >> 8) & 0xff, nty = (h >> 16) & 0xff, njobs = (int)(h >> 24);
         const bool reduce = (h & 0x80) != 0;
         const u32 f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};     // 16 x u16: dst, 7 x-terms, 7 y-terms, flags
@@ -139,8 +153,8 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
             ty[i] = (f[jy >> 1] >> (16 * (jy & 1))) & 0xffffu;
         }
         const u32 dst = f[0] & 0xffffu;
-        if (l + 1 < nlevels) {                                                 // next level's descriptors while this one computes
-            d0 = desc[((size_t)(l + 1) * 64 + lane) * 2]; d1 = desc[((size_t)(l + 1) * 64 + lane) * 2 + 1];
+        if (nl < nlevels) {                                                    // next level's descriptors while this one computes
+            d0 = desc[((size_t)ndl * 64 + lane) * 2]; d1 = desc[((size_t)ndl * 64 + lane) * 2 + 1];
         }
         i32 r[NL];
         if (kind == K_MUL) {
@@ -256,6 +270,7 @@ __global__ void __launch_bounds__(64, 1) k_lat(const u8* prog, const u8* b0, siz
         __builtin_amdgcn_wave_barrier();
         store_slot(S, dst, r);
         __builtin_amdgcn_wave_barrier();
+        l = nl; dl = ndl;
     }
     // results leave LDS
     const int okind = (int)H->out_kind;

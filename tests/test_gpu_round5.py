@@ -1,0 +1,81 @@
+"""-m gpu, round 5: the rolled level program (K_REP loops in k_lat.hip), blsmi_set_option, the environment read once."""
+import numpy as np
+import pytest
+
+from gpu_common import P, RC, rand_g1, rand_g2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bls_amd import engine
+    engine.init(0)
+    yield engine
+    engine.set_option("lat_rolled", 0)
+
+
+def test_rolled_pairing_program_on_the_device(eng):
+    """pairing1r: the squaring runs of the five ExpByX as loops the kernel repeats (K_REP; the reference's own loop, fq12.go:112-118).  Same
+    Fq12 bits as the straight-line program and as the oracle, at one tuple, a ragged handful and a batch that queues several waves per SIMD."""
+    xs = P.XORShift(5201)
+    base = 6
+    w1 = [rand_g1(xs) for _ in range(base)]; w2 = [rand_g2(xs) for _ in range(base)]
+    want = RC.pairing_batch(b"".join(w1), b"".join(w2), base)
+    try:
+        for n in (1, 5, 70, 3000):
+            a = b"".join(w1[i % base] for i in range(n)); b = b"".join(w2[i % base] for i in range(n))
+            eng.set_option("lat_rolled", 0)
+            straight = eng.pairing_batch(a, b, n)
+            eng.set_option("lat_rolled", 1)
+            rolled = eng.pairing_batch(a, b, n)
+            assert np.array_equal(rolled, straight)
+            assert np.array_equal(rolled[:min(n, base)], want[:min(n, base)])
+            assert np.array_equal(rolled[n - 1], want[(n - 1) % base])
+    finally:
+        eng.set_option("lat_rolled", 0)
+
+
+def test_set_option_rejects_unknown_names(eng):
+    lib = eng._lib()
+    assert lib.blsmi_set_option(b"no_such_option", 1) == -3 and lib.blsmi_set_option(None, 1) == -3
+    for name in ("agg_cofactor_pow", "msm_sort", "dup_force_sort", "lat_rolled"):
+        assert lib.blsmi_set_option(name.encode(), 1) == 0
+    eng.set_option("dup_force_sort", 0); eng.set_option("lat_rolled", 0)
+
+
+def test_environment_is_read_at_initialisation_only(eng):
+    """BLSMI_* variables changed AFTER the library initialised change nothing (include/blsmi.h "Environment"): a large g2pubs aggregate keeps
+    taking the cofactor-power program whatever os.environ says; blsmi_set_option is what switches it."""
+    import ctypes
+    import hashlib
+    import os
+    n = 65536
+    nk = 64
+    sk = b"".join(hashlib.sha256(b"env-sk-%d" % i).digest()[:31].rjust(32, b"\0") for i in range(nk))
+    pks, _ = eng.g2_mul_generator_batch(sk, nk)
+    msgs = eng.PackedMsgs([hashlib.sha256(b"env %d" % i).digest() for i in range(n)])
+    sigs, _ = eng.g2pubs_sign_batch(msgs, sk * (n // nk))
+    agg = eng.g1_sum(sigs.reshape(-1), n)
+    allpk = np.ascontiguousarray(np.tile(pks, (n // nk, 1))).reshape(-1)
+    lib = eng._lib()
+
+    def prof_of_call():
+        lib.blsmi_set_profiling(1)
+        v = eng.g2pubs_verify_aggregate(msgs, allpk, agg)
+        buf = ctypes.create_string_buffer(8192); lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
+        return v, buf.value.decode()
+    saved = os.environ.get("BLSMI_AGG_COFACTOR_POW")
+    try:
+        os.environ["BLSMI_AGG_COFACTOR_POW"] = "0"
+        v, prof = prof_of_call()
+        assert v is True and "k_lat:powc12raw" in prof                        # the environment is not consulted any more
+        eng.set_option("agg_cofactor_pow", 0)
+        v, prof = prof_of_call()
+        assert v is True and "k_lat:powc12raw" not in prof
+    finally:
+        eng.set_option("agg_cofactor_pow", 1)
+        if saved is None:
+            os.environ.pop("BLSMI_AGG_COFACTOR_POW", None)
+        else:
+            os.environ["BLSMI_AGG_COFACTOR_POW"] = saved

@@ -37,6 +37,31 @@ def test_pairing_program_matches_oracle(progs, kats):
     assert out == [int(v) for v in kats["pairing_g1gen_g2gen"]]               # the reference's own vector, pairing_test.go:9-58
 
 
+def test_rolled_pairing_program(kats):
+    """pairing1r = pairing1 with the squaring runs of its five ExpByX (pairing.go:92-98: the reference writes them as loops, fq12.go:112-118)
+    ROLLED: fixed ping-pong slots, a value reduction on every even iteration, the kernel repeats four levels (K_REP).  (i) the schedule with
+    its fixed slots computes the reference's pairing (exact simulator); (ii) what the kernel executes -- the encoding with its loops expanded --
+    is byte for byte the straight-line encoding of the same schedule; (iii) the image is a third smaller."""
+    p = G.schedule(G.build_program("pairing1r"))
+    assert len(p.repeats) == 15 and sum(c for _, _, c in p.repeats) == 5 * (3 + 15 + 7) - 1      # runs of 9, 32, 16 squarings in |x|; 8, 32, 15 in |x| >> 1
+    xs = P.XORShift(6)
+    for Pa, Qa in [(P.G1_GEN, P.G2_GEN), _pt(xs)]:
+        out = G.simulate(p, {0: [Pa[0], Pa[1]], 1: [Qa[0][0], Qa[0][1], Qa[1][0], Qa[1][1]]})
+        assert out == P.fq12_flat(P.pairing(Pa, Qa))
+    out = G.simulate(p, {0: list(P.G1_GEN), 1: [P.G2_GEN[0][0], P.G2_GEN[0][1], P.G2_GEN[1][0], P.G2_GEN[1][1]]})
+    assert out == [int(v) for v in kats["pairing_g1gen_g2gen"]]
+    rolled = G.encode(p)
+    reps, p.repeats = p.repeats, []
+    straight = G.encode(p)
+    p.repeats = reps
+    a, b = G.executed_levels(rolled), G.executed_levels(straight)
+    assert len(a) == len(b) == len(p.levels) and a == b
+    assert len(rolled) < 0.7 * len(straight)
+    # the straight-line program next to it: the same number of executed levels (rolling costs no level), fewer slots
+    q = G.schedule(G.build_program("pairing1"))
+    assert len(q.levels) == len(p.levels) and q.nslot + 54 >= p.nslot - 2
+
+
 def test_exact_miller_program_is_the_reference_miller_value(progs):
     p = progs["miller1x"]
     xs = P.XORShift(15)
