@@ -305,7 +305,7 @@ struct EnvCfg {
 } g_env;
 std::atomic<bool> g_agg_cofactor_pow{true};    // BLSMI_AGG_COFACTOR_POW / blsmi_set_option("agg_cofactor_pow")
 std::atomic<bool> g_msm_sort{true};            // BLSMI_MSM_SORT / blsmi_set_option("msm_sort")
-std::atomic<bool> g_lat_rolled{false};         // BLSMI_LAT_ROLLED / blsmi_set_option("lat_rolled"): small Pairing calls run the level program with ROLLED squaring runs (pairing1r; A/B)
+std::atomic<bool> g_lat_rolled{true};          // BLSMI_LAT_ROLLED / blsmi_set_option("lat_rolled"): 0 = small Pairing calls take the STRAIGHT-LINE copy of their level program (pairing1s) instead of the one with rolled squaring runs (A/B)
 std::atomic<bool> g_dup_force_sort{false};     // BLSMI_DUP_FORCE_SORT / blsmi_set_option("dup_force_sort"): test hook, the duplicate screen's fallback on every call
 void load_env() {                       // caller holds g_mu; runs once per initialisation
     auto num = [](const char* name, size_t dflt) { const char* v = getenv(name); return v ? (size_t)strtoull(v, nullptr, 10) : dflt; };
@@ -327,7 +327,7 @@ void load_env() {                       // caller holds g_mu; runs once per init
     { const char* v = getenv("BLSMI_AGG_COFACTOR_POW"); g_agg_cofactor_pow = !(v && v[0] == '0'); }
     { const char* v = getenv("BLSMI_MSM_SORT"); g_msm_sort = !(v && v[0] == '0'); }
     g_dup_force_sort = getenv("BLSMI_DUP_FORCE_SORT") != nullptr;
-    { const char* v = getenv("BLSMI_LAT_ROLLED"); g_lat_rolled = v && v[0] != '0'; }
+    { const char* v = getenv("BLSMI_LAT_ROLLED"); g_lat_rolled = !(v && v[0] == '0'); }
 }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -732,8 +732,8 @@ bool jac_host_is_infinity(const uint8_t* rec, size_t wire_bytes) {
 static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n, hipStream_t s, int mode) {
     if (n == 0) return BLSMI_OK;
     if (mode == 0 && use_lat(n)) {                                         // small call: one pairing per wave (k_lat.hip)
-        const size_t prog = g_lat_rolled.load(std::memory_order_relaxed) ? (size_t)LAT_PAIRING1R_OFFSET : (size_t)LAT_PAIRING1_OFFSET;   // the same pairing, its squaring runs as loops
-        prof_mark(prog == LAT_PAIRING1_OFFSET ? "k_lat:pairing1" : "k_lat:pairing1r");
+        const size_t prog = g_lat_rolled.load(std::memory_order_relaxed) ? (size_t)LAT_PAIRING1_OFFSET : (size_t)LAT_PAIRING1S_OFFSET;   // the same pairing, its squaring runs unrolled (A/B partner)
+        prof_mark(prog == LAT_PAIRING1_OFFSET ? "k_lat:pairing1" : "k_lat:pairing1s");
         hipLaunchKernelGGL(k_lat, dim3((unsigned)n), dim3(64), lat_lds_bytes(prog), s, (const u8*)g_gens.lat + prog,
                            (const u8*)d_g1, (size_t)96, (const u8*)d_g2, (size_t)192, (const u8*)nullptr, (size_t)0, (const u8*)nullptr, (size_t)0,
                            (const u8*)nullptr, (u8*)nullptr, (u64*)d_out, n);

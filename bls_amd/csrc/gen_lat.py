@@ -454,6 +454,7 @@ class Pairing:
         self.b = b
         self.T = Tower(b)
         self.b3 = self.T.k2(f2mul((3, 0), B_TWIST))          # 3 b'
+        self.rolled = True                                   # exp_by_x: squaring runs as K_REP loops (build_program says when not)
 
     def dbl_step(self, R):
         """homogeneous projective doubling on E' (y^2 = x^3 + b', b' = 4 xi) and the tangent line at R, as (c0, o1, o0) of the
@@ -603,7 +604,7 @@ class Pairing:
             run = 1
             while bits[k + run - 1] == 0 and k + run < len(bits):
                 run += 1                                               # squarings up to and including the one whose bit is set (or the last)
-            if getattr(self, "rolled", False) and run >= 4:
+            if self.rolled and run >= 4:
                 rid = self.nruns = getattr(self, "nruns", 0) + 1
                 for it in range(run - 1):
                     res = T.cyc_sqr(res, ring=(rid, it, it % 2 == 0))
@@ -910,8 +911,11 @@ def build_program(kind):
              'miller1x' -- inputs P (buf 0), Q (buf 1); output MillerLoop(P, Q), the reference's value (pairing.go:16-75), as 12 Fq"""
     b = Builder()
     pr = Pairing(b)
-    if kind == "pairing1r":                                              # pairing1 with its squaring runs ROLLED (K_REP): the A/B partner of pairing1 (DESIGN 3a)
-        pr.rolled = True
+    # Every program with a final exponentiation has the squaring runs of its ExpByX ROLLED (K_REP loops, Pairing.exp_by_x): measured on one box
+    # against the straight-line form (tools/rolled_ab.py, profiles/r05_rolled_ab.log): lone Pairing kernel 1.464 -> 1.459 ms, 4 096 pairings
+    # 4.47 -> 4.41 ms, image 2.72 -> 1.82 MB.  'pairing1s' keeps the straight-line form of pairing1 as the A/B partner.
+    pr.rolled = kind != "pairing1s"
+    if kind == "pairing1s":
         kind = "pairing1"
     if kind in ("hashfin1", "hashfin2", "cofac2"):
         return build_hash_program(b, pr.T, kind)
@@ -1498,7 +1502,7 @@ def main():
     sys.setrecursionlimit(100000)
     out = bytearray()
     index = []
-    for name in ("verify2", "verify1s", "pairing1", "pairing1r", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "powc12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
+    for name in ("verify2", "verify1s", "pairing1", "pairing1s", "aggtail", "aggtail2", "finalexp1", "miller1raw", "miller1rawn", "miller1x", "hashfin1", "hashfin2", "cofac2", "subgrp1", "subgrp2", "msmfin1", "msmfin2", "mul1", "mul2", "mul12raw", "powc12raw", "sum0_1", "sum0_2", "sum1_1", "sum1_2", "sumfin_1", "sumfin_2"):
         p = schedule(build_program(name))
         blob = encode(p)
         index.append((name, len(out), len(blob)))

@@ -121,9 +121,11 @@ int blsmi_prefer_cpu(int shape, size_t n);
  * BLSMI_LAT_MAX / BLSMI_QUAD_MAX / BLSMI_QUAD_MIN (layout hand-overs; also blsmi_set_latency_threshold / _quad_threshold), BLSMI_MUL_GENERIC,
  * BLSMI_COMBINE_MAX / _WAIT_US / _INFLIGHT / _DEBUG (merging of concurrent one-tuple Verify calls).  A/B switches between code paths with
  * identical results: BLSMI_LAYOUT, BLSMI_GEN_LINES, BLSMI_HASH_G1_SPLIT, BLSMI_HASH_G2_PAIR, BLSMI_HASH_G2_PAIR_REDO_EVERY, BLSMI_COFAC2_PAIR,
- * BLSMI_SWU_WAVE_MAX, BLSMI_SIG_SIDE_MAX, BLSMI_SIDE_MAX, BLSMI_FIXED_WAVE_MAX, BLSMI_MSM_BUCKET_MIN, and the three that can ALSO be
+ * BLSMI_SWU_WAVE_MAX, BLSMI_SIG_SIDE_MAX, BLSMI_SIDE_MAX, BLSMI_FIXED_WAVE_MAX, BLSMI_MSM_BUCKET_MIN, and the four that can ALSO be
  * switched while running (atomically; a call in flight sees the old or the new value), through blsmi_set_option(name, 0 / 1):
- *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0).
+ *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0),
+ *   "lat_rolled" (BLSMI_LAT_ROLLED, default 1; 0: small Pairing calls run the straight-line copy of their level program instead of the one
+ *   whose squaring runs are loops).
  * Test hook: BLSMI_DEVICE_ALIAS (above).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
 int blsmi_set_option(const char *name, long long value);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);

@@ -12,11 +12,11 @@ def eng():
     from bls_amd import engine
     engine.init(0)
     yield engine
-    engine.set_option("lat_rolled", 0)
+    engine.set_option("lat_rolled", 1)
 
 
 def test_rolled_pairing_program_on_the_device(eng):
-    """pairing1r: the squaring runs of the five ExpByX as loops the kernel repeats (K_REP; the reference's own loop, fq12.go:112-118).  Same
+    """pairing1 (default) against pairing1s, its straight-line copy: the squaring runs of the five ExpByX as loops the kernel repeats (K_REP; the reference's own loop, fq12.go:112-118).  Same
     Fq12 bits as the straight-line program and as the oracle, at one tuple, a ragged handful and a batch that queues several waves per SIMD."""
     xs = P.XORShift(5201)
     base = 6
@@ -33,7 +33,7 @@ def test_rolled_pairing_program_on_the_device(eng):
             assert np.array_equal(rolled[:min(n, base)], want[:min(n, base)])
             assert np.array_equal(rolled[n - 1], want[(n - 1) % base])
     finally:
-        eng.set_option("lat_rolled", 0)
+        eng.set_option("lat_rolled", 1)
 
 
 def test_set_option_rejects_unknown_names(eng):
@@ -41,7 +41,7 @@ def test_set_option_rejects_unknown_names(eng):
     assert lib.blsmi_set_option(b"no_such_option", 1) == -3 and lib.blsmi_set_option(None, 1) == -3
     for name in ("agg_cofactor_pow", "msm_sort", "dup_force_sort", "lat_rolled"):
         assert lib.blsmi_set_option(name.encode(), 1) == 0
-    eng.set_option("dup_force_sort", 0); eng.set_option("lat_rolled", 0)
+    eng.set_option("dup_force_sort", 0)
 
 
 def test_environment_is_read_at_initialisation_only(eng):

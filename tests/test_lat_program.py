@@ -38,11 +38,11 @@ def test_pairing_program_matches_oracle(progs, kats):
 
 
 def test_rolled_pairing_program(kats):
-    """pairing1r = pairing1 with the squaring runs of its five ExpByX (pairing.go:92-98: the reference writes them as loops, fq12.go:112-118)
+    """pairing1 (and every program with a final exponentiation) has the squaring runs of its five ExpByX (pairing.go:92-98: the reference writes them as loops, fq12.go:112-118)
     ROLLED: fixed ping-pong slots, a value reduction on every even iteration, the kernel repeats four levels (K_REP).  (i) the schedule with
     its fixed slots computes the reference's pairing (exact simulator); (ii) what the kernel executes -- the encoding with its loops expanded --
     is byte for byte the straight-line encoding of the same schedule; (iii) the image is a third smaller."""
-    p = G.schedule(G.build_program("pairing1r"))
+    p = G.schedule(G.build_program("pairing1"))
     assert len(p.repeats) == 15 and sum(c for _, _, c in p.repeats) == 5 * (3 + 15 + 7) - 1      # runs of 9, 32, 16 squarings in |x|; 8, 32, 15 in |x| >> 1
     xs = P.XORShift(6)
     for Pa, Qa in [(P.G1_GEN, P.G2_GEN), _pt(xs)]:
@@ -58,8 +58,8 @@ def test_rolled_pairing_program(kats):
     assert len(a) == len(b) == len(p.levels) and a == b
     assert len(rolled) < 0.7 * len(straight)
     # the straight-line program next to it: the same number of executed levels (rolling costs no level), fewer slots
-    q = G.schedule(G.build_program("pairing1"))
-    assert len(q.levels) == len(p.levels) and q.nslot + 54 >= p.nslot - 2
+    q = G.schedule(G.build_program("pairing1s"))
+    assert not q.repeats and len(q.levels) == len(p.levels) and q.nslot + 54 >= p.nslot - 2
 
 
 def test_exact_miller_program_is_the_reference_miller_value(progs):

@@ -1,4 +1,4 @@
-"""A/B of the level program `pairing1` (straight-line) against `pairing1r` (its squaring runs as K_REP loops), same box, interleaved:
+"""A/B of the level program `pairing1s` (straight-line) against `pairing1` (its squaring runs as K_REP loops), same box, interleaved:
 lone bls.Pairing latency through the host entry point, the kernel's own duration (HIP events), and the batch sizes up to the latency
 path's hand-over.  VERDICT r04 item 8: measure the repeat construct, then adopt or close.   python tools/rolled_ab.py"""
 import ctypes
@@ -39,4 +39,4 @@ engine.set_option("lat_rolled", 0)
 hdr = open(os.path.join(ROOT, "bls_amd", "csrc", "lat_programs.h")).read()
 import re  # noqa: E402
 sz = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define LAT_(\w+)_BYTES (\d+)", hdr)}
-print("program bytes: pairing1 %d, pairing1r %d (%.0f %%)" % (sz["PAIRING1"], sz["PAIRING1R"], 100.0 * sz["PAIRING1R"] / sz["PAIRING1"]))
+print("program bytes: straight %d, rolled %d (%.0f %%)" % (sz["PAIRING1S"], sz["PAIRING1"], 100.0 * sz["PAIRING1"] / sz["PAIRING1S"]))
