@@ -285,7 +285,7 @@ inline bool use_quad(size_t n) { return g_pair_layout && n > std::min(g_lat_max.
 inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
 inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }
 inline bool mul_subgroup() { return !tl_mul_any && g_mul_subgroup.load(std::memory_order_relaxed); }
-inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 64; }
+inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 80; }   // k_lat.hip: SLOT_WORDS * 4
 // ---- the environment is read ONCE, at initialisation (under g_mu), never from an entry point ---------------------------------------
 // getenv racing a setenv in another thread is undefined (glibc), and a variable read per call silently changes what a concurrent caller
 // gets.  Every BLSMI_* variable is therefore read here and nowhere else; what the A/B tests flip at run time are the three

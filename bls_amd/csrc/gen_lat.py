@@ -1292,17 +1292,22 @@ def schedule(b):
         for n in tnodes:
             n.slot = nslot + n.pin[1]
         nslot += len(tnodes)
+    # slots by live range.  A rolled run's 54 fixed slots are taken from the FREE list at the run's first level and go back to it one by one, each when
+    # its last value is dead: a run borrows what the products around it have just released, and costs (almost) no LDS of its own.
     ring_nodes = [n for n in nodes if n.ring is not None]
-    if ring_nodes:                                                         # the rolled runs' fixed slots: one block of 54, shared by all runs (they follow one another)
-        ring_base = nslot; nslot += 54
-        by_slot = {}
-        for n in ring_nodes:
-            n.slot = ring_base + n.ring[2]
-            by_slot.setdefault(n.slot, []).append(n)
-        for lst in by_slot.values():                                       # users of one fixed slot must not overlap: written strictly after the previous value's last read
-            lst.sort(key=lambda n: n.level)
-            for a, c in zip(lst, lst[1:]):
-                assert c.level > a.last, ("rolled run: slot reused while live", a.ring, a.level, a.last, c.ring, c.level)
+    run_first = {}
+    for n in ring_nodes:
+        run_first[n.ring[0]] = min(run_first.get(n.ring[0], n.level), n.level)
+    starts, ends = {}, {}
+    for rid, lv in run_first.items():
+        starts.setdefault(lv, []).append(rid)
+    slot_last = {}
+    for n in ring_nodes:                                                   # every fixed slot goes back as soon as ITS last value is dead
+        key = (n.ring[0], n.ring[2])
+        slot_last[key] = max(slot_last.get(key, -1), n.last)
+    for key, lv in slot_last.items():
+        ends.setdefault(lv, []).append(key)
+    ring_slots = {}
     free = []
     expiring = {}
     for n in nodes:
@@ -1311,13 +1316,33 @@ def schedule(b):
     for li, (k, jobs) in enumerate(levels):
         for n in expiring.get(li - 1, []):  # values last read in an EARLIER level are dead (a multi-wave workgroup gathers and
             free.append(n.slot)             # stores of one level without a barrier in between: no reuse within the level)
+        for rid, idx in ends.get(li - 1, []):
+            free.append(ring_slots[rid][idx])
+        for rid in starts.get(li, []):
+            got = []
+            while len(got) < 54:
+                if free:
+                    got.append(free.pop())
+                else:
+                    got.append(nslot); nslot += 1
+            ring_slots[rid] = got
         for n in jobs:
-            if n.pin or n.ring is not None:
+            if n.pin:
+                continue
+            if n.ring is not None:
+                n.slot = ring_slots[n.ring[0]][n.ring[2]]
                 continue
             if free:
                 n.slot = free.pop()
             else:
                 n.slot = nslot; nslot += 1
+    by_slot = {}
+    for n in ring_nodes:
+        by_slot.setdefault(n.slot, []).append(n)
+    for lst in by_slot.values():                                           # users of one fixed slot must not overlap: written strictly after the previous value's last read
+        lst.sort(key=lambda n: n.level)
+        for a, c in zip(lst, lst[1:]):
+            assert c.level > a.last, ("rolled run: slot reused while live", a.ring, a.level, a.last, c.ring, c.level)
     p = Program()
     p.levels, p.consts, p.nslot, p.out, p.out_nodes, p.nodes = levels, consts, nslot, b.out[0], out_nodes, nodes
     # loops: per rolled run, iterations 1 .. n - 2 sit in consecutive exclusive levels (SQR, LIN each); (1, 2), (3, 4), ... repeat

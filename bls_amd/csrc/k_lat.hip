@@ -26,7 +26,7 @@
 namespace {
 constexpr int K_MUL = 0, K_LIN = 1, K_INV = 2, K_LOAD = 3, K_OUT12 = 4, K_CHECK1 = 5, K_OUTRAW12 = 6, K_OUTAFF = 7, K_ISZERO = 8, K_SEL = 9, K_SQR = 10;
 constexpr int K_REP = 11;               // not a level: "the next `len` (bits 8-15) levels run `count` (bits 16-23) times" -- the rolled squaring runs of gen_lat.py (Pairing.exp_by_x)
-constexpr int SLOT_WORDS = 16;
+constexpr int SLOT_WORDS = 20;              // 15 limbs + pad, at a stride of 80 bytes: see lat_lds_bytes (blsmi.hip)
 
 struct LatHeader {                      // gen_lat.py: encode()
     u32 magic, nlevels, nslot, nconst, out_kind, nout, nchk, r2;   // OUTAFF: nout result elements, then nchk values that must not be zero
