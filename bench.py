@@ -443,7 +443,12 @@ def compact_line(d, detail_file=None):
     if isinstance(vb, dict) and "error" not in vb:
         line["verifies_per_s"] = {"g2pubs": vb.get("g2pubs_verifies_per_s"), "g1pubs": vb.get("g1pubs_verifies_per_s"),
                                   "g1pubs_with_domain": (vb.get("g1pubs_with_domain") or {}).get("verifies_per_s"),
-                                  "g2pubs_prepared_keys": (vb.get("g2pubs_prepared_keys") or {}).get("verifies_per_s")}
+                                  "g2pubs_prepared_keys": (vb.get("g2pubs_prepared_keys") or {}).get("verifies_per_s"),
+                                  "g2pubs_in_memory_points": (vb.get("g2pubs_in_memory_points") or {}).get("verifies_per_s")}
+    e2e = (d.get("reference_shapes") or {}).get("end_to_end_host")
+    if isinstance(e2e, dict):                                                       # what a Go caller reaches, marshalling included (host buffers)
+        line["end_to_end_host"] = {"jac_entry_verifies_per_s": e2e.get("jac_entry_verifies_per_s"),
+                                   "affine_entry_one_marshalling_core": e2e.get("affine_entry_verifies_per_s_one_marshalling_core")}
     mid = d.get("mid_batches")
     if isinstance(mid, dict) and "error" not in mid:
         line["mid_batches"] = {"pairings_per_s": mid.get("pairings_per_s"), "verifies_per_s": mid.get("verifies_per_s")}
@@ -458,7 +463,7 @@ def compact_line(d, detail_file=None):
         line["leg_errors"] = errs
     if detail_file:
         line["detail"] = detail_file
-    for drop in ("mid_batches", "verifies_per_s", "self_check", "library", "launch"):
+    for drop in ("mid_batches", "end_to_end_host", "verifies_per_s", "self_check", "library", "launch"):
         if len(json.dumps(line, separators=(",", ":"))) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -580,6 +585,26 @@ def verify_bench(E, steps=5, warmup=2, n=65536):
                 pk["roofline"] = roofline_of(profiled(E.lib, local_step_prepared), n, BYTES["verify"], E.ctr, lambda k: 2 * n if k.endswith("_pair") else n)
             out["g2pubs_prepared_keys"] = pk
             del tab
+            if rank == 0 and world == 1:
+                # the same tuples as the Go side holds them (blsmi 0.6): Jacobian records with z != 1 resident in HBM, ToAffine on the device inside the call
+                from tools import reference_shapes as RS
+                zs = RS.jac_zs()
+                nkk = 256
+                pkj = np.frombuffer(b"".join(RS.to_jac2(pks[i].tobytes(), (zs[i], zs[i + 1])) for i in range(nkk)) * (n // nkk), dtype=np.uint8)
+                sgj = np.frombuffer(b"".join(RS.to_jac1(sigs[i].tobytes(), zs[i % 257]) for i in range(n)), dtype=np.uint8)
+                assert np.array_equal(pks[:nkk], pks[nkk:2 * nkk]), "bench keys repeat every 256 tuples"
+                d_pj = torch.from_numpy(pkj.copy()).to(dev); d_sj = torch.from_numpy(sgj.copy()).to(dev)
+
+                def step_jac():
+                    d_ok.zero_()
+                    engine.verify_batch_jac_dev("g2pubs", d[0].data_ptr(), d[1].data_ptr(), d_pj.data_ptr(), d_sj.data_ptr(), d_ok.data_ptr(), n)
+                dtj = timed_steps(E, step_jac, steps, warmup)
+                assert bool(d_ok.all().item()), "synthetic tuples must all verify from their in-memory form"
+                pj = profiled(E.lib, step_jac)
+                out["g2pubs_in_memory_points"] = {"verifies_per_s": round(n * steps / dtj, 1), "ms_per_step": round(dtj / steps * 1e3, 3),
+                                                  "to_affine_ms": {k: round(v[0], 4) for k, v in pj.items() if "jac_to_affine" in k},
+                                                  "note": "keys and signatures resident as bls.G2Projective / bls.G1Projective records (z != 1): ToAffine + the wire form on the device, then the same kernels"}
+                del d_pj, d_sj
         if group == "g1pubs":
             # VerifyWithDomain (g1pubs/bls.go:171-174): the same keys, 32-byte messages hashed by HashG2WithDomain (try-and-increment + ScaleByCofactor)
             nk = 256

@@ -884,6 +884,19 @@ BLSMI_API int blsmi_miller_loop_batch(const uint8_t* g1, const uint8_t* g2, uint
 BLSMI_API int blsmi_pairing_batch_jac(const uint64_t* g1_jac, const uint64_t* g2_jac, uint64_t* out, size_t n) {
     return pairing_host(reinterpret_cast<const uint8_t*>(g1_jac), reinterpret_cast<const uint8_t*>(g2_jac), out, n, 0, true);
 }
+// ... and with the in-memory points RESIDENT on one of the library's devices (a verifier that keeps its keys in HBM as it holds them in Go)
+BLSMI_API int blsmi_pairing_batch_jac_dev(const void* d_g1_jac, const void* d_g2_jac, void* d_out, size_t n, void* stream) {
+    if (n == 0) return BLSMI_OK;
+    if (!d_g1_jac || !d_g2_jac || !d_out) return BLSMI_E_ARG;
+    LOCK_AND_INIT_AT(d_out);
+    UseStream us(stream);
+    DBuf a, b;
+    HIPCHK(a.alloc(96 * n)); HIPCHK(b.alloc(192 * n));
+    int rc = jac_to_wire_dev(96, d_g1_jac, a.p, nullptr, n, g_stream);
+    if (!rc) rc = jac_to_wire_dev(192, d_g2_jac, b.p, nullptr, n, g_stream);
+    if (rc) return rc;
+    return pairing_dev(a.p, b.p, d_out, n, g_stream, 0);
+}
 // G?Projective.ToAffine().SerializeBytes() (g1.go:322-340 + 157-167, g2.go:365-386 + 172-186) for n points: wire records (all zero for
 // the point at infinity) and the infinity flags
 template <int PB>

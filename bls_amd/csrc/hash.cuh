@@ -238,7 +238,10 @@ __device__ __noinline__ void iso11(G1Aff& out, const G1Aff& p) {
 // clear == 0: WITHOUT the cofactor clearing of hash.go:306-309 -- the point S on E(Fq) whose multiple [1 - x] S is HashG1.  A large g2pubs
 // VerifyAggregate pairs S_i instead of H_i and raises the PRODUCT of its Miller values to 1 - x once (verify_host.inc: the reduced pairing is
 // bilinear in its E(Fq) argument modulo r E(Fq), so FE(ML(S, Q))^(1-x) = FE(ML([1-x] S, Q))): 63 doublings + 6 additions less per message.
-__device__ __noinline__ void swu_finish_g1(G1Aff& out, const G1Aff& p1, const G1Aff& p2, int clear = 1) {
+// special (may be null; meaningful with clear == 0): raised (bit 1) when a message's two mapped points cancel (p2 = -p1).  The reference then
+// clears the cofactor of a value its affine steps produce out of (0, 0) -- not a curve point, so the identity FE(ML(S, Q))^(1-x) = FE(ML([1-x] S, Q))
+// does not cover it: the caller redoes its aggregate with the cleared hash points (verify_host.inc; probability ~2^-381 per message).
+__device__ __noinline__ void swu_finish_g1(G1Aff& out, const G1Aff& p1, const G1Aff& p2, int clear = 1, int* special = nullptr) {
     const G1Jac sj = jac_add_affine(to_jac(p1), p2);
     G1Jac ij; iso_jac(ij, sj, C_XNUM11, C_XDEN11, C_YNUM11, C_YDEN11);
     if (clear) out = jac_to_affine(jac_add(jac_mul_u64_public(ij, BLSMI_X_ABS), ij));
@@ -248,20 +251,21 @@ __device__ __noinline__ void swu_finish_g1(G1Aff& out, const G1Aff& p1, const G1
         iso11(q, s);
         r = clear ? jac_to_affine(jac_add_affine(aff_mul_u64_public(q, BLSMI_X_ABS), q)) : q;
         out.x = fp_select(sj.inf, r.x, out.x); out.y = fp_select(sj.inf, r.y, out.y); out.inf = (sj.inf & r.inf) | (~sj.inf & out.inf);
+        if (!clear && special && sj.inf) atomicOr(special, 2);
     }
 }
-__device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2, int clear = 1) {
+__device__ __noinline__ void swu_map_g1(G1Aff& out, const FpS& t1, const FpS& t2, int clear = 1, int* special = nullptr) {
     G1Aff p1, p2;
     swu_g1_helper(p1, t1);
     swu_g1_helper(p2, t2);
-    swu_finish_g1(out, p1, p2, clear);
+    swu_finish_g1(out, p1, p2, clear, special);
 }
 // hash.go:326-331
-__device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len, int clear = 1) {
+__device__ __noinline__ void hash_g1(G1Aff& out, const u8* msg, size_t len, int clear = 1, int* special = nullptr) {
     u32 d[8];
     sha256_msg(d, 1, 0x01, msg, len);
     const FpS t1 = hp_from_digest(d, 0), t2 = hp_from_digest(d, 1);
-    swu_map_g1(out, t1, t2, clear);
+    swu_map_g1(out, t1, t2, clear, special);
 }
 // ---- G2 (g2.go:933-1031, hash.go:282-411) ---------------------------------------------------------------
 // Reference-shaped version (inversion + norm root + root: three exponentiations); serves g(x0) = 0.

@@ -7,11 +7,11 @@
 
 // ---- hash to curve --------------------------------------------------------------------------------
 // clear == 0: the hash point before its cofactor clearing (hash.cuh: swu_finish_g1; large g2pubs aggregates only)
-KERNEL2 k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n, int clear) {
+KERNEL2 k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n, int clear, int* special) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
     G1Aff h;
-    hash_g1(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]), clear);
+    hash_g1(h, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]), clear, t < n ? special : nullptr);
     if (t < n) store_g1(out + 96 * t, h);
 }
 KERNEL k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n) {
@@ -45,12 +45,12 @@ KERNEL2 k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
 // 11-isogeny and the cofactor clearing (hash.go:306-321; hash.cuh: swu_finish_g1).  The one-kernel k_hash_g1 runs a message per lane from
 // start to end -- 16 384 messages are 256 waves and take the 2.0 ms a full chip's 65 536 take; with the two square-root chains of a message
 // on two lanes (k_swu_g1_two_lanes: 512 waves) and this tail behind them the same hash is 0.55 + 0.8 ms.
-KERNEL2 k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear) {
+KERNEL2 k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear, int* special) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
     const G1Aff p1 = load_g1(pts + 192 * tt), p2 = load_g1(pts + 192 * tt + 96);
     G1Aff h;
-    swu_finish_g1(h, p1, p2, clear);
+    swu_finish_g1(h, p1, p2, clear, t < n ? special : nullptr);
     if (t < n) store_g1(out + 96 * t, h);
 }
 KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {

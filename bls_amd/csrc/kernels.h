@@ -53,11 +53,11 @@ __global__ void k_miller1x2_prep_pair(const u8* g1, const i32* tables, const u32
 __global__ void k_lat(const u8* prog, const u8* b0, size_t s0, const u8* b1, size_t s1, const u8* b2, size_t s2,
                                                 const u8* b3, size_t s3, const u8* flags, u8* ok, u64* out, size_t n);
 // k_hash.hip
-__global__ void k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n, int clear);
+__global__ void k_hash_g1(const u8* msgs, const u64* off, u8* out, size_t n, int clear, int* special);
 __global__ void k_hash_g2(const u8* msgs, const u64* off, u8* out, size_t n);
 __global__ void k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n);
 __global__ void k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
-__global__ void k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear);
+__global__ void k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear, int* special);
 __global__ void k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g2_waves(const u8* msgs, const u64* off, u8* pts, size_t n);

@@ -889,3 +889,14 @@ def g2pubs_verify_aggregate_prepared_jac(msgs, prepared, key_idx, sig):
     _check(_lib().blsmi_g2pubs_verify_aggregate_prepared_jac(_p8(buf), off.ctypes.data_as(_u64p), C.c_void_p(ptr), None if idx is None else idx.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                             ps, C.c_size_t(n), C.byref(ok)), "verify_aggregate_prepared_jac")
     return bool(ok.value)
+
+
+def pairing_batch_jac_dev(d_g1_jac, d_g2_jac, d_out, n, stream=0):
+    _check(_lib().blsmi_pairing_batch_jac_dev(C.c_void_p(d_g1_jac), C.c_void_p(d_g2_jac), C.c_void_p(d_out), C.c_size_t(n), C.c_void_p(stream)), "blsmi_pairing_batch_jac_dev")
+
+
+def verify_batch_jac_dev(group, d_msgs, d_off, d_pks_jac, d_sigs_jac, d_ok, n, stream=0):
+    """group: "g2pubs" / "g1pubs" / "g1pubs_with_domain" (d_off = the 8-byte domain on the device)"""
+    fn = {"g2pubs": _lib().blsmi_g2pubs_verify_batch_jac_dev, "g1pubs": _lib().blsmi_g1pubs_verify_batch_jac_dev,
+          "g1pubs_with_domain": _lib().blsmi_g1pubs_verify_with_domain_batch_jac_dev}[group]
+    _check(fn(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_pks_jac), C.c_void_p(d_sigs_jac), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_batch_jac_dev")

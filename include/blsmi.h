@@ -311,6 +311,12 @@ int blsmi_g1pubs_verify_aggregate_jac(const uint8_t *msgs, const uint64_t *off, 
 int blsmi_g1pubs_verify_aggregate_with_domain_jac(const uint8_t *msgs32, const uint8_t domain[8], const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
 int blsmi_g1pubs_verify_aggregate_common_jac(const uint8_t *msg, size_t msg_len, const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
 int blsmi_g1pubs_verify_aggregate_common_with_domain_jac(const uint8_t msg32[32], const uint8_t domain[8], const uint64_t *pks /* n*18 */, const uint64_t sig[36], size_t n, int *ok);
+/* device-pointer forms (every buffer on ONE of the library's devices; `stream` as in blsmi_pairing_batch_dev): the points resident in HBM as the
+ * Go side holds them.  d_ok: n verdict bytes on the device. */
+int blsmi_pairing_batch_jac_dev(const void *d_g1_jac, const void *d_g2_jac, void *d_out_fq12, size_t n, void *stream);
+int blsmi_g2pubs_verify_batch_jac_dev(const void *d_msgs, const void *d_off, const void *d_pks_jac, const void *d_sigs_jac, void *d_ok, size_t n, void *stream);
+int blsmi_g1pubs_verify_batch_jac_dev(const void *d_msgs, const void *d_off, const void *d_pks_jac, const void *d_sigs_jac, void *d_ok, size_t n, void *stream);
+int blsmi_g1pubs_verify_with_domain_batch_jac_dev(const void *d_msgs32, const void *d_domain8, const void *d_pks_jac, const void *d_sigs_jac, void *d_ok, size_t n, void *stream);
 /* prepared keys (see above) made from, and verified against, in-memory points */
 int blsmi_g2_prepared_create_jac(const uint64_t *g2_jac /* n*36 */, size_t n, void **handle);
 int blsmi_g2pubs_verify_batch_prepared_jac(const uint8_t *msgs, const uint64_t *msg_off, const void *d_prepared, const uint32_t *key_idx /* n, may be NULL */,
@@ -399,6 +405,10 @@ int blsmi_debug_g2_prepare(const uint8_t *g2_aff /* 192 */, int mode, uint64_t *
  * blsmi_debug_hash_redo: that kernel -- messages with good[i] == 0 are hashed by the one-message-per-lane routine into
  * out[i]; the records of the others are left as they were.  n <= 4096 for the tail. */
 int blsmi_debug_hash_tail(int kind, const uint8_t *pts, uint8_t *out, uint8_t *good, size_t n);
+/* the same tail of HashG1 as the THROUGHPUT kernel runs it (k_hash_g1_finish), with (clear != 0) or without the cofactor clearing of hash.go:306-309;
+ * *special gets bit 1 when clear == 0 and some message's two mapped points cancel -- the case a large VerifyAggregate's uncleared-hash path hands
+ * back to the cleared one. */
+int blsmi_debug_hash_g1_finish(const uint8_t *pts /* n*192 */, int clear, uint8_t *out /* n*96 */, int *special, size_t n);
 int blsmi_debug_hash_redo(int kind, const uint8_t *msgs, const uint64_t *off_or_domain, const uint8_t *good, uint8_t *out /* in/out */, size_t n);
 
 #ifdef __cplusplus

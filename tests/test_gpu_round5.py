@@ -79,3 +79,52 @@ def test_environment_is_read_at_initialisation_only(eng):
             os.environ.pop("BLSMI_AGG_COFACTOR_POW", None)
         else:
             os.environ["BLSMI_AGG_COFACTOR_POW"] = saved
+
+
+def test_uncleared_hash_path_flags_cancelling_map_points(eng):
+    """a large g2pubs VerifyAggregate pairs the hash points BEFORE their cofactor clearing (hash.cuh: swu_finish_g1 with clear = 0)
+    and raises the Miller product to 1 - x.  That identity needs S on the curve; when a message's two SWU points cancel (p2 = -p1, ~2^-381) the
+    reference's affine steps produce a value out of (0, 0) and the identity does not apply: the kernel raises a flag and the host redoes the call
+    with cleared points.  Here the throughput tail runs on chosen mapped points: the flag comes up exactly for the cancelling pair, the other
+    messages' uncleared points S satisfy [1 - x] S = the cleared point, and with clear = 1 nothing is flagged."""
+    import ctypes
+    lib = eng._lib()
+    xs = P.XORShift(5210)
+    # mapped points of real messages: the two SWU points per message, through the library's own first half
+    msgs = [b"special %d" % i for i in range(6)]
+    h = eng.hash_g1_batch(msgs)
+    # recover usable (p1, p2) pairs on the 11-isogenous curve: any two points of E11 serve -- take them from the debug SWU op on random t
+    from gpu_common import pack, rand_fq
+    ts = rand_fq(xs, 12)
+    rec = np.zeros((12, 18), dtype=np.uint64)
+    for i, t in enumerate(ts):
+        rec[i, :6] = pack([t])
+    swu, _ = eng.debug_op("SWU_G1", rec.reshape(-1))
+    pts = []
+    for i in range(12):
+        x = P.from_mont(P.from_limbs64(swu.reshape(12, 18)[i, :6])); y = P.from_mont(P.from_limbs64(swu.reshape(12, 18)[i, 6:12]))
+        pts.append((x, y))
+    def wire(p):
+        return p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+    pairs = [wire(pts[2 * i]) + wire(pts[2 * i + 1]) for i in range(6)]
+    neg = (pts[4][0], (P.Q - pts[4][1]) % P.Q)
+    pairs[2] = wire(pts[4]) + wire(neg)                                       # message 2: p2 = -p1
+    buf = np.frombuffer(b"".join(pairs), dtype=np.uint8)
+
+    def finish(clear):
+        out = np.zeros(96 * 6, dtype=np.uint8); sp = ctypes.c_int(0)
+        assert lib.blsmi_debug_hash_g1_finish(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), clear, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(sp), ctypes.c_size_t(6)) == 0
+        return out.reshape(6, 96), sp.value
+    cleared, sp1 = finish(1)
+    raw, sp0 = finish(0)
+    assert sp1 == 0 and sp0 == 2
+    ok_pairs = [i for i in range(6) if i != 2]
+    flagless = np.frombuffer(b"".join(pairs[i] for i in ok_pairs), dtype=np.uint8)
+    out = np.zeros(96 * 5, dtype=np.uint8); sp = ctypes.c_int(0)
+    assert lib.blsmi_debug_hash_g1_finish(flagless.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 0, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(sp), ctypes.c_size_t(5)) == 0
+    assert sp.value == 0
+    # [1 - x] S == the cleared point, for the messages the identity covers (1 - x = 1 + |x|; any-point ladder: S is outside the subgroup)
+    k = (0xd201000000010000 + 1).to_bytes(32, "big")
+    mul, inf = eng.g1_mul_batch(b"".join(raw[i].tobytes() for i in ok_pairs), k * 5, 5, any_point=True)
+    assert not inf.any() and [m.tobytes() for m in mul] == [cleared[i].tobytes() for i in ok_pairs]
+    assert h.shape[0] == 6

@@ -35,6 +35,36 @@ def RC_Q():
     return 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
 
 
+_Q = RC_Q()
+_R384 = (1 << 384) % _Q
+
+
+def _m(v):
+    return (v * _R384 % _Q).to_bytes(48, "little")
+
+
+def to_jac1(w, z):
+    """96-byte affine wire record -> the 144 bytes of a bls.G1Projective holding the same point with the given z (6 LE u64 Montgomery limbs per FQ)"""
+    x, y = int.from_bytes(w[:48], "big"), int.from_bytes(w[48:96], "big")
+    return _m(x * z * z % _Q) + _m(y * z * z * z % _Q) + _m(z)
+
+
+def _f2(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % _Q, (a[0] * b[1] + a[1] * b[0]) % _Q)
+
+
+def to_jac2(w, z):
+    """192-byte affine wire record -> the 288 bytes of a bls.G2Projective"""
+    c = [int.from_bytes(w[48 * i:48 * i + 48], "big") for i in range(4)]
+    z2 = _f2(z, z); z3 = _f2(z2, z)
+    X, Y = _f2((c[0], c[1]), z2), _f2((c[2], c[3]), z3)
+    return _m(X[0]) + _m(X[1]) + _m(Y[0]) + _m(Y[1]) + _m(z[0]) + _m(z[1])
+
+
+def jac_zs(k=257):
+    return [int.from_bytes(hashlib.sha256(b"z%d" % i).digest() * 2, "big") % (_Q - 1) + 1 for i in range(k)]
+
+
 def run(engine, batch=65536):
     from oracle import refcpu as RC                     # the CPU baseline leg (kind "port"): checker code, timed here as the reference's stand-in
     from bls_amd import g1pubs as G1P
@@ -90,24 +120,7 @@ def run(engine, batch=65536):
     # ctypes overhead per point).  In-memory (*_jac) entry points, blsmi 0.6: the shim copies the struct (144 / 288 bytes) and the library runs
     # ToAffine on the device inside the call.
     Q = RC_Q()
-    R384 = (1 << 384) % Q
-
-    def _m(v):
-        return (v * R384 % Q).to_bytes(48, "little")
-
-    def to_jac1(w, z):
-        x, y = int.from_bytes(w[:48], "big"), int.from_bytes(w[48:96], "big")
-        return _m(x * z * z % Q) + _m(y * z * z * z % Q) + _m(z)
-
-    def f2(a, b):
-        return ((a[0] * b[0] - a[1] * b[1]) % Q, (a[0] * b[1] + a[1] * b[0]) % Q)
-
-    def to_jac2(w, z):
-        c = [int.from_bytes(w[48 * i:48 * i + 48], "big") for i in range(4)]
-        z2 = f2(z, z); z3 = f2(z2, z)
-        X, Y = f2((c[0], c[1]), z2), f2((c[2], c[3]), z3)
-        return _m(X[0]) + _m(X[1]) + _m(Y[0]) + _m(Y[1]) + _m(z[0]) + _m(z[1])
-    zs = [int.from_bytes(hashlib.sha256(b"z%d" % i).digest() * 2, "big") % (Q - 1) + 1 for i in range(257)]
+    zs = jac_zs()
     sg_bytes = sigs.reshape(nb, 96)
     sgj = np.frombuffer(b"".join(to_jac1(sg_bytes[i].tobytes(), zs[i % 257]) for i in range(nb)), dtype=np.uint8)
     pk256 = pks.reshape(nb, 192)[:256]
