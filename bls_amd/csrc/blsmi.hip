@@ -1324,10 +1324,15 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     // grouping the 16 n items by bucket: a device radix sort (msm.inc: k_msm_items, k_util.hip); BLSMI_MSM_SORT=0 at start-up or
     // blsmi_set_option("msm_sort", 0) (the tests cross-check the two) takes the exact histogram + scan + atomic scatter instead
     const size_t nitems = (size_t)16 * n;
-    const bool sort_mode = nitems < ((size_t)1 << 31) && g_msm_sort.load(std::memory_order_relaxed);   // (the sort counts its items in an int: 2^27 points and beyond take the exact passes)
+    bool sort_mode = nitems < ((size_t)1 << 31) && g_msm_sort.load(std::memory_order_relaxed);   // (the sort counts its items in an int: 2^27 points and beyond take the exact passes)
     DBuf skey[2], sval[2];
-    if (sort_mode) { for (int i = 0; i < 2; i++) { HIPCHK(skey[i].alloc(sizeof(u32) * nitems, s)); HIPCHK(sval[i].alloc(sizeof(u32) * nitems, s)); } }
-    else HIPCHK(idx.alloc(sizeof(u32) * per_win_items * nbw, s));
+    if (sort_mode) {
+        // the sort's ping-pong buffers are 256 bytes per point (4 x 16 n words) on top of everything else: when they do not fit, the exact passes
+        // (64 bytes per point) serve instead of failing the call
+        for (int i = 0; i < 2 && sort_mode; i++)
+            if (skey[i].alloc(sizeof(u32) * nitems, s) != hipSuccess || sval[i].alloc(sizeof(u32) * nitems, s) != hipSuccess) { (void)hipGetLastError(); sort_mode = false; }
+    }
+    if (!sort_mode) { if (idx.alloc(sizeof(u32) * per_win_items * nbw, s) != hipSuccess) { (void)hipGetLastError(); return BLSMI_E_NOMEM; } }
     HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));
     HIPCHK(ch0.alloc(sizeof(i32) * jw * 2 * nct, s)); HIPCHK(ch1.alloc(sizeof(i32) * jw * 2 * nct, s));   // the fold's arrays: at most 2 nct records on either side
     HIPCHK(cls.alloc(sizeof(u32) * 768, s)); HIPCHK(perm.alloc(sizeof(u32) * nb, s));
@@ -1362,7 +1367,7 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
         u32* kk[2] = {skey[0].as<u32>(), skey[1].as<u32>()}; u32* vv[2] = {sval[0].as<u32>(), sval[1].as<u32>()};
         u32 *ks = nullptr, *vs = nullptr;
         int bits = 17; while (((size_t)1 << bits) <= nb) bits++;            // buckets 0 .. nb - 1 and the sentinel nb
-        if (blsmi_util::sort_pairs_async(kk, vv, nitems, bits, s, [](size_t b) { return tl_ctx->arena.alloc(b); }, &ks, &vs) != 0) { (void)hipGetLastError(); return BLSMI_E_HIP; }
+        if (const int e = blsmi_util::sort_pairs_async(kk, vv, nitems, bits, s, [](size_t b) { return tl_ctx->arena.alloc(b); }, &ks, &vs)) { (void)hipGetLastError(); return e == (int)hipErrorOutOfMemory ? BLSMI_E_NOMEM : BLSMI_E_HIP; }
         prof_mark("k_msm_runs");
         HIPCHK(hipMemsetAsync(offs.p, 0, sizeof(u32) * nb, s)); HIPCHK(hipMemsetAsync(cursor.p, 0, sizeof(u32) * nb, s));
         hipLaunchKernelGGL(k_msm_runs, dim3(nblocks(nitems)), dim3(WG), 0, s, (const u32*)ks, nitems, (u32)nb, offs.as<u32>(), cursor.as<u32>());
