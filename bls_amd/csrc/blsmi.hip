@@ -1058,8 +1058,9 @@ static int mul_dev_core(K kernel, const u8* d_pts, int gen_group, const u8* d_sc
     return BLSMI_OK;
 }
 template <int PB, class K>
-static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n, bool any_point = false) {
-    if (n && ((!pts && !gen_group) || !scalars || !out || !out_inf)) return BLSMI_E_ARG;
+static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n, bool any_point = false, uint64_t* out_jac = nullptr) {
+    // out_jac (replaces out / out_inf): the results as in-memory Jacobian records with z = 1, (0, 1, 0) for the point at infinity
+    if (n && ((!pts && !gen_group) || !scalars || (out_jac ? false : (!out || !out_inf)))) return BLSMI_E_ARG;
     if (n == 0) return BLSMI_OK;
     { std::lock_guard<std::mutex> lk(g_mu); int rc = ensure_init_default(); if (rc) return rc; }
     // independent multiplications: large host-buffer batches are split by contiguous block like a verify batch (devices,
@@ -1073,6 +1074,15 @@ static int mul_batch(K kernel, const uint8_t* pts, int gen_group, const uint8_t*
         HIPCHK(hipMemcpyAsync(ds.p, scalars + 32 * lo, 32 * m, hipMemcpyHostToDevice, g_stream));
         int rc = mul_dev_core<PB>(kernel, pts ? dp.as<u8>() : nullptr, gen_group, ds.as<u8>(), dout.as<u8>(), dinf.as<u8>(), m, g_stream);
         if (rc) return rc;
+        if (out_jac) {
+            const size_t jb = rec_bytes(PB, true);
+            DBuf dj; HIPCHK(dj.alloc(jb * m));
+            hipLaunchKernelGGL(k_affine_to_jac, dim3(nblocks(m)), dim3(WG), 0, g_stream, (const u8*)dout.as<u8>(), (const void*)dinf.p, 1, PB == 96 ? 1 : 2, dj.as<u64>(), m);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<uint8_t*>(out_jac) + jb * lo, dj.p, jb * m, hipMemcpyDeviceToHost, g_stream));
+            HIPCHK(hipStreamSynchronize(g_stream));
+            return BLSMI_OK;
+        }
         HIPCHK(hipMemcpyAsync(out + (size_t)PB * lo, dout.p, (size_t)PB * m, hipMemcpyDeviceToHost, g_stream));
         HIPCHK(hipMemcpyAsync(out_inf + lo, dinf.p, m, hipMemcpyDeviceToHost, g_stream));
         HIPCHK(hipStreamSynchronize(g_stream));
@@ -1083,6 +1093,9 @@ BLSMI_API int blsmi_g1_mul_batch(const uint8_t* pts, const uint8_t* scalars, uin
 BLSMI_API int blsmi_g2_mul_batch(const uint8_t* pts, const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { if (n && !pts) return BLSMI_E_ARG; return mul_batch<192>(k_g2_mul, pts, 0, scalars, out, out_inf, n); }
 BLSMI_API int blsmi_g1_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<96>(k_g1_mul, nullptr, 1, scalars, out, out_inf, n); }
 BLSMI_API int blsmi_g2_mul_generator_batch(const uint8_t* scalars, uint8_t* out, uint8_t* out_inf, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, 2, scalars, out, out_inf, n); }
+// PrivToPub for n keys with the results as the Go types hold them (bls.G?Projective with z = 1): PublicKey{p} is the record, no FQReprToFQ on the host
+BLSMI_API int blsmi_g1_mul_generator_batch_jac(const uint8_t* scalars, uint64_t* out_jac, size_t n) { return mul_batch<96>(k_g1_mul, nullptr, 1, scalars, nullptr, nullptr, n, false, out_jac); }
+BLSMI_API int blsmi_g2_mul_generator_batch_jac(const uint8_t* scalars, uint64_t* out_jac, size_t n) { return mul_batch<192>(k_g2_mul, nullptr, 2, scalars, nullptr, nullptr, n, false, out_jac); }
 // device-pointer forms: points (NULL = the group generator), scalars, results and infinity bytes resident on one device
 template <int PB, class K>
 static int mul_batch_dev(K kernel, int gen_group, const void* d_pts, const void* d_scalars, void* d_out, void* d_out_inf, size_t n, void* stream, bool any_point = false) {
@@ -1197,7 +1210,7 @@ static int sum_host(K0 k0, K1 k1, K2 kfinal, const uint8_t* pts, const uint8_t* 
     if (rc) return rc;
     i32 flag = 0;
     if (out_jac) {
-        hipLaunchKernelGGL(k_affine_to_jac, dim3(1), dim3(WG), 0, g_stream, (const u8*)dout.as<u8>(), (const i32*)dflag.as<i32>(), W == 3 ? 1 : 2, dj.as<u64>(), (size_t)1);
+        hipLaunchKernelGGL(k_affine_to_jac, dim3(1), dim3(WG), 0, g_stream, (const u8*)dout.as<u8>(), (const void*)dflag.p, 0, W == 3 ? 1 : 2, dj.as<u64>(), (size_t)1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(out_jac, dj.p, jb, hipMemcpyDeviceToHost, g_stream));
     }

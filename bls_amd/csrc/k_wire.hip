@@ -187,11 +187,13 @@ KERNEL2 k_g1_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n) { jac_
 KERNEL k_g2_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n) { jac_to_affine_body<Fp2S, 192>(in, out, out_inf, n); }
 // the other direction, for results that go back into a Go value (AggregatePublicKeys / AggregateSignatures: one point): wire record
 // + infinity flag -> the in-memory record with z = 1
-KERNEL k_affine_to_jac(const u8* in, const i32* in_inf, int group, u64* out, size_t n) {
+// (in_inf: n flags, int32 -- the sums' -- or, inf_u8 != 0, bytes -- the multiplication kernels')
+KERNEL k_affine_to_jac(const u8* in, const void* in_inf, int inf_u8, int group, u64* out, size_t n) {
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     if (t >= n) return;
-    if (group == 1) { G1Aff a = load_g1(in + 96 * t); if (in_inf && in_inf[t]) a.inf = -1; store_jac_m384(out + 18 * t, a); }
-    else { G2Aff a = load_g2(in + 192 * t); if (in_inf && in_inf[t]) a.inf = -1; store_jac_m384(out + 36 * t, a); }
+    const bool inf = in_inf && (inf_u8 ? static_cast<const u8*>(in_inf)[t] != 0 : static_cast<const i32*>(in_inf)[t] != 0);
+    if (group == 1) { G1Aff a = load_g1(in + 96 * t); if (inf) a.inf = -1; store_jac_m384(out + 18 * t, a); }
+    else { G2Aff a = load_g2(in + 192 * t); if (inf) a.inf = -1; store_jac_m384(out + 36 * t, a); }
 }
 
 KERNEL k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n) {

@@ -82,7 +82,7 @@ __global__ void k_g1_compress(const u8* pts, const u8* in_inf, u8* out, size_t n
 __global__ void k_g2_compress(const u8* pts, const u8* in_inf, u8* out, size_t n);
 __global__ void k_g1_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n);
 __global__ void k_g2_jac_to_affine(const u64* in, u8* out, u8* out_inf, size_t n);
-__global__ void k_affine_to_jac(const u8* in, const i32* in_inf, int group, u64* out, size_t n);
+__global__ void k_affine_to_jac(const u8* in, const void* in_inf, int inf_u8, int group, u64* out, size_t n);
 __global__ void k_debug_fq(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
 __global__ void k_debug_fq2(int op, const u64* a, const u64* b, u64* out, u8* flag, size_t n);
 __global__ void k_debug_swu_g1(const u64* a, u64* out, size_t n);

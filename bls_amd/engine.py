@@ -900,3 +900,43 @@ def verify_batch_jac_dev(group, d_msgs, d_off, d_pks_jac, d_sigs_jac, d_ok, n, s
     fn = {"g2pubs": _lib().blsmi_g2pubs_verify_batch_jac_dev, "g1pubs": _lib().blsmi_g1pubs_verify_batch_jac_dev,
           "g1pubs_with_domain": _lib().blsmi_g1pubs_verify_with_domain_batch_jac_dev}[group]
     _check(fn(C.c_void_p(d_msgs), C.c_void_p(d_off), C.c_void_p(d_pks_jac), C.c_void_p(d_sigs_jac), C.c_void_p(d_ok), C.c_size_t(n), C.c_void_p(stream)), "verify_batch_jac_dev")
+
+
+def _mul_gen_jac(fn, jb, scalars, n):
+    sc = _u8(scalars, 32 * n)
+    out = np.zeros(max(1, jb // 8 * n), dtype=np.uint64)
+    _check(fn(_p8(sc), out.ctypes.data_as(_u64p), C.c_size_t(n)), "mul_generator_batch_jac")
+    return out[:jb // 8 * n].view(np.uint8).reshape(n, jb)
+
+
+def g1_mul_generator_batch_jac(scalars, n):
+    """PrivToPub for g1pubs: k_i * G1 as (n, 144) bytes of bls.G1Projective records (z = 1; (0, 1, 0) for k = 0 mod r)"""
+    return _mul_gen_jac(_lib().blsmi_g1_mul_generator_batch_jac, 144, scalars, n)
+
+
+def g2_mul_generator_batch_jac(scalars, n):
+    return _mul_gen_jac(_lib().blsmi_g2_mul_generator_batch_jac, 288, scalars, n)
+
+
+def _sign_jac(fn, jb, n, head, sks):
+    sk = _u8(sks, 32 * n)
+    out = np.zeros(max(1, jb // 8 * n), dtype=np.uint64)
+    _check(fn(*head, _p8(sk), out.ctypes.data_as(_u64p), C.c_size_t(n)), "sign_batch_jac")
+    return out[:jb // 8 * n].view(np.uint8).reshape(n, jb)
+
+
+def g2pubs_sign_batch_jac(msgs, sks):
+    buf, off = _msgs(msgs)
+    return _sign_jac(_lib().blsmi_g2pubs_sign_batch_jac, 144, len(msgs), (_p8(buf), off.ctypes.data_as(_u64p)), sks)
+
+
+def g1pubs_sign_batch_jac(msgs, sks):
+    buf, off = _msgs(msgs)
+    return _sign_jac(_lib().blsmi_g1pubs_sign_batch_jac, 288, len(msgs), (_p8(buf), off.ctypes.data_as(_u64p)), sks)
+
+
+def g1pubs_sign_with_domain_batch_jac(msgs32, domain8, sks):
+    n = len(msgs32)
+    buf = _u8(b"".join(bytes(m) for m in msgs32), 32 * n)
+    d = _u8(domain8, 8)
+    return _sign_jac(_lib().blsmi_g1pubs_sign_with_domain_batch_jac, 288, n, (_p8(buf), _p8(d)), sks)

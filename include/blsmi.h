@@ -297,6 +297,14 @@ int blsmi_pairing_batch_jac(const uint64_t *g1_jac /* n*18 */, const uint64_t *g
  * as they are (Jacobian + Jacobian, g1.go:400-470): no inversion but the one at the end. */
 int blsmi_g1_sum_jac(const uint64_t *g1_jac /* n*18 */, size_t n, uint64_t out_jac[18], int *out_inf);
 int blsmi_g2_sum_jac(const uint64_t *g2_jac /* n*36 */, size_t n, uint64_t out_jac[36], int *out_inf);
+/* Results in the in-memory form: PrivToPub (k_i * generator) and Sign (sk_i * H(m_i)) for n scalars, each result a bls.G?Projective record with
+ * z = 1 -- (0, 1, 0) when the scalar is 0 mod r -- so that the shim builds its PublicKey / Signature by one copy (upstream: FQReprToFQ per coordinate).
+ * Same caveats as the affine forms (not side-channel hardened; secret scalars cross the bus). */
+int blsmi_g1_mul_generator_batch_jac(const uint8_t *scalars /* n*32 */, uint64_t *out_jac /* n*18 */, size_t n);
+int blsmi_g2_mul_generator_batch_jac(const uint8_t *scalars /* n*32 */, uint64_t *out_jac /* n*36 */, size_t n);
+int blsmi_g2pubs_sign_batch_jac(const uint8_t *msgs, const uint64_t *off /* n+1 */, const uint8_t *sks /* n*32 */, uint64_t *out_sigs_jac /* n*18 */, size_t n);
+int blsmi_g1pubs_sign_batch_jac(const uint8_t *msgs, const uint64_t *off /* n+1 */, const uint8_t *sks /* n*32 */, uint64_t *out_sigs_jac /* n*36 */, size_t n);
+int blsmi_g1pubs_sign_with_domain_batch_jac(const uint8_t *msgs32 /* n*32 */, const uint8_t domain[8], const uint8_t *sks /* n*32 */, uint64_t *out_sigs_jac /* n*36 */, size_t n);
 /* g2pubs (PublicKey = G2Projective 36 x u64, Signature = G1Projective 18 x u64) */
 int blsmi_g2pubs_verify_batch_jac(const uint8_t *msgs, const uint64_t *off, const uint64_t *pks /* n*36 */, const uint64_t *sigs /* n*18 */,
                                   uint8_t *ok /* n, may be NULL */, uint8_t *ok_bitmap /* ceil(n/8), may be NULL */, size_t n);

@@ -241,17 +241,6 @@ func VerifySerializedBatch(msgs [][]byte, pubs [][48]byte, sigs [][96]byte) []bo
 	return out
 }
 
-// g2FromBytes rebuilds a G2 point from the 192 affine bytes the library returns (x.c0, x.c1, y.c0, y.c1, 48 bytes big-endian each:
-// G2Affine.SerializeBytes, g2.go:172-186).
-func g2FromBytes(b []byte) *bls.G2Affine {
-	var c [4][48]byte
-	for j := range c {
-		copy(c[j][:], b[48*j:48*j+48])
-	}
-	fq := func(x [48]byte) bls.FQ { return bls.FQReprToFQ(bls.FQReprFromBytes(x)) }
-	return bls.NewG2Affine(bls.NewFQ2(fq(c[0]), fq(c[1])), bls.NewFQ2(fq(c[2]), fq(c[3])))
-}
-
 func secretBytes(keys []*SecretKey) []byte {
 	sk := make([]byte, 0, 32*len(keys))
 	for i := range keys {
@@ -261,14 +250,13 @@ func secretBytes(keys []*SecretKey) []byte {
 	return sk
 }
 
-func sigsFromBytes(sg, inf []byte) []*Signature {
-	out := make([]*Signature, len(inf))
+// sigsFromWords: the library hands signatures back as G2Projective records (z = 1; the reference's zero point for sk = 0 mod r): one copy each.
+func sigsFromWords(sg []C.uint64_t, n int) []*Signature {
+	out := make([]*Signature, n)
 	for i := range out {
-		if inf[i] != 0 {
-			out[i] = NewSignatureFromG2(bls.G2AffineZero.Copy())
-		} else {
-			out[i] = NewSignatureFromG2(g2FromBytes(sg[192*i : 192*i+192]))
-		}
+		p := new(bls.G2Projective)
+		copy((*[36]C.uint64_t)(unsafe.Pointer(p))[:], sg[36*i:36*i+36])
+		out[i] = &Signature{s: p}
 	}
 	return out
 }
@@ -288,12 +276,11 @@ func SignBatch(msgs [][]byte, keys []*SecretKey) []*Signature {
 		return out
 	}
 	m, off := packMsgs(msgs)
-	sg := make([]byte, 192*n)
-	inf := make([]byte, n)
-	if rc := C.blsmi_g1pubs_sign_batch(u8(m), &off[0], u8(secretBytes(keys)), u8(sg), u8(inf), C.size_t(n)); rc != 0 {
+	sg := make([]C.uint64_t, 36*n)
+	if rc := C.blsmi_g1pubs_sign_batch_jac(u8(m), &off[0], u8(secretBytes(keys)), &sg[0], C.size_t(n)); rc != 0 {
 		panic("blsmi: g1pubs sign_batch failed")
 	}
-	return sigsFromBytes(sg, inf)
+	return sigsFromWords(sg, n)
 }
 
 // SignWithDomainBatch: out[i] = SignWithDomain(msgs[i], keys[i], domain) (g1pubs/bls.go:138-141).
@@ -302,12 +289,11 @@ func SignWithDomainBatch(msgs [][32]byte, keys []*SecretKey, domain [8]byte) []*
 	if n == 0 {
 		return nil
 	}
-	sg := make([]byte, 192*n)
-	inf := make([]byte, n)
-	rc := C.blsmi_g1pubs_sign_with_domain_batch((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u8(secretBytes(keys)), u8(sg), u8(inf), C.size_t(n))
+	sg := make([]C.uint64_t, 36*n)
+	rc := C.blsmi_g1pubs_sign_with_domain_batch_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u8(secretBytes(keys)), &sg[0], C.size_t(n))
 	if rc != 0 {
 		panic("blsmi: g1pubs sign_with_domain_batch failed")
 	}
-	return sigsFromBytes(sg, inf)
+	return sigsFromWords(sg, n)
 }

@@ -294,20 +294,15 @@ func SignBatch(msgs [][]byte, keys []*SecretKey) []*Signature {
 		kb := keys[i].Serialize() // g2pubs/bls.go:115-117: 32 bytes big-endian
 		sk = append(sk, kb[:]...)
 	}
-	sg := make([]byte, 96*n)
-	inf := make([]byte, n)
-	if rc := C.blsmi_g2pubs_sign_batch(u8(m), &off[0], u8(sk), u8(sg), u8(inf), C.size_t(n)); rc != 0 {
+	// the signatures come back as G1Projective records (z = 1; the reference's zero point for sk = 0 mod r): one copy each
+	sg := make([]C.uint64_t, 18*n)
+	if rc := C.blsmi_g2pubs_sign_batch_jac(u8(m), &off[0], u8(sk), &sg[0], C.size_t(n)); rc != 0 {
 		panic("blsmi: g2pubs sign_batch failed")
 	}
 	for i := range out {
-		if inf[i] != 0 {
-			out[i] = NewSignatureFromG1(bls.G1AffineZero.Copy())
-			continue
-		}
-		var xb, yb [48]byte
-		copy(xb[:], sg[96*i:96*i+48])
-		copy(yb[:], sg[96*i+48:96*i+96])
-		out[i] = NewSignatureFromG1(bls.NewG1Affine(bls.FQReprToFQ(bls.FQReprFromBytes(xb)), bls.FQReprToFQ(bls.FQReprFromBytes(yb))))
+		p := new(bls.G1Projective)
+		copy((*[18]C.uint64_t)(unsafe.Pointer(p))[:], sg[18*i:18*i+18])
+		out[i] = &Signature{s: p}
 	}
 	return out
 }

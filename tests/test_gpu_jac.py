@@ -462,3 +462,33 @@ def test_resident_in_memory_points(eng):
     o = torch.zeros((4, 72), dtype=torch.int64, device=dev)
     eng.pairing_batch_jac_dev(a.data_ptr(), b.data_ptr(), o.data_ptr(), 4)
     assert np.array_equal(o.cpu().numpy().view(np.uint64), RC.pairing_batch(b"".join(w1), b"".join(w2), 4))
+
+
+def test_sign_and_priv_to_pub_hand_back_in_memory_points(eng):
+    """Sign / PrivToPub (g2pubs/bls.go:132-140, g1pubs/bls.go:132-146) with results as the Go types hold them: records with z = 1 whose
+    ToAffine is the oracle's point; the zero scalar gives the reference's zero point (0, 1, 0); the records verify through the *_jac entry."""
+    xs = P.XORShift(5190)
+    n = 70
+    sks = [sk_bytes(xs) for _ in range(n)]
+    sks[3] = bytes(32)                                                         # 0 mod r: infinity
+    sks[4] = P.R_ORDER.to_bytes(32, "big")
+    msgs = [b"sign %d" % i for i in range(n)]
+    one = mont(1).tobytes()
+    for pkg, R, pk_fn, sg_fn, aff_pk, aff_sg, zero_pk, zero_sg in (
+            ("g2pubs", RC.g2pubs, eng.g2_mul_generator_batch_jac, eng.g2pubs_sign_batch_jac, _oracle_affine2, _oracle_affine1, g2_to_jac(None), g1_to_jac(None)),
+            ("g1pubs", RC.g1pubs, eng.g1_mul_generator_batch_jac, eng.g1pubs_sign_batch_jac, _oracle_affine1, _oracle_affine2, g1_to_jac(None), g2_to_jac(None))):
+        pk = pk_fn(b"".join(sks), n); sg = sg_fn(msgs, b"".join(sks))
+        for i in range(n):
+            if i in (3, 4):
+                assert pk[i].tobytes() == zero_pk and sg[i].tobytes() == zero_sg
+                continue
+            assert aff_pk(pk[i].tobytes()) == R.priv_to_pub(sks[i]) and aff_sg(sg[i].tobytes()) == R.sign(msgs[i], sks[i]), (pkg, i)
+            assert one in (pk[i].tobytes()[-48:], pk[i].tobytes()[-96:-48])      # z = FQOne / FQ2One
+        ver = eng.g2pubs_verify_batch_jac if pkg == "g2pubs" else eng.g1pubs_verify_batch_jac
+        ok, _ = ver(msgs, pk.reshape(-1), sg.reshape(-1))
+        assert list(ok) == [i not in (3, 4) for i in range(n)]
+    dom = b"\x01\x00\x00\x00\x00\x00\x00\x02"
+    m32 = [RC.sha256(m) for m in msgs[:5]]
+    sd = eng.g1pubs_sign_with_domain_batch_jac(m32, dom, b"".join(sks[:3] + sks[5:7]))
+    for i, k in enumerate(sks[:3] + sks[5:7]):
+        assert _oracle_affine2(sd[i].tobytes()) == RC.g1pubs.sign_with_domain(m32[i], k, dom)
