@@ -143,6 +143,8 @@ struct Ctx {
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     bool busy = false;
     Device* dev = nullptr;
+    // what this call put on its device and what the device carried from OTHER calls when it first asked (call_load: the layout choice)
+    bool load_set = false; size_t load_n = 0, load_others = 0;
     // per-kernel timing (blsmi_set_profiling): events recorded between the major kernels of the call that holds this context
     std::vector<hipEvent_t> pev; std::vector<const char*> pname; size_t pused = 0;
     bool pclosed = false;               // the call's closing mark is already recorded (on a caller-supplied stream, by UseStream)
@@ -166,6 +168,7 @@ struct Device {
     Ctx ctx[MAX_CTX];
     Gens gens;
     int leased = 0;                     // contexts in use (device choice for unpinned calls)
+    std::atomic<size_t> load{0};        // tuples of the pairing / verify calls in flight on this device (call_load)
     unsigned long long leases = 0;      // context leases served since initialisation (blsmi_debug_device_leases)
     // collectives: one RCCL communicator rank and one stream per device, plus a grow-only exchange buffer
     ncclComm_t comm = nullptr;
@@ -281,7 +284,28 @@ std::atomic<size_t> g_lat_max{8192};    // BLSMI_LAT_MAX, blsmi_set_latency_thre
 // one per lane QUAD up to g_quad_max (16 384 tuples = one wave on every SIMD), one per lane PAIR beyond (65 536 fill the chip twice over).
 std::atomic<size_t> g_quad_max{16384};  // BLSMI_QUAD_MAX, blsmi_set_quad_threshold (0: no quad kernels)
 std::atomic<size_t> g_quad_min{5632};   // BLSMI_QUAD_MIN: the quad kernels take over from the latency path here already (pairings: 5.9 ms flat against 1 ms per 1 024 tuples; verifies 8.7 against 1.5)
-inline bool use_quad(size_t n) { return g_pair_layout && n > std::min(g_lat_max.load(), g_quad_min.load()) && n <= g_quad_max; }
+// The thresholds above are a LONE caller's: one tuple per wave finishes 4 096 pairings in 4.3 ms where the quad kernels take their flat 6 ms.
+// Callers that arrive together are a different matter (tools/midsize_concurrency.py): the latency path saturates the chip at 1.04 M pairings/s
+// whatever the number of calls in flight (its waves are bounded by LDS, 9 per CU), the quad kernels at 2.8 M/s (two 8 192-tuple calls take
+// the 6 ms of one).  So the choice goes by what the DEVICE carries: a call of at least g_crowd_floor tuples takes the quad kernels when its
+// tuples plus those of the other calls in flight pass the lone crossover.  A call registers its tuples at its first layout question and
+// keeps the answer's input for its whole life (one call never sees two different loads); ~CtxLease takes them off again.
+std::atomic<bool> g_crowd_quad{true};        // BLSMI_CROWD_QUAD / blsmi_set_option("crowd_quad")
+std::atomic<size_t> g_crowd_floor{2560};     // BLSMI_CROWD_FLOOR / blsmi_set_option("crowd_floor")
+std::atomic<size_t> g_assume_load{0};        // blsmi_set_option("assume_load"): test hook, tuples pretended to be in flight from other calls
+inline size_t call_load(size_t n) {
+    Ctx* c = tl_ctx;
+    if (!c || !c->dev) return 0;
+    if (!c->load_set) { c->load_others = c->dev->load.fetch_add(n, std::memory_order_relaxed); c->load_n = n; c->load_set = true; }
+    return c->load_others + g_assume_load.load(std::memory_order_relaxed);
+}
+inline bool use_quad(size_t n) {
+    if (!g_pair_layout || n > g_quad_max) return false;
+    const size_t lone = std::min(g_lat_max.load(), g_quad_min.load());
+    if (n > lone) return true;
+    if (!g_crowd_quad.load(std::memory_order_relaxed) || n < g_crowd_floor.load(std::memory_order_relaxed)) return false;
+    return n + call_load(n) > lone;
+}
 inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
 inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }
 inline bool mul_subgroup() { return !tl_mul_any && g_mul_subgroup.load(std::memory_order_relaxed); }
@@ -328,6 +352,8 @@ void load_env() {                       // caller holds g_mu; runs once per init
     { const char* v = getenv("BLSMI_MSM_SORT"); g_msm_sort = !(v && v[0] == '0'); }
     g_dup_force_sort = getenv("BLSMI_DUP_FORCE_SORT") != nullptr;
     { const char* v = getenv("BLSMI_LAT_ROLLED"); g_lat_rolled = !(v && v[0] == '0'); }
+    { const char* v = getenv("BLSMI_CROWD_QUAD"); g_crowd_quad = !(v && v[0] == '0'); }
+    if (const char* v = getenv("BLSMI_CROWD_FLOOR")) g_crowd_floor = (size_t)strtoull(v, nullptr, 10);
 }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -439,6 +465,7 @@ struct CtxLease {
         if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = BLSMI_E_HIP; return; }
         c->busy = true; c->dev->leased++; c->dev->leases++;
         c->pused = 0; c->pclosed = false;
+        c->load_set = false; c->load_n = 0; c->load_others = 0;
         c->arena.reset();                                                   // the temporaries of the context's previous call (its streams are idle: see the destructor)
         outer = tl_ctx;
         tl_ctx = mine = c;
@@ -455,6 +482,7 @@ struct CtxLease {
             if (mine->ws.cap > g_arena_keep / 2) mine->ws.release();
             (void)mine->arena.trim(g_arena_keep > mine->ws.cap ? g_arena_keep - mine->ws.cap : 0);
         }
+        if (mine->load_set) { mine->dev->load.fetch_sub(mine->load_n, std::memory_order_relaxed); mine->load_set = false; }
         { std::lock_guard<std::mutex> lk(g_mu); mine->busy = false; mine->dev->leased--; }
         tl_ctx = outer;
         if (outer) (void)hipSetDevice(outer->dev->id);
@@ -823,6 +851,9 @@ BLSMI_API int blsmi_set_option(const char* name, long long value) {
     else if (n == "msm_sort") g_msm_sort.store(value != 0);
     else if (n == "dup_force_sort") g_dup_force_sort.store(value != 0);
     else if (n == "lat_rolled") g_lat_rolled.store(value != 0);
+    else if (n == "crowd_quad") g_crowd_quad.store(value != 0);
+    else if (n == "crowd_floor") g_crowd_floor.store((size_t)std::max(0LL, value));
+    else if (n == "assume_load") g_assume_load.store((size_t)std::max(0LL, value));
     else return BLSMI_E_ARG;
     return BLSMI_OK;
 }

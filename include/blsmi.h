@@ -121,12 +121,16 @@ int blsmi_prefer_cpu(int shape, size_t n);
  * BLSMI_LAT_MAX / BLSMI_QUAD_MAX / BLSMI_QUAD_MIN (layout hand-overs; also blsmi_set_latency_threshold / _quad_threshold), BLSMI_MUL_GENERIC,
  * BLSMI_COMBINE_MAX / _WAIT_US / _INFLIGHT / _DEBUG (merging of concurrent one-tuple Verify calls).  A/B switches between code paths with
  * identical results: BLSMI_LAYOUT, BLSMI_GEN_LINES, BLSMI_HASH_G1_SPLIT, BLSMI_HASH_G2_PAIR, BLSMI_HASH_G2_PAIR_REDO_EVERY, BLSMI_COFAC2_PAIR,
- * BLSMI_SWU_WAVE_MAX, BLSMI_SIG_SIDE_MAX, BLSMI_SIDE_MAX, BLSMI_FIXED_WAVE_MAX, BLSMI_MSM_BUCKET_MIN, and the four that can ALSO be
- * switched while running (atomically; a call in flight sees the old or the new value), through blsmi_set_option(name, 0 / 1):
+ * BLSMI_SWU_WAVE_MAX, BLSMI_SIG_SIDE_MAX, BLSMI_SIDE_MAX, BLSMI_FIXED_WAVE_MAX, BLSMI_MSM_BUCKET_MIN, and the ones that can ALSO be
+ * switched while running (atomically; a call in flight sees the old or the new value), through blsmi_set_option(name, value):
  *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0),
  *   "lat_rolled" (BLSMI_LAT_ROLLED, default 1; 0: small Pairing calls run the straight-line copy of their level program instead of the one
  *   whose squaring runs are loops).
- * Test hook: BLSMI_DEVICE_ALIAS (above).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
+ * Layout by what the DEVICE carries (blsmi 0.6): the hand-overs above are a lone caller's.  Calls that arrive together share the chip, and
+ * under load the quad kernels serve 2.7x the tuples per second of the one-tuple-per-wave path, so a pairing / verify call of at least
+ * "crowd_floor" tuples (BLSMI_CROWD_FLOOR, default 2560: below, four concurrent quad launches measured no better than the latency path) takes them when its tuples plus those of the other calls in flight on its device pass
+ * BLSMI_QUAD_MIN; "crowd_quad" (BLSMI_CROWD_QUAD, default 1) 0: by the call's own size only.  Same results either way (bit-exact layouts).
+ * Test hooks: BLSMI_DEVICE_ALIAS (above); "assume_load" (tuples pretended to be in flight from other calls).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
 int blsmi_set_option(const char *name, long long value);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
 /* General form: with profiling on, every entry point records HIP events on its launch stream between its major kernels.  This

@@ -39,7 +39,7 @@ def test_rolled_pairing_program_on_the_device(eng):
 def test_set_option_rejects_unknown_names(eng):
     lib = eng._lib()
     assert lib.blsmi_set_option(b"no_such_option", 1) == -3 and lib.blsmi_set_option(None, 1) == -3
-    for name in ("agg_cofactor_pow", "msm_sort", "dup_force_sort", "lat_rolled"):
+    for name in ("agg_cofactor_pow", "msm_sort", "dup_force_sort", "lat_rolled", "crowd_quad"):
         assert lib.blsmi_set_option(name.encode(), 1) == 0
     eng.set_option("dup_force_sort", 0)
 
@@ -128,3 +128,70 @@ def test_uncleared_hash_path_flags_cancelling_map_points(eng):
     mul, inf = eng.g1_mul_batch(b"".join(raw[i].tobytes() for i in ok_pairs), k * 5, 5, any_point=True)
     assert not inf.any() and [m.tobytes() for m in mul] == [cleared[i].tobytes() for i in ok_pairs]
     assert h.shape[0] == 6
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_layout_follows_the_load_of_the_device(eng, group):
+    """blsmi 0.6: the layout of a mid-size call goes by what its DEVICE carries (blsmi.hip: call_load / use_quad; tools/midsize_concurrency.py) --
+    a call of >= crowd_floor tuples takes the lane-quad kernels when other calls' tuples are in flight, the one-tuple-per-wave path when it is alone.
+    Same verdicts (and the same Fq12 bits for Pairing) on either; "assume_load" stands in for the other callers; calls below the floor never move."""
+    import ctypes
+    from test_gpu_verify import _tuples
+    msgs, pks, sigs, expect = _tuples(group, 96, 91)
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    for i in (0, 5, 9):
+        assert o.verify(msgs[i], pks[i], sigs[i]) == expect[i]
+    n = 2600
+    sel = [i % 96 for i in range(n)]
+    M = eng.PackedMsgs([msgs[i] for i in sel]); A = b"".join(pks[i] for i in sel); B = b"".join(sigs[i] for i in sel)
+    want = [expect[i] for i in sel]
+    fn = eng.g2pubs_verify_batch if group == "g2pubs" else eng.g1pubs_verify_batch
+    lib = eng._lib()
+
+    def call(f):
+        lib.blsmi_set_profiling(1)
+        r = f()
+        buf = ctypes.create_string_buffer(8192); lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
+        return r, buf.value.decode()
+    try:
+        (ok, _), prof = call(lambda: fn(M, A, B))
+        assert list(ok) == want and "k_lat:verify" in prof and "quad" not in prof, prof
+        eng.set_option("assume_load", 4000)
+        (ok, _), prof = call(lambda: fn(M, A, B))
+        assert list(ok) == want and "quad" in prof and "k_lat:verify" not in prof and "k_lat:hashfin" not in prof, prof
+        eng.set_option("crowd_quad", 0)
+        (ok, _), prof = call(lambda: fn(M, A, B))
+        assert list(ok) == want and "quad" not in prof, prof
+        eng.set_option("crowd_quad", 1)
+        m = 1000                                                                # below the floor: a small call keeps its latency whatever else runs
+        (ok, _), prof = call(lambda: fn(eng.PackedMsgs([msgs[i] for i in sel[:m]]), A[:len(pks[0]) * m], B[:len(sigs[0]) * m]))
+        assert list(ok) == want[:m] and "quad" not in prof, prof
+        if group == "g2pubs":                                                   # Pairing: the same Fq12 bits from both layouts
+            g1 = np.frombuffer(B, dtype=np.uint8); g2 = np.frombuffer(A, dtype=np.uint8)
+            crowded, prof = call(lambda: eng.pairing_batch(g1, g2, n))
+            assert "k_miller1h_quad" in prof, prof
+            eng.set_option("assume_load", 0)
+            alone, prof = call(lambda: eng.pairing_batch(g1, g2, n))
+            assert "k_lat:pairing1" in prof and np.array_equal(crowded, alone), prof
+            assert alone[7].tobytes() == RC.pairing_batch(g1[96 * 7:96 * 8].tobytes(), g2[192 * 7:192 * 8].tobytes(), 1).tobytes()
+    finally:
+        eng.set_option("assume_load", 0); eng.set_option("crowd_quad", 1)
+    # concurrent callers: the load is taken off the device when a call ends (nothing left behind for the next lone caller)
+    import threading
+    errs = []
+
+    def worker():
+        try:
+            for _ in range(3):
+                ok, _ = fn(M, A, B)
+                assert list(ok) == want
+        except Exception as e:                                                  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    (ok, _), prof = call(lambda: fn(M, A, B))
+    assert list(ok) == want and "quad" not in prof, prof
