@@ -330,6 +330,7 @@ struct EnvCfg {
 std::atomic<bool> g_agg_cofactor_pow{true};    // BLSMI_AGG_COFACTOR_POW / blsmi_set_option("agg_cofactor_pow")
 std::atomic<bool> g_msm_sort{true};            // BLSMI_MSM_SORT / blsmi_set_option("msm_sort")
 std::atomic<bool> g_lat_rolled{true};          // BLSMI_LAT_ROLLED / blsmi_set_option("lat_rolled"): 0 = small Pairing calls take the STRAIGHT-LINE copy of their level program (pairing1s) instead of the one with rolled squaring runs (A/B)
+std::atomic<size_t> g_combine_mid_max{8192};  // BLSMI_COMBINE_MID_MAX / blsmi_set_option("combine_mid_max"): concurrent Verify calls of BLSMI_COMBINE_MAX <= n < this many tuples merge into one launch (verify_host.inc); 0: never
 std::atomic<bool> g_dup_force_sort{false};     // BLSMI_DUP_FORCE_SORT / blsmi_set_option("dup_force_sort"): test hook, the duplicate screen's fallback on every call
 void load_env() {                       // caller holds g_mu; runs once per initialisation
     auto num = [](const char* name, size_t dflt) { const char* v = getenv(name); return v ? (size_t)strtoull(v, nullptr, 10) : dflt; };
@@ -344,6 +345,7 @@ void load_env() {                       // caller holds g_mu; runs once per init
     g_env.fixed_wave_max = num("BLSMI_FIXED_WAVE_MAX", 2048);
     g_env.msm_bucket_min = num("BLSMI_MSM_BUCKET_MIN", (size_t)1 << 17);
     g_env.combine_max = num("BLSMI_COMBINE_MAX", 1024);
+    g_combine_mid_max = num("BLSMI_COMBINE_MID_MAX", 8192);
     g_env.combine_wait_us = (int)num("BLSMI_COMBINE_WAIT_US", 150);
     g_env.combine_inflight_max = std::max(1, (int)num("BLSMI_COMBINE_INFLIGHT", 2));
     g_env.combine_debug = getenv("BLSMI_COMBINE_DEBUG") != nullptr;
@@ -852,6 +854,7 @@ BLSMI_API int blsmi_set_option(const char* name, long long value) {
     else if (n == "dup_force_sort") g_dup_force_sort.store(value != 0);
     else if (n == "lat_rolled") g_lat_rolled.store(value != 0);
     else if (n == "crowd_quad") g_crowd_quad.store(value != 0);
+    else if (n == "combine_mid_max") g_combine_mid_max.store((size_t)std::max(0LL, value));
     else if (n == "crowd_floor") g_crowd_floor.store((size_t)std::max(0LL, value));
     else if (n == "assume_load") g_assume_load.store((size_t)std::max(0LL, value));
     else return BLSMI_E_ARG;

@@ -39,9 +39,9 @@ def test_rolled_pairing_program_on_the_device(eng):
 def test_set_option_rejects_unknown_names(eng):
     lib = eng._lib()
     assert lib.blsmi_set_option(b"no_such_option", 1) == -3 and lib.blsmi_set_option(None, 1) == -3
-    for name in ("agg_cofactor_pow", "msm_sort", "dup_force_sort", "lat_rolled", "crowd_quad"):
+    for name in ("agg_cofactor_pow", "msm_sort", "dup_force_sort", "lat_rolled", "crowd_quad", "combine_mid_max"):
         assert lib.blsmi_set_option(name.encode(), 1) == 0
-    eng.set_option("dup_force_sort", 0)
+    eng.set_option("dup_force_sort", 0); eng.set_option("combine_mid_max", 8192)
 
 
 def test_environment_is_read_at_initialisation_only(eng):
@@ -195,3 +195,45 @@ def test_layout_follows_the_load_of_the_device(eng, group):
     assert not errs, errs
     (ok, _), prof = call(lambda: fn(M, A, B))
     assert list(ok) == want and "quad" not in prof, prof
+
+
+def test_concurrent_mid_size_verify_calls_merge_and_keep_their_verdicts(eng):
+    """verify_host.inc, the combiner's mid-size class: concurrent Verify calls of 1 024 ... 8 191 tuples are merged into one launch among themselves
+    (one-tuple calls keep their own queue).  Every caller gets exactly its own verdicts, in both point formats, whatever it was merged with;
+    blsmi_set_option("combine_mid_max", 0) switches the class off and changes nothing in the results."""
+    import threading
+    from gpu_common import g1_to_jac, g2_to_jac
+    from test_gpu_verify import _tuples
+    msgs, pks, sigs, expect = _tuples("g2pubs", 64, 123)
+    jp = [g2_to_jac(p, (3 + i, 2 * i + 1)) for i, p in enumerate(pks)]
+    js = [g1_to_jac(s, 11 + i) for i, s in enumerate(sigs)]
+    errs, done = [], []
+
+    def caller(seed, n, jac, rounds):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(rounds):
+                sel = rng.integers(64, size=n)
+                M = eng.PackedMsgs([msgs[i] for i in sel])
+                if jac:
+                    ok, _ = eng.g2pubs_verify_batch_jac(M, b"".join(jp[i] for i in sel), b"".join(js[i] for i in sel))
+                else:
+                    ok, _ = eng.g2pubs_verify_batch(M, b"".join(pks[i] for i in sel), b"".join(sigs[i] for i in sel))
+                assert list(ok) == [expect[i] for i in sel], (seed, n, jac)
+            done.append(seed)
+        except Exception as e:                                                  # noqa: BLE001
+            errs.append(e)
+    assert any(expect) and not all(expect)
+    for mid in (8192, 0):
+        eng.set_option("combine_mid_max", mid)
+        try:
+            shapes = [(1, 1500, True, 4), (2, 3000, True, 4), (3, 5000, True, 3), (4, 1, True, 12), (5, 2600, False, 4), (6, 1100, False, 4), (7, 7000, True, 2), (8, 3, False, 12)]
+            ts = [threading.Thread(target=caller, args=a) for a in shapes]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            assert not errs, errs
+        finally:
+            eng.set_option("combine_mid_max", 8192)
+    assert len(done) == 16

@@ -48,9 +48,11 @@ def run(fn, threads, calls):
 
 
 SIZES = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256, 1024, 2048, 4096, 8192, 16384]
-print("%-8s %-6s %-8s %8s %14s %14s %10s" % ("shape", "crowd", "tuples", "threads", "ms per call", "aggregate /s", "vs lone"))
-for shape, crowd in (("verify", 0), ("verify", 1), ("pairing", 0), ("pairing", 1)):
-    E.set_option("crowd_quad", crowd)                      # 0: layout by the call's own size (the behaviour before blsmi 0.6); 1: by what the device carries
+print("%-8s %-6s %-8s %8s %14s %14s %10s" % ("shape", "mode", "tuples", "threads", "ms per call", "aggregate /s", "vs lone"))
+for shape, crowd in (("verify", 0), ("verify", 1), ("verify", 2), ("pairing", 0), ("pairing", 1)):
+    # 0: layout by the call's own size, mid-size calls never merged (the behaviour before this change); 1: layout by what the device carries;
+    # 2 (the default): + concurrent mid-size Verify calls merge into one launch (verify_host.inc: the combiner's mid-size class)
+    E.set_option("crowd_quad", 1 if crowd else 0); E.set_option("combine_mid_max", 8192 if crowd == 2 else 0)
     for n in SIZES:
         pm, pk, sg, a1, a2 = batch(n)
         if shape == "verify":
