@@ -288,7 +288,8 @@ std::atomic<size_t> g_quad_min{5632};   // BLSMI_QUAD_MIN: the quad kernels take
 // Callers that arrive together are a different matter (tools/midsize_concurrency.py): the latency path saturates the chip at 1.04 M pairings/s
 // whatever the number of calls in flight (its waves are bounded by LDS, 9 per CU), the quad kernels at 2.8 M/s (two 8 192-tuple calls take
 // the 6 ms of one).  So the choice goes by what the DEVICE carries: a call of at least g_crowd_floor tuples takes the quad kernels when its
-// tuples plus those of the other calls in flight pass the lone crossover.  A call registers its tuples at its first layout question and
+// tuples plus those of the other calls in flight pass the lone crossover (floor 2 560 with the runtime's default four hardware queues: at 2 048
+// four concurrent quad launches measured no better than the latency path there; with GPU_MAX_HW_QUEUES=8 a floor of 1 536 pays, 8.1 -> 6.0 ms a call).  A call registers its tuples at its first layout question and
 // keeps the answer's input for its whole life (one call never sees two different loads); ~CtxLease takes them off again.
 std::atomic<bool> g_crowd_quad{true};        // BLSMI_CROWD_QUAD / blsmi_set_option("crowd_quad")
 std::atomic<size_t> g_crowd_floor{2560};     // BLSMI_CROWD_FLOOR / blsmi_set_option("crowd_floor")
@@ -492,6 +493,13 @@ struct CtxLease {
     }
 };
 
+// is a call context free on some device right now?  (a hint for the request combiner: the answer may be stale by the time it is used)
+bool context_free_now() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ready) return true;
+    for (int i = 0; i < g_ndev; i++) if (g_dev[i].leased < g_nctx) return true;
+    return false;
+}
 // A caller-supplied stream (the *_dev entry points) stands in for the leased context's stream for one call.
 struct UseStream {
     hipStream_t saved;

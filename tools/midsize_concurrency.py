@@ -48,6 +48,8 @@ def run(fn, threads, calls):
 
 
 SIZES = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [256, 1024, 2048, 4096, 8192, 16384]
+if os.environ.get("CROWD_FLOOR"):
+    E.set_option("crowd_floor", int(os.environ["CROWD_FLOOR"]))        # (A/B of the floor itself)
 print("%-8s %-6s %-8s %8s %14s %14s %10s" % ("shape", "mode", "tuples", "threads", "ms per call", "aggregate /s", "vs lone"))
 for shape, crowd in (("verify", 0), ("verify", 1), ("verify", 2), ("pairing", 0), ("pairing", 1)):
     # 0: layout by the call's own size, mid-size calls never merged (the behaviour before this change); 1: layout by what the device carries;
