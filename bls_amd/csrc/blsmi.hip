@@ -301,11 +301,12 @@ inline size_t call_load(size_t n) {
     return c->load_others + g_assume_load.load(std::memory_order_relaxed);
 }
 inline bool use_quad(size_t n) {
+    // every sizeable call is counted, whatever layout it takes itself (a 65 536-tuple call in flight is load for the 3 000-tuple call beside it)
+    const bool crowd = g_crowd_quad.load(std::memory_order_relaxed) && n >= g_crowd_floor.load(std::memory_order_relaxed);
+    const size_t others = crowd ? call_load(n) : 0;
     if (!g_pair_layout || n > g_quad_max) return false;
     const size_t lone = std::min(g_lat_max.load(), g_quad_min.load());
-    if (n > lone) return true;
-    if (!g_crowd_quad.load(std::memory_order_relaxed) || n < g_crowd_floor.load(std::memory_order_relaxed)) return false;
-    return n + call_load(n) > lone;
+    return n > lone || (crowd && n + others > lone);
 }
 inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
 inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }

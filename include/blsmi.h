@@ -136,7 +136,8 @@ int blsmi_prefer_cpu(int shape, size_t n);
  * Concurrency needs hardware queues: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES of them (default 4) and kernels of one
  * queue run one after the other.  An operator may export GPU_MAX_HW_QUEUES=8 before the process starts: four callers x 4 096 pairings 9.0 -> 6.3 ms
  * a call (profiles/r05_midsize_concurrency.log).  The library does NOT set it: one long-running test process with sixteen caller threads aborted
- * inside the runtime with 8 queues and never with 4, so it stays an opt-in.
+ * inside the runtime with 8 queues and never with 4, and a mixed soak of sixteen callers ran 5.7x slower with 8 queues than with 4 (eight callers: the
+ * same speed) -- profiles/r05_soak9.log --, so it stays an opt-in for hosts with few concurrent callers.
  * Test hooks: BLSMI_DEVICE_ALIAS (above); "assume_load" (tuples pretended to be in flight from other calls).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
 int blsmi_set_option(const char *name, long long value);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
