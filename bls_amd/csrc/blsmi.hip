@@ -239,6 +239,10 @@ int init_device(Device& d) {            // caller holds g_mu
     uint64_t keep = UINT64_MAX;
     HIPCHK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
     for (auto& c : d.ctx) c.dev = &d;
+    // The call contexts' streams, created back to back before any other stream of the library: the HIP runtime hands its hardware queues
+    // (GPU_MAX_HW_QUEUES, default 4) to streams in creation order, and kernels of one queue run one after the other -- created lazily, between
+    // side streams and the exchange stream, two of four contexts shared a queue (rocprofv3 --kernel-trace of four concurrent callers: three queues)
+    for (int i = 0; i < g_nctx; i++) if (!d.ctx[i].stream) HIPCHK(hipStreamCreateWithFlags(&d.ctx[i].stream, hipStreamNonBlocking));
     if (!d.gens.g1) {
         HIPCHK(hipMalloc((void**)&d.gens.g1, 96)); HIPCHK(hipMalloc((void**)&d.gens.g2, 192));
         hipLaunchKernelGGL(k_write_generators, dim3(1), dim3(WG), 0, nullptr, d.gens.g1, d.gens.g2);
@@ -288,11 +292,11 @@ std::atomic<size_t> g_quad_min{5632};   // BLSMI_QUAD_MIN: the quad kernels take
 // Callers that arrive together are a different matter (tools/midsize_concurrency.py): the latency path saturates the chip at 1.04 M pairings/s
 // whatever the number of calls in flight (its waves are bounded by LDS, 9 per CU), the quad kernels at 2.8 M/s (two 8 192-tuple calls take
 // the 6 ms of one).  So the choice goes by what the DEVICE carries: a call of at least g_crowd_floor tuples takes the quad kernels when its
-// tuples plus those of the other calls in flight pass the lone crossover (floor 2 560 with the runtime's default four hardware queues: at 2 048
-// four concurrent quad launches measured no better than the latency path there; with GPU_MAX_HW_QUEUES=8 a floor of 1 536 pays, 8.1 -> 6.0 ms a call).  A call registers its tuples at its first layout question and
+// tuples plus those of the other calls in flight pass the lone crossover (floor 1 536: four callers x 2 048 pairings 7.9 -> 6.1 ms a call; at 1 024
+// the sum never passes the crossover with four contexts).  A call registers its tuples at its first layout question and
 // keeps the answer's input for its whole life (one call never sees two different loads); ~CtxLease takes them off again.
 std::atomic<bool> g_crowd_quad{true};        // BLSMI_CROWD_QUAD / blsmi_set_option("crowd_quad")
-std::atomic<size_t> g_crowd_floor{2560};     // BLSMI_CROWD_FLOOR / blsmi_set_option("crowd_floor")
+std::atomic<size_t> g_crowd_floor{1536};     // BLSMI_CROWD_FLOOR / blsmi_set_option("crowd_floor")
 std::atomic<size_t> g_assume_load{0};        // blsmi_set_option("assume_load"): test hook, tuples pretended to be in flight from other calls
 inline size_t call_load(size_t n) {
     Ctx* c = tl_ctx;

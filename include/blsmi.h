@@ -128,16 +128,16 @@ int blsmi_prefer_cpu(int shape, size_t n);
  *   whose squaring runs are loops).
  * Layout by what the DEVICE carries (blsmi 0.6): the hand-overs above are a lone caller's.  Calls that arrive together share the chip, and
  * under load the quad kernels serve 2.7x the tuples per second of the one-tuple-per-wave path, so a pairing / verify call of at least
- * "crowd_floor" tuples (BLSMI_CROWD_FLOOR, default 2560; 1536 pays with GPU_MAX_HW_QUEUES=8) takes them when its tuples plus those of the other calls in flight on its device pass
+ * "crowd_floor" tuples (BLSMI_CROWD_FLOOR, default 1536) takes them when its tuples plus those of the other calls in flight on its device pass
  * BLSMI_QUAD_MIN; "crowd_quad" (BLSMI_CROWD_QUAD, default 1) 0: by the call's own size only.  Same results either way (bit-exact layouts).
  * Concurrent Verify calls of BLSMI_COMBINE_MAX <= n < "combine_mid_max" tuples (BLSMI_COMBINE_MID_MAX, default 8192; 0: never) are merged into one
  * launch among themselves when no call context is free (more callers than BLSMI_STREAMS), like the one-tuple calls below BLSMI_COMBINE_MAX are among
- * theirs.  Eight callers x 4 096 g2pubs tuples: 0.73 -> 1.79 M verifies/s with both; four callers x 4 096 pairings: 1.05 -> 2.59 M/s.
- * Concurrency needs hardware queues: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES of them (default 4) and kernels of one
- * queue run one after the other.  An operator may export GPU_MAX_HW_QUEUES=8 before the process starts: four callers x 4 096 pairings 9.0 -> 6.3 ms
- * a call (profiles/r05_midsize_concurrency.log).  The library does NOT set it: one long-running test process with sixteen caller threads aborted
- * inside the runtime with 8 queues and never with 4, and a mixed soak of sixteen callers ran 5.7x slower with 8 queues than with 4 (eight callers: the
- * same speed) -- profiles/r05_soak9.log --, so it stays an opt-in for hosts with few concurrent callers.
+ * theirs.
+ * Eight callers x 4 096 g2pubs tuples: 0.73 -> 1.84 M verifies/s with both; four callers x 4 096 pairings: 1.04 -> 2.50 M/s.
+ * Concurrency needs hardware queues: the HIP runtime hands its GPU_MAX_HW_QUEUES queues (default 4) to streams in creation order and kernels of one
+ * queue run one after the other, so the library creates its call contexts' streams back to back when it initialises (BLSMI_STREAMS = 4 = one queue
+ * each).  Raising GPU_MAX_HW_QUEUES is not needed and not harmless: with 8, sixteen concurrent callers ran 5.7x slower and one long test process
+ * aborted inside the runtime (profiles/r05_soak9.log).
  * Test hooks: BLSMI_DEVICE_ALIAS (above); "assume_load" (tuples pretended to be in flight from other calls).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
 int blsmi_set_option(const char *name, long long value);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
