@@ -7,12 +7,9 @@ import bench
 from bls_amd import engine
 
 engine.init(0)
-import torch
-dev = torch.device("cuda", 0)
 nmax = 65536
-d = bench._verify_inputs(engine, dev, "g2pubs", nmax)
-buf, off, pks, sigs = [x.cpu().numpy() for x in d]
-off = off.view(np.uint64)
+packed, pks, sigs = bench._verify_tuples(engine, "g2pubs", nmax)
+buf, off = packed.buf, packed.off
 for n in (1, 2, 32, 64, 1024, 8192, 65536):
     msgs = [bytes(buf[int(off[i]):int(off[i + 1])]) for i in range(n)]
     pk = pks[:n].tobytes(); sg = sigs[:n].tobytes()
