@@ -7,7 +7,9 @@
 // implementations of Verify, VerifyWithDomain, VerifyAggregate, VerifyAggregateCommon,
 // VerifyAggregateCommonWithDomain and VerifyAggregateWithDomain (g1pubs/bls.go:165-174, 252-311) move
 // behind `// +build !blsmi`.  bls.go keeps types, Sign, SignWithDomain, PrivToPub, (de)serialisation and
-// the aggregation helpers.  tests/test_shim.py checks every C.blsmi_* call below against include/blsmi.h.
+// the aggregation helpers.  tests/test_shim.py checks every C.blsmi_* call below against include/blsmi.h (name, arity and the
+// C type of every argument, in order).  Go version: the language of the reference's go.mod (`go 1.13`, /root/reference/go.mod:15)
+// -- nothing newer is used (no unsafe.Slice / unsafe.Add, no generics, no `any`, old-style build tags).
 package g1pubs
 
 /*
@@ -18,15 +20,32 @@ package g1pubs
 import "C"
 
 import (
+	"strconv"
 	"unsafe"
 
 	"github.com/phoreproject/bls"
 )
 
-func init() {
-	if rc := C.blsmi_init_devices(0); rc != 0 {
-		panic("blsmi: no usable MI355X (or RCCL missing on a multi-GPU node)")
+// must: ONE error policy for every entry point.  A non-zero return code is a device / runtime failure (BLSMI_E_HIP, _NOMEM, _RCCL, _ARG:
+// include/blsmi.h), never a verdict -- `false` from a Verify* function only ever means that the pairing check failed, as upstream
+// (g1pubs/bls.go).  A consensus caller must not mistake a failed hipMalloc for an invalid signature: panic, like upstream does on its own
+// internal errors (a deployment that prefers to degrade wraps the call sites in recover() and re-runs them on the upstream CPU path).
+func must(rc C.int, what string) {
+	if rc != 0 {
+		panic("blsmi: " + what + " failed (" + strconv.Itoa(int(rc)) + ")")
 	}
+}
+
+// Compile-time layout guards: the *_jac entry points read the structs below as 36 / 18 contiguous uint64 (x, y, z; FQ2 = two FQ; FQ =
+// FQRepr = [6]uint64: g2.go:298-302, g1.go:252-256, fq2.go:14-17, fq.go:11-13, fqrepr.go:14).  If upstream ever changes a layout the
+// index below is no longer the constant 0 and the package stops compiling (constant index out of range / constant overflow) instead of
+// handing the device garbage.
+var _ = [1]struct{}{}[unsafe.Sizeof(bls.G2Projective{})-288]
+var _ = [1]struct{}{}[unsafe.Sizeof(bls.G1Projective{})-144]
+var _ = [1]struct{}{}[unsafe.Sizeof(bls.FQRepr{})-48]
+
+func init() {
+	must(C.blsmi_init_devices(0), "init_devices (no usable MI355X, or RCCL missing on a multi-GPU node)")
 }
 
 func u8(b []byte) *C.uint8_t {
@@ -95,9 +114,7 @@ func VerifyBatch(msgs [][]byte, pubs []*PublicKey, sigs []*Signature) []bool {
 	pk := packKeys(pubs)
 	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	if rc := C.blsmi_g1pubs_verify_batch_jac(u8(m), &off[0], u64(pk), u64(sg), u8(ok), nil, C.size_t(n)); rc != 0 {
-		panic("blsmi: g1pubs verify_batch failed")
-	}
+	must(C.blsmi_g1pubs_verify_batch_jac(u8(m), &off[0], u64(pk), u64(sg), u8(ok), nil, C.size_t(n)), "g1pubs_verify_batch_jac")
 	for i := range ok {
 		out[i] = ok[i] != 0
 	}
@@ -124,11 +141,8 @@ func VerifyWithDomainBatch(msgs [][32]byte, pubs []*PublicKey, sigs []*Signature
 	pk := packKeys(pubs)
 	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g1pubs_verify_with_domain_batch_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u64(pk), u64(sg), u8(ok), nil, C.size_t(n))
-	if rc != 0 {
-		panic("blsmi: g1pubs verify_with_domain_batch failed")
-	}
+	must(C.blsmi_g1pubs_verify_with_domain_batch_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u64(pk), u64(sg), u8(ok), nil, C.size_t(n)), "g1pubs_verify_with_domain_batch_jac")
 	for i := range ok {
 		out[i] = ok[i] != 0
 	}
@@ -144,8 +158,8 @@ func (s *Signature) VerifyAggregate(pubKeys []*PublicKey, msgs [][]byte) bool {
 	m, off := packMsgs(msgs)
 	pk := packKeys(pubKeys) // a key or the signature at infinity (z == 0): verdict false (upstream panics in MillerLoop)
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_jac(u8(m), &off[0], u64(pk), sigWords(s), C.size_t(len(msgs)), &ok)
-	return rc == 0 && ok != 0
+	must(C.blsmi_g1pubs_verify_aggregate_jac(u8(m), &off[0], u64(pk), sigWords(s), C.size_t(len(msgs)), &ok), "g1pubs_verify_aggregate_jac")
+	return ok != 0
 }
 
 // VerifyAggregateCommon keeps the upstream signature (g1pubs/bls.go:287).
@@ -160,17 +174,17 @@ func (s *Signature) VerifyAggregateCommon(pubKeys []*PublicKey, msg []byte) bool
 		mp = u8(one)
 	}
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_common_jac(mp, C.size_t(len(msg)), u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok)
-	return rc == 0 && ok != 0
+	must(C.blsmi_g1pubs_verify_aggregate_common_jac(mp, C.size_t(len(msg)), u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok), "g1pubs_verify_aggregate_common_jac")
+	return ok != 0
 }
 
 // VerifyAggregateCommonWithDomain keeps the upstream signature (g1pubs/bls.go:294).
 func (s *Signature) VerifyAggregateCommonWithDomain(pubKeys []*PublicKey, msg [32]byte, domain [8]byte) bool {
 	pk := packKeys(pubKeys)
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_common_with_domain_jac((*C.uint8_t)(unsafe.Pointer(&msg[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok)
-	return rc == 0 && ok != 0
+	must(C.blsmi_g1pubs_verify_aggregate_common_with_domain_jac((*C.uint8_t)(unsafe.Pointer(&msg[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok), "g1pubs_verify_aggregate_common_with_domain_jac")
+	return ok != 0
 }
 
 // VerifyAggregateWithDomain keeps the upstream signature (g1pubs/bls.go:300); no duplicate check upstream
@@ -185,9 +199,9 @@ func (s *Signature) VerifyAggregateWithDomain(pubKeys []*PublicKey, msgs [][32]b
 	}
 	pk := packKeys(pubKeys)
 	var ok C.int
-	rc := C.blsmi_g1pubs_verify_aggregate_with_domain_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u64(pk), sigWords(s), C.size_t(len(msgs)), &ok)
-	return rc == 0 && ok != 0
+	must(C.blsmi_g1pubs_verify_aggregate_with_domain_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u64(pk), sigWords(s), C.size_t(len(msgs)), &ok), "g1pubs_verify_aggregate_with_domain_jac")
+	return ok != 0
 }
 
 // SumPublicKeys is AggregatePublicKeys (g1pubs/bls.go:192-204) for large sets: the points are summed on the device as they are and the sum
@@ -199,9 +213,7 @@ func SumPublicKeys(pubKeys []*PublicKey) *PublicKey {
 	pk := packKeys(pubKeys)
 	out := new(bls.G1Projective)
 	var inf C.int
-	if rc := C.blsmi_g1_sum_jac(u64(pk), C.size_t(len(pubKeys)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
-		panic("blsmi: g1 sum failed")
-	}
+	must(C.blsmi_g1_sum_jac(u64(pk), C.size_t(len(pubKeys)), (*C.uint64_t)(unsafe.Pointer(out)), &inf), "g1_sum_jac")
 	return &PublicKey{p: out}
 }
 
@@ -213,9 +225,7 @@ func SumSignatures(sigs []*Signature) *Signature {
 	sg := packSigs(sigs)
 	out := new(bls.G2Projective)
 	var inf C.int
-	if rc := C.blsmi_g2_sum_jac(u64(sg), C.size_t(len(sigs)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
-		panic("blsmi: g2 sum failed")
-	}
+	must(C.blsmi_g2_sum_jac(u64(sg), C.size_t(len(sigs)), (*C.uint64_t)(unsafe.Pointer(out)), &inf), "g2_sum_jac")
 	return &Signature{s: out}
 }
 
@@ -229,12 +239,9 @@ func VerifySerializedBatch(msgs [][]byte, pubs [][48]byte, sigs [][96]byte) []bo
 	}
 	m, off := packMsgs(msgs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g1pubs_verify_serialized_batch(u8(m), &off[0],
+	must(C.blsmi_g1pubs_verify_serialized_batch(u8(m), &off[0],
 		(*C.uint8_t)(unsafe.Pointer(&pubs[0])), (*C.uint8_t)(unsafe.Pointer(&sigs[0])), 1,
-		u8(ok), nil, nil, C.size_t(n))
-	if rc != 0 {
-		panic("blsmi: verify_serialized_batch failed")
-	}
+		u8(ok), nil, nil, C.size_t(n)), "g1pubs_verify_serialized_batch")
 	for i := range ok {
 		out[i] = ok[i] != 0
 	}
@@ -277,9 +284,7 @@ func SignBatch(msgs [][]byte, keys []*SecretKey) []*Signature {
 	}
 	m, off := packMsgs(msgs)
 	sg := make([]C.uint64_t, 36*n)
-	if rc := C.blsmi_g1pubs_sign_batch_jac(u8(m), &off[0], u8(secretBytes(keys)), &sg[0], C.size_t(n)); rc != 0 {
-		panic("blsmi: g1pubs sign_batch failed")
-	}
+	must(C.blsmi_g1pubs_sign_batch_jac(u8(m), &off[0], u8(secretBytes(keys)), &sg[0], C.size_t(n)), "g1pubs_sign_batch_jac")
 	return sigsFromWords(sg, n)
 }
 
@@ -290,10 +295,7 @@ func SignWithDomainBatch(msgs [][32]byte, keys []*SecretKey, domain [8]byte) []*
 		return nil
 	}
 	sg := make([]C.uint64_t, 36*n)
-	rc := C.blsmi_g1pubs_sign_with_domain_batch_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
-		u8(secretBytes(keys)), &sg[0], C.size_t(n))
-	if rc != 0 {
-		panic("blsmi: g1pubs sign_with_domain_batch failed")
-	}
+	must(C.blsmi_g1pubs_sign_with_domain_batch_jac((*C.uint8_t)(unsafe.Pointer(&msgs[0])), (*C.uint8_t)(unsafe.Pointer(&domain[0])),
+		u8(secretBytes(keys)), &sg[0], C.size_t(n)), "g1pubs_sign_with_domain_batch_jac")
 	return sigsFromWords(sg, n)
 }

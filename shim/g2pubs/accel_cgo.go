@@ -6,7 +6,9 @@
 // implementations of Verify, VerifyAggregate and VerifyAggregateCommon (g2pubs/bls.go:159-162, 240-270,
 // 275-278) move behind `// +build !blsmi`.  Everything else in bls.go (types, Sign, PrivToPub,
 // serialisation, the aggregation helpers) stays as it is; SignBatch below is an addition for bulk signing.  The C prototypes are include/blsmi.h;
-// tests/test_shim.py checks every C.blsmi_* call below against it (name and arity).
+// tests/test_shim.py checks every C.blsmi_* call below against it (name, arity and the C type of every argument, in order).
+// Go version: the language of the reference's go.mod (`go 1.13`, /root/reference/go.mod:15) -- nothing newer is used (no unsafe.Slice /
+// unsafe.Add, no generics, no `any`, old-style build tags); cgo as shipped with go >= 1.13.
 package g2pubs
 
 /*
@@ -18,17 +20,34 @@ import "C"
 
 import (
 	"runtime"
+	"strconv"
 	"unsafe"
 
 	"github.com/phoreproject/bls"
 )
 
+// must: ONE error policy for every entry point.  A non-zero return code is a device / runtime failure (BLSMI_E_HIP, _NOMEM, _RCCL, _ARG:
+// include/blsmi.h), never a verdict -- `false` from a Verify* function only ever means that the pairing check failed, as upstream
+// (g2pubs/bls.go).  A consensus caller must not mistake a failed hipMalloc for an invalid signature: panic, like upstream does on its own
+// internal errors (a deployment that prefers to degrade wraps the call sites in recover() and re-runs them on the upstream CPU path).
+func must(rc C.int, what string) {
+	if rc != 0 {
+		panic("blsmi: " + what + " failed (" + strconv.Itoa(int(rc)) + ")")
+	}
+}
+
+// Compile-time layout guards: the *_jac entry points read the structs below as 36 / 18 contiguous uint64 (x, y, z; FQ2 = two FQ; FQ =
+// FQRepr = [6]uint64: g2.go:298-302, g1.go:252-256, fq2.go:14-17, fq.go:11-13, fqrepr.go:14).  If upstream ever changes a layout the
+// index below is no longer the constant 0 and the package stops compiling (constant index out of range / constant overflow) instead of
+// handing the device garbage.
+var _ = [1]struct{}{}[unsafe.Sizeof(bls.G2Projective{})-288]
+var _ = [1]struct{}{}[unsafe.Sizeof(bls.G1Projective{})-144]
+var _ = [1]struct{}{}[unsafe.Sizeof(bls.FQRepr{})-48]
+
 func init() {
 	// Every visible device (<= 0), or the first n.  Must precede any other blsmi call.  With more than one
 	// device, batches of BLSMI_SHARD_MIN tuples or more are split over the GPUs inside the library.
-	if rc := C.blsmi_init_devices(0); rc != 0 {
-		panic("blsmi: no usable MI355X (or RCCL missing on a multi-GPU node)")
-	}
+	must(C.blsmi_init_devices(0), "init_devices (no usable MI355X, or RCCL missing on a multi-GPU node)")
 }
 
 func u8(b []byte) *C.uint8_t {
@@ -98,10 +117,7 @@ func VerifyBatch(msgs [][]byte, pubs []*PublicKey, sigs []*Signature) []bool {
 	pk := packKeys(pubs)
 	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g2pubs_verify_batch_jac(u8(m), &off[0], u64(pk), u64(sg), u8(ok), nil, C.size_t(n))
-	if rc != 0 {
-		panic("blsmi: g2pubs verify_batch failed")
-	}
+	must(C.blsmi_g2pubs_verify_batch_jac(u8(m), &off[0], u64(pk), u64(sg), u8(ok), nil, C.size_t(n)), "g2pubs_verify_batch_jac")
 	for i := range ok {
 		out[i] = ok[i] != 0
 	}
@@ -123,8 +139,8 @@ func (s *Signature) VerifyAggregate(pubKeys []*PublicKey, msgs [][]byte) bool {
 	m, off := packMsgs(msgs)
 	pk := packKeys(pubKeys)
 	var ok C.int
-	rc := C.blsmi_g2pubs_verify_aggregate_jac(u8(m), &off[0], u64(pk), sigWords(s), C.size_t(len(msgs)), &ok)
-	return rc == 0 && ok != 0
+	must(C.blsmi_g2pubs_verify_aggregate_jac(u8(m), &off[0], u64(pk), sigWords(s), C.size_t(len(msgs)), &ok), "g2pubs_verify_aggregate_jac")
+	return ok != 0
 }
 
 // VerifyAggregateCommon keeps the upstream signature (g2pubs/bls.go:275): the key sum stays on the upstream
@@ -141,8 +157,8 @@ func (s *Signature) VerifyAggregateCommon(pubKeys []*PublicKey, msg []byte) bool
 		mp = u8(one)
 	}
 	var ok C.int
-	rc := C.blsmi_g2pubs_verify_aggregate_common_jac(mp, C.size_t(len(msg)), u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok)
-	return rc == 0 && ok != 0
+	must(C.blsmi_g2pubs_verify_aggregate_common_jac(mp, C.size_t(len(msg)), u64(pk), sigWords(s), C.size_t(len(pubKeys)), &ok), "g2pubs_verify_aggregate_common_jac")
+	return ok != 0
 }
 
 // SumPublicKeys is AggregatePublicKeys (g2pubs/bls.go:180-192) for large sets: the points are summed on the device as they are and the sum
@@ -154,9 +170,7 @@ func SumPublicKeys(pubKeys []*PublicKey) *PublicKey {
 	pk := packKeys(pubKeys)
 	out := new(bls.G2Projective)
 	var inf C.int
-	if rc := C.blsmi_g2_sum_jac(u64(pk), C.size_t(len(pubKeys)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
-		panic("blsmi: g2 sum failed")
-	}
+	must(C.blsmi_g2_sum_jac(u64(pk), C.size_t(len(pubKeys)), (*C.uint64_t)(unsafe.Pointer(out)), &inf), "g2_sum_jac")
 	return &PublicKey{p: out}
 }
 
@@ -168,9 +182,7 @@ func SumSignatures(sigs []*Signature) *Signature {
 	sg := packSigs(sigs)
 	out := new(bls.G1Projective)
 	var inf C.int
-	if rc := C.blsmi_g1_sum_jac(u64(sg), C.size_t(len(sigs)), (*C.uint64_t)(unsafe.Pointer(out)), &inf); rc != 0 {
-		panic("blsmi: g1 sum failed")
-	}
+	must(C.blsmi_g1_sum_jac(u64(sg), C.size_t(len(sigs)), (*C.uint64_t)(unsafe.Pointer(out)), &inf), "g1_sum_jac")
 	return &Signature{s: out}
 }
 
@@ -185,12 +197,9 @@ func VerifySerializedBatch(msgs [][]byte, pubs [][96]byte, sigs [][48]byte) []bo
 	}
 	m, off := packMsgs(msgs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g2pubs_verify_serialized_batch(u8(m), &off[0],
+	must(C.blsmi_g2pubs_verify_serialized_batch(u8(m), &off[0],
 		(*C.uint8_t)(unsafe.Pointer(&pubs[0])), (*C.uint8_t)(unsafe.Pointer(&sigs[0])), 1,
-		u8(ok), nil, nil, C.size_t(n))
-	if rc != 0 {
-		panic("blsmi: verify_serialized_batch failed")
-	}
+		u8(ok), nil, nil, C.size_t(n)), "g2pubs_verify_serialized_batch")
 	for i := range ok {
 		out[i] = ok[i] != 0
 	}
@@ -208,9 +217,7 @@ type PreparedKeys struct {
 func PrepareKeys(pubs []*PublicKey) *PreparedKeys {
 	pk := packKeys(pubs) // a key at infinity (z == 0) keeps that mark in its table: every verdict over it is false
 	var h unsafe.Pointer
-	if rc := C.blsmi_g2_prepared_create_jac(u64(pk), C.size_t(len(pubs)), &h); rc != 0 {
-		panic("blsmi: prepare failed")
-	}
+	must(C.blsmi_g2_prepared_create_jac(u64(pk), C.size_t(len(pubs)), &h), "g2_prepared_create_jac")
 	k := &PreparedKeys{h, len(pubs)}
 	runtime.SetFinalizer(k, func(k *PreparedKeys) { k.Close() })
 	return k
@@ -233,36 +240,12 @@ func VerifyBatchPrepared(msgs [][]byte, keys *PreparedKeys, keyIdx []uint32, sig
 	m, off := packMsgs(msgs)
 	sg := packSigs(sigs)
 	ok := make([]byte, n)
-	rc := C.blsmi_g2pubs_verify_batch_prepared_jac(u8(m), &off[0], keys.h, (*C.uint32_t)(unsafe.Pointer(&keyIdx[0])),
-		u64(sg), u8(ok), nil, C.size_t(n))
-	if rc != 0 {
-		panic("blsmi: verify_batch_prepared failed")
-	}
+	must(C.blsmi_g2pubs_verify_batch_prepared_jac(u8(m), &off[0], keys.h, (*C.uint32_t)(unsafe.Pointer(&keyIdx[0])),
+		u64(sg), u8(ok), nil, C.size_t(n)), "g2pubs_verify_batch_prepared_jac")
 	for i := range ok {
 		out[i] = ok[i] != 0
 	}
 	return out
-}
-
-// staging is a reusable page-locked buffer (blsmi_host_alloc): copies from it are single DMAs instead of
-// being staged by the HIP runtime.  b aliases C memory (no Go pointers inside: safe to hand to cgo as-is);
-// keep one set per goroutine that calls into the library and serialise points straight into b[:0].
-type staging struct {
-	p unsafe.Pointer
-	b []byte
-}
-
-func newStaging(n int) *staging {
-	var p unsafe.Pointer
-	if rc := C.blsmi_host_alloc(C.size_t(n), &p); rc != 0 {
-		panic("blsmi_host_alloc")
-	}
-	return &staging{p: p, b: unsafe.Slice((*byte)(p), n)}
-}
-
-func (s *staging) free() {
-	C.blsmi_host_free(s.p)
-	s.p, s.b = nil, nil
 }
 
 // Trim hands the temporaries the library keeps for future calls back to the driver (after a burst of very
@@ -296,9 +279,7 @@ func SignBatch(msgs [][]byte, keys []*SecretKey) []*Signature {
 	}
 	// the signatures come back as G1Projective records (z = 1; the reference's zero point for sk = 0 mod r): one copy each
 	sg := make([]C.uint64_t, 18*n)
-	if rc := C.blsmi_g2pubs_sign_batch_jac(u8(m), &off[0], u8(sk), &sg[0], C.size_t(n)); rc != 0 {
-		panic("blsmi: g2pubs sign_batch failed")
-	}
+	must(C.blsmi_g2pubs_sign_batch_jac(u8(m), &off[0], u8(sk), &sg[0], C.size_t(n)), "g2pubs_sign_batch_jac")
 	for i := range out {
 		p := new(bls.G1Projective)
 		copy((*[18]C.uint64_t)(unsafe.Pointer(p))[:], sg[18*i:18*i+18])
