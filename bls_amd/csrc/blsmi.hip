@@ -304,16 +304,32 @@ inline size_t call_load(size_t n) {
     if (!c->load_set) { c->load_others = c->dev->load.fetch_add(n, std::memory_order_relaxed); c->load_n = n; c->load_set = true; }
     return c->load_others + g_assume_load.load(std::memory_order_relaxed);
 }
+// A fourth layout between the wave and the quad (round 6, k_pairing_row.hip): one tuple per DPP ROW of sixteen lanes.  g_row_min .. g_row_max
+// tuples of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
+// 3.3 x the instructions on the one-tuple-per-wave path).  When other calls are in flight on the device the choice above stands (the quad
+// kernels spend fewer lane-instructions per tuple: 12.6 M against 18 M).  blsmi_set_row_threshold / BLSMI_ROW_MIN / BLSMI_ROW_MAX; max 0: off.
+std::atomic<size_t> g_row_min{2048};
+std::atomic<size_t> g_row_max{10240};
+inline bool use_row(size_t n) {
+    const bool crowd = g_crowd_quad.load(std::memory_order_relaxed) && n >= g_crowd_floor.load(std::memory_order_relaxed);
+    const size_t others = crowd ? call_load(n) : 0;                        // (every sizeable call is counted, whatever layout it takes itself)
+    const size_t hi = g_row_max.load(std::memory_order_relaxed);
+    if (!g_pair_layout || hi == 0 || n > hi || n < g_row_min.load(std::memory_order_relaxed)) return false;
+    const size_t lone = std::min(g_lat_max.load(), g_quad_min.load());
+    return !(others > 0 && n + others > lone);
+}
 inline bool use_quad(size_t n) {
     // every sizeable call is counted, whatever layout it takes itself (a 65 536-tuple call in flight is load for the 3 000-tuple call beside it)
     const bool crowd = g_crowd_quad.load(std::memory_order_relaxed) && n >= g_crowd_floor.load(std::memory_order_relaxed);
     const size_t others = crowd ? call_load(n) : 0;
     if (!g_pair_layout || n > g_quad_max) return false;
+    if (use_row(n)) return false;
     const size_t lone = std::min(g_lat_max.load(), g_quad_min.load());
     return n > lone || (crowd && n + others > lone);
 }
-inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n); }
+inline bool use_lat(size_t n) { return n <= g_lat_max && !use_quad(n) && !use_row(n); }
 inline unsigned qblocks(size_t n) { return (unsigned)((n + QT - 1) / QT); }
+inline unsigned rblocks(size_t n) { return (unsigned)((n + RT - 1) / RT); }
 inline bool mul_subgroup() { return !tl_mul_any && g_mul_subgroup.load(std::memory_order_relaxed); }
 inline u32 lat_lds_bytes(size_t prog_offset) { u32 nslot; memcpy(&nslot, blsmi_lat_blob + prog_offset + 8, 4); return nslot * 80; }   // k_lat.hip: SLOT_WORDS * 4
 // ---- the environment is read ONCE, at initialisation (under g_mu), never from an entry point ---------------------------------------
@@ -382,6 +398,8 @@ int ensure_init_list(const int* devs, int ndev) {
     if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_QUAD_MAX")) g_quad_max = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_QUAD_MIN")) g_quad_min = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_ROW_MIN")) g_row_min = (size_t)strtoull(v, nullptr, 10);
+    if (const char* v = getenv("BLSMI_ROW_MAX")) g_row_max = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_ARENA_KEEP_MB")) g_arena_keep = (size_t)strtoull(v, nullptr, 10) << 20;
     if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
@@ -798,6 +816,16 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
+    if (mode == 0 && use_row(n)) {                                         // a few thousand tuples: sixteen lanes per tuple, one wave per SIMD at 4 096 tuples
+        prof_mark("k_miller1h_row");
+        hipLaunchKernelGGL(k_miller1h_row, dim3(rblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
+        prof_mark("k_final_exp_row");
+        hipLaunchKernelGGL(k_final_exp_row, dim3(rblocks(n)), dim3(WG), 0, s, (const i32*)f, (u64*)d_out, n, 0);
+        prof_mark(nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+        return BLSMI_OK;
+    }
     if (mode == 0 && use_quad(n)) {                                        // mid-size batch: four lanes per tuple, one wave per SIMD at 16 384 tuples
         prof_mark("k_miller1h_quad");
         hipLaunchKernelGGL(k_miller1h_quad, dim3(qblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
@@ -849,6 +877,11 @@ BLSMI_API int blsmi_prefer_cpu(int shape, size_t n) {
 }
 BLSMI_API int blsmi_set_quad_threshold(size_t max_tuples) {
     g_quad_max.store(max_tuples);
+    return BLSMI_OK;
+}
+BLSMI_API int blsmi_set_row_threshold(size_t min_tuples, size_t max_tuples) {
+    g_row_min.store(min_tuples);
+    g_row_max.store(max_tuples);
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
@@ -994,9 +1027,11 @@ BLSMI_API int blsmi_final_exponentiation_batch(const uint64_t* in, uint64_t* out
 BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, uint64_t* out, uint8_t* flag, size_t n) {
     const bool pairl = (op_in & BLSMI_OP_LANE_PAIR) != 0;                 // run the tower op in the lane-pair layout
     const bool quadl = (op_in & BLSMI_OP_LANE_QUAD) != 0;                 // ... the Fq12 op in the lane-quad layout
-    const int op = op_in & ~(BLSMI_OP_LANE_PAIR | BLSMI_OP_LANE_QUAD);
+    const bool rowl = (op_in & BLSMI_OP_LANE_ROW) != 0;                   // ... in the lane-row layout
+    const int op = op_in & ~(BLSMI_OP_LANE_PAIR | BLSMI_OP_LANE_QUAD | BLSMI_OP_LANE_ROW);
     if (pairl && (op < 16 || op >= 64)) return BLSMI_E_ARG;
-    if (quadl && (pairl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014)) return BLSMI_E_ARG;
+    if (quadl && (pairl || rowl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014)) return BLSMI_E_ARG;
+    if (rowl && (pairl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014 || op == BLSMI_OP_FQ12_CYCLO_RUN16)) return BLSMI_E_ARG;
     int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
     if (n && (!a || !out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
@@ -1008,7 +1043,8 @@ BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, ui
     if (b) HIPCHK(hipMemcpyAsync(db.p, b, bytes, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemsetAsync(dflag.p, 1, n, g_stream));
     dim3 g(nblocks(n)), w(WG);
-    if (quadl) hipLaunchKernelGGL(k_debug_quad, dim3(qblocks(n)), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
+    if (rowl) hipLaunchKernelGGL(k_debug_row, dim3(rblocks(n)), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
+    else if (quadl) hipLaunchKernelGGL(k_debug_quad, dim3(qblocks(n)), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
     else if (pairl) hipLaunchKernelGGL(k_debug_pairl, dim3((unsigned)((n + WG / 2 - 1) / (WG / 2))), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
     else if (op < 16) hipLaunchKernelGGL(k_debug_fq, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);
     else if (op < 32) hipLaunchKernelGGL(k_debug_fq2, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);

@@ -1,0 +1,102 @@
+// k_pairing_row.hip -- pairing kernels in the LANE-ROW layout (row_body.inc): sixteen adjacent lanes per tuple, 4 tuples per 64-lane
+// workgroup.  For the call sizes the reference's API produces -- a few thousand tuples: 4 096 tuples are 1 024 waves here, one on every
+// SIMD of the chip (lane quad: 256 waves; one tuple per wave: 4 096 waves of 3.3 x the lane-instructions).  A lane holds one Fq of an
+// Fq12 (14 words), so the kernels fit the 256-register budget of two waves per SIMD and serve up to ~10 000 tuples.
+#ifndef BLSMI_ROW_WAVES
+#define BLSMI_ROW_WAVES 2
+#endif
+#include "pairing.cuh"
+#include "device_io.cuh"
+namespace blsmi {
+namespace pairl {
+#include "row_body.inc"
+}  // namespace pairl
+}  // namespace blsmi
+
+#define KERNEL_ROW __global__ void __launch_bounds__(WG, BLSMI_ROW_WAVES)
+namespace P2 = blsmi::pairl;
+constexpr int RT = WG / 16;                                              // tuples per workgroup
+
+// the hand-off buffer between Miller loop and final exponentiation is the lane-pair kernels' (device_io.cuh: soa_store): Fq number
+// e = 2 (3 half + j) + parity of tuple t.  Pair p of a row holds the Fq2 coefficient j = p >> 1 of half p & 1.
+BLSMI_DEV int row_fq_index(int pr, int par) { return 2 * (3 * (pr & 1) + (pr >> 1)) + par; }
+BLSMI_DEV void row_store12(i32* buf, size_t n, size_t t, int pr, int par, const P2::R12& f) {
+    if (pr < 6) soa_store(buf, n, t, row_fq_index(pr, par), fp_relabel<FpS::L, FpS::V>(f.c.c));
+}
+BLSMI_DEV P2::R12 row_load12(const i32* buf, size_t n, size_t t, int pr, int par) {
+    P2::R12 f;
+    f.c = P2::fp2_tight(P2::wrap(soa_load(buf, n, t, row_fq_index(pr < 6 ? pr : 0, par))));
+    return f;
+}
+// Pairing(P, Q) = FinalExponentiation(MillerLoop) (pairing.go:132-136): the Miller value by the homogeneous steps, as k_miller1h_pair
+KERNEL_ROW k_miller1h_row(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
+    const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;                                  // all sixteen lanes of a row stay active (DPP exchanges)
+    const FpS px = load_be48(g1 + 96 * tt), py = load_be48(g1 + 96 * tt + 48);
+    const P2::Fp2S qx = P2::wrap(load_be48(g2 + 192 * tt + 48 * par)), qy = P2::wrap(load_be48(g2 + 192 * tt + 96 + 48 * par));
+    P2::R12 f;
+    P2::miller_loop_r(f, px, py, qx, qy);
+    if (t < n) row_store12(fbuf, n, t, pr, par, f);
+}
+// pairing.go:79-129 on the hand-off buffer; out = the reference's in-memory FQ12 (72 u64 per tuple).  mode 1: no exponentiation
+KERNEL_ROW k_final_exp_row(const i32* fbuf, u64* out, size_t n, int mode) {
+    const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;
+    P2::R12 f = row_load12(fbuf, n, tt, pr, par);
+    if (mode == 0) P2::final_exponentiation_r(f);
+    if (t < n && pr < 6) store_m384(out + 72 * t + 6 * row_fq_index(pr, par), f.c.c);
+}
+// CompareTwoPairings in the row layout (k_miller2_pair's arguments: strides in bytes, 0 = one broadcast record; P1 is negated here;
+// `pre`: pair 0's G2 point is the generator, read its prepared lines)
+KERNEL_ROW k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre) {
+    const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;
+    FpS px[2], py[2]; P2::Fp2S qx[2], qy[2];
+    px[0] = load_be48(p0 + sp0 * tt); py[0] = load_be48(p0 + sp0 * tt + 48);
+    qx[0] = P2::wrap(load_be48(q0 + sq0 * tt + 48 * par)); qy[0] = P2::wrap(load_be48(q0 + sq0 * tt + 96 + 48 * par));
+    px[1] = load_be48(p1 + sp1 * tt); py[1] = fp_store(fp_neg(load_be48(p1 + sp1 * tt + 48)));      // -P1
+    qx[1] = P2::wrap(load_be48(q1 + sq1 * tt + 48 * par)); qy[1] = P2::wrap(load_be48(q1 + sq1 * tt + 96 + 48 * par));
+    P2::R12 f;
+    if (pre) P2::miller_loop2_r<true>(f, px, py, qx, qy, pre);
+    else P2::miller_loop2_r<false>(f, px, py, qx, qy, nullptr);
+    if (t < n) row_store12(fbuf, n, t, pr, par, f);
+}
+KERNEL_ROW k_final_exp_is_one_row(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n) {
+    const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;
+    P2::R12 f = row_load12(fbuf, n, tt, pr, par);
+    P2::final_exponentiation_r(f);
+    const bool one = P2::r12_is_one(f);
+    if (t < n && (threadIdx.x & 15) == 0) ok[t] = (one && !(inf_flags && inf_flags[t])) ? 1 : 0;
+}
+
+// unit-level access for the parity tests (blsmi_debug_op with BLSMI_OP_LANE_ROW): records as in k_debug_pairl -- every pair of a row reads
+// the whole Fq12, keeps its coefficient, the operation runs in the row layout and pair 0 writes the reassembled result
+KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
+    const int par = threadIdx.x & 1;
+    const size_t t0 = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t t = t0 < n ? t0 : n - 1;
+    P2::Fp12S x, y;
+    FpS* cx = reinterpret_cast<FpS*>(&x); FpS* cy = reinterpret_cast<FpS*>(&y);
+    for (int j = 0; j < 6; j++) { cx[j] = load_m384(a + (size_t)6 * (12 * t + 2 * j + par)); cy[j] = b ? load_m384(b + (size_t)6 * (12 * t + 2 * j + par)) : cx[j]; }
+    const P2::R12 rx = P2::r12_from_pair(x), ry = P2::r12_from_pair(y);
+    P2::R12 r;
+    switch (op) {
+        case BLSMI_OP_FQ12_MUL: r = P2::r12_mul(rx, ry); break;
+        case BLSMI_OP_FQ12_SQR: r = P2::r12_sqr(rx); break;
+        case BLSMI_OP_FQ12_INV: r = P2::r12_inv(rx); break;
+        case BLSMI_OP_FQ12_FROB1: r = P2::r12_frob1(rx); break;
+        case BLSMI_OP_FQ12_FROB2: r = P2::r12_frob2(rx); break;
+        case BLSMI_OP_FQ12_FROB3: r = P2::r12_frob3(rx); break;
+        case BLSMI_OP_FQ12_CYCLO_SQR: r = P2::r12_cyc_sqr(rx); break;
+        default: r = P2::r12_mul_by_014(rx, P2::fp2_tight(y.c0.c0), P2::fp2_tight(y.c0.c1), P2::fp2_tight(y.c0.c2)); break;   // BLSMI_OP_FQ12_MUL_BY_014
+    }
+    const P2::Fp12S z = P2::r12_to_pair(r);
+    const FpS* cz = reinterpret_cast<const FpS*>(&z);
+    if (t0 < n && (threadIdx.x & 14) == 0)
+        for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), cz[j]);
+}

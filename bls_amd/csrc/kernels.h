@@ -6,6 +6,7 @@ using namespace blsmi;
 #define WG 64
 constexpr int PT = WG / 2;          // tuples per workgroup of the lane-pair kernels
 constexpr int QT = WG / 4;          // tuples per workgroup of the lane-quad kernels
+constexpr int RT = WG / 16;         // tuples per workgroup of the lane-row kernels
 // k_pairing_single.hip
 __global__ void k_miller1(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_miller1h(const u8* g1, const u8* g2, i32* fbuf, size_t n);
@@ -41,6 +42,12 @@ __global__ void k_miller2_quad(const u8* p0, size_t sp0, const u8* q0, size_t sq
 __global__ void k_miller1x2_quad(const u8* g1, const u8* g2, i32* fbuf, size_t n, size_t m);
 __global__ void k_final_exp_is_one_quad(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
 __global__ void k_debug_quad(int op, const u64* a, const u64* b, u64* out, size_t n);
+// k_pairing_row.hip
+__global__ void k_miller1h_row(const u8* g1, const u8* g2, i32* fbuf, size_t n);
+__global__ void k_final_exp_row(const i32* fbuf, u64* out, size_t n, int mode);
+__global__ void k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
+__global__ void k_final_exp_is_one_row(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+__global__ void k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n);
 // k_prepared_pair.hip
 __global__ void k_g2_prepare_pair(const u8* g2, i32* tables, size_t n);
 __global__ void k_prepared_export(const i32* tables, u64* out, size_t n);

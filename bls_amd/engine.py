@@ -98,6 +98,14 @@ def set_quad_threshold(max_tuples):
     _check(_lib().blsmi_set_quad_threshold(C.c_size_t(int(max_tuples))), "blsmi_set_quad_threshold")
 
 
+def set_row_threshold(min_tuples, max_tuples):
+    """A lone pairing / verify call of min_tuples .. max_tuples tuples takes the lane-row kernels (sixteen lanes per tuple); max 0 = off."""
+    _check(_lib().blsmi_set_row_threshold(C.c_size_t(int(min_tuples)), C.c_size_t(int(max_tuples))), "blsmi_set_row_threshold")
+
+
+ROW_DEFAULT = (2048, 10240)
+
+
 def set_option(name, value):
     """run-time switch between code paths with identical results: "agg_cofactor_pow", "msm_sort", "dup_force_sort" (include/blsmi.h)"""
     _check(_lib().blsmi_set_option(name.encode(), C.c_longlong(int(value))), "blsmi_set_option(%s)" % name)
@@ -700,9 +708,10 @@ def debug_hash_redo(kind, msgs, good, out, domain8=None):
 
 
 LANE_QUAD = 0x200          # BLSMI_OP_LANE_QUAD
+LANE_ROW = 0x400           # BLSMI_OP_LANE_ROW
 
 
-def debug_op(name, a, b=None, lane_pair=False, raw_flag=False, lane_quad=False):
+def debug_op(name, a, b=None, lane_pair=False, raw_flag=False, lane_quad=False, lane_row=False):
     op = OPS[name]
     width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 else (3 if op in (64, 65, 68) else 6)
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 6 * width)
@@ -714,7 +723,7 @@ def debug_op(name, a, b=None, lane_pair=False, raw_flag=False, lane_quad=False):
         b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 6 * width)
         assert b.shape == a.shape
         bp = b.ctypes.data_as(_u64p)
-    _check(_lib().blsmi_debug_op(op | (LANE_PAIR if lane_pair else 0) | (LANE_QUAD if lane_quad else 0), a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
+    _check(_lib().blsmi_debug_op(op | (LANE_PAIR if lane_pair else 0) | (LANE_QUAD if lane_quad else 0) | (LANE_ROW if lane_row else 0), a.ctypes.data_as(_u64p), bp, out.ctypes.data_as(_u64p), _p8(flag), C.c_size_t(n)), "blsmi_debug_op")
     return out, (flag.copy() if raw_flag else flag.astype(bool))
 
 

@@ -105,6 +105,11 @@ int blsmi_set_latency_threshold(size_t max_tuples);
  * tuples to fill it (16 384 pairings: 11.5 ms there).  Default 16 384 (environment BLSMI_QUAD_MAX); 0 switches the layout off.
  * Same results bit for bit on all three paths. */
 int blsmi_set_quad_threshold(size_t max_tuples);
+/* A few thousand tuples (blsmi 0.7): a LONE pairing / verify call of min_tuples .. max_tuples tuples runs in the LANE-ROW layout -- sixteen lanes (one DPP
+ * row) per tuple, 4 096 tuples = one wave on every SIMD of the chip -- instead of one tuple per wave (below) or per lane quad (above).  Default
+ * 2 048 .. 10 240 (environment BLSMI_ROW_MIN / BLSMI_ROW_MAX); max_tuples = 0 switches the layout off.  Calls that find other calls in flight on
+ * their device keep the quad kernels (see "crowd_quad" below).  Same results bit for bit on all four paths. */
+int blsmi_set_row_threshold(size_t min_tuples, size_t max_tuples);
 /* When should a lone call stay on the upstream CPU path?  A call with few elements costs the dependent depth of ONE wave walking the
  * whole computation -- about 0.7 ms for a Miller loop, 1.4 ms for a pairing, a signature or a G2 preparation, 2.0 ms for a Verify --
  * whatever n is, up to a few thousand elements.  Where one CPU core needs less than that for the whole call (BLSSign 0.45 ms,
@@ -409,6 +414,7 @@ enum blsmi_debug_op {
 };
 #define BLSMI_OP_LANE_PAIR 0x100 /* OR into an FQ2 / FQ6 / FQ12 op: run it in the lane-pair layout of the pairing kernels */
 #define BLSMI_OP_LANE_QUAD 0x200 /* OR into an FQ12 op: run it in the lane-quad layout (four lanes per tuple, k_pairing_quad.hip) */
+#define BLSMI_OP_LANE_ROW 0x400  /* OR into an FQ12 op (not CYCLO_RUN16): run it in the lane-row layout (sixteen lanes per tuple, k_pairing_row.hip) */
 int blsmi_debug_op(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, uint8_t *flag /* n, may be NULL */, size_t n);
 /* G2AffineToPrepared (g2.go:650-801) of one affine G2 point: 68 line-coefficient triples, each Fq2 as 12 LE uint64 Montgomery(2^384)
  * limbs, in Miller-loop order.  mode 0: computed by the one-tuple-per-lane doubling/addition steps; 1: by the lane-pair

@@ -1,0 +1,191 @@
+"""-m gpu: the lane-ROW layout (sixteen lanes per tuple, bls_amd/csrc/row_body.inc, k_pairing_row.hip) -- the layout for the call sizes the
+reference's API produces: a few thousand tuples (4 096 tuples = one wave per SIMD).  Every Fq12 routine op by op
+against the oracle, then Pairing and Verify on all FOUR paths (one tuple per wave / per lane row / per lane quad / per lane pair):
+bit-identical Fq12 (pairing.go:132-136, fq12.go:27-237), identical verdicts (g2pubs/bls.go:159-162, g1pubs/bls.go:165-168)."""
+import numpy as np
+import pytest
+
+from gpu_common import P, RC, pack, rand_fq, rand_g1, rand_g2, sk_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bls_amd import engine
+    engine.init(0)
+    yield engine
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384); engine.set_row_threshold(*engine.ROW_DEFAULT)
+
+
+def _rand_rec(xs, n, width):
+    return np.stack([pack(rand_fq(xs, width)) for _ in range(n)])
+
+
+def _cyclotomic(recs):
+    """x^((q^6-1)(q^2+1)) of every record, from the oracle: elements of the cyclotomic subgroup"""
+    cyc = []
+    for x in recs:
+        inv = RC.fq12_inverse(x)[1]
+        conj = x.copy().reshape(12, 6)
+        for k in range(6, 12):
+            conj[k] = RC.fq_neg(conj[k])
+        t = RC.fq12_mul(conj.reshape(-1), inv)
+        cyc.append(RC.fq12_mul(RC.fq12_frobenius(t, 2), t))
+    return np.stack(cyc)
+
+
+def test_fq12_ops_in_lane_row_layout(eng):
+    """n = 11: a ragged final workgroup (4 tuples per workgroup); values with coefficient patterns that exercise every pair of a row"""
+    xs = P.XORShift(6101)
+    n = 11
+    a12 = _rand_rec(xs, n, 12); b12 = _rand_rec(xs, n, 12)
+    # sparse operands: one non-zero Fq2 coefficient each (w^p alone), so that a wrong route between pairs cannot cancel out
+    for k in range(6):
+        a12[k] = 0; a12[k][12 * k:12 * k + 12] = pack(rand_fq(xs, 2))
+    for name, ref in [("FQ12_MUL", lambda x, y: RC.fq12_mul(x, y)), ("FQ12_SQR", lambda x, y: RC.fq12_sqr(x)), ("FQ12_INV", lambda x, y: RC.fq12_inverse(x)[1]),
+                      ("FQ12_FROB1", lambda x, y: RC.fq12_frobenius(x, 1)), ("FQ12_FROB2", lambda x, y: RC.fq12_frobenius(x, 2)), ("FQ12_FROB3", lambda x, y: RC.fq12_frobenius(x, 3))]:
+        out, _ = eng.debug_op(name, a12, b12 if name == "FQ12_MUL" else None, lane_row=True)
+        want = np.stack([ref(x, y) for x, y in zip(a12, b12)])
+        bad = [i for i in range(n) if not np.array_equal(out[i], want[i])]
+        assert not bad, (name, bad)
+    out, _ = eng.debug_op("FQ12_MUL", b12, a12, lane_row=True)             # the sparse operand on the other side
+    assert np.array_equal(out, np.stack([RC.fq12_mul(x, y) for x, y in zip(b12, a12)]))
+    # the sparse line multiplication (fq12.go:32-47): (c0, c1, c4) = b[0..5]
+    out, _ = eng.debug_op("FQ12_MUL_BY_014", a12, b12, lane_row=True)
+    want = np.stack([RC.fq12_mul_by_014(x, y[0:12], y[12:24], y[24:36]) for x, y in zip(a12, b12)])
+    assert np.array_equal(out, want)
+    cyc = _cyclotomic(b12[:9])
+    out, _ = eng.debug_op("FQ12_CYCLO_SQR", cyc, lane_row=True)
+    assert np.array_equal(out, np.stack([RC.fq12_sqr(x) for x in cyc]))
+    one = np.zeros((3, 72), dtype=np.uint64); one[:, :6] = pack([1])
+    for name in ("FQ12_CYCLO_SQR", "FQ12_SQR", "FQ12_INV", "FQ12_FROB1"):
+        out, _ = eng.debug_op(name, one, lane_row=True)
+        assert np.array_equal(out, one), name
+
+
+def test_pairing_on_the_four_paths_agrees_with_the_oracle(eng):
+    """the same tuples through the lane-row kernels at ragged sizes around their 4-tuple workgroups, and through the other three layouts:
+    the reference's generator vector (pairing_test.go:9-58) and points outside the subgroup included"""
+    from test_gpu_round3 import _torsion_points
+    xs = P.XORShift(6102)
+    g1s, g2s = _torsion_points()
+    a = [RC.g1_generator()] + [rand_g1(xs) for _ in range(20)] + g1s[:3]
+    b = [RC.g2_generator()] + [rand_g2(xs) for _ in range(20)] + g2s[:3]
+    n = len(a)
+    want = RC.pairing_batch(b"".join(a), b"".join(b), n)
+    try:
+        eng.set_row_threshold(1, 1 << 20)                                          # lane row, whatever the size
+        for m in (1, 3, 4, 5, n):
+            got = eng.pairing_batch(b"".join(a[:m]), b"".join(b[:m]), m)
+            assert np.array_equal(got, want[:m]), ("row", m)
+        eng.set_row_threshold(0, 0)
+        eng.set_latency_threshold(0); eng.set_quad_threshold(1 << 20)              # lane quad
+        assert np.array_equal(eng.pairing_batch(b"".join(a), b"".join(b), n), want)
+        eng.set_quad_threshold(0)                                                  # lane pair
+        assert np.array_equal(eng.pairing_batch(b"".join(a), b"".join(b), n), want)
+        eng.set_latency_threshold(8192)                                            # one tuple per wave
+        assert np.array_equal(eng.pairing_batch(b"".join(a), b"".join(b), n), want)
+    finally:
+        eng.set_latency_threshold(8192); eng.set_quad_threshold(16384); eng.set_row_threshold(*eng.ROW_DEFAULT)
+
+
+def _g2pubs_tuples(n, seed, every):
+    xs = P.XORShift(seed)
+    msgs, pks, sigs, expect = [], [], [], []
+    for i in range(n):
+        sk = sk_bytes(xs)
+        m = b"row layout %d" % i
+        pk, sig = RC.g2pubs.priv_to_pub(sk), RC.g2pubs.sign(m, sk)
+        good = True
+        if i % every == every - 1:
+            good = False
+            kind = (i // every) % 3
+            if kind == 0:
+                m = m + b"!"
+            elif kind == 1:
+                pk = RC.g2pubs.priv_to_pub(sk_bytes(xs))
+            else:
+                sig = sig[:48] + ((P.Q - int.from_bytes(sig[48:], "big")) % P.Q).to_bytes(48, "big")
+        msgs.append(m); pks.append(pk); sigs.append(sig); expect.append(good)
+    return msgs, pks, sigs, expect
+
+
+def _g1pubs_tuples(n, seed, every):
+    xs = P.XORShift(seed)
+    msgs, pks, sigs, expect = [], [], [], []
+    for i in range(n):
+        sk = sk_bytes(xs)
+        m = b"row layout g1pubs %d" % i
+        pk, sig = RC.g1pubs.priv_to_pub(sk), RC.g1pubs.sign(m, sk)
+        good = True
+        if i % every == every - 1:
+            good = False
+            if (i // every) % 2 == 0:
+                m = m + b"?"
+            else:
+                pk = RC.g1pubs.priv_to_pub(sk_bytes(xs))
+        msgs.append(m); pks.append(pk); sigs.append(sig); expect.append(good)
+    return msgs, pks, sigs, expect
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_verify_in_the_row_layout(eng, group):
+    """Verify of both packages forced into the row kernels (k_miller2_row with the generator's prepared lines for g2pubs, two running points
+    for g1pubs; k_final_exp_is_one_row): the oracle's verdict table, ragged sizes"""
+    msgs, pks, sigs, expect = (_g2pubs_tuples if group == "g2pubs" else _g1pubs_tuples)(13, 6103, 3)
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    assert [o.verify(m, p, s) for m, p, s in zip(msgs, pks, sigs)] == expect
+    fn = eng.g2pubs_verify_batch if group == "g2pubs" else eng.g1pubs_verify_batch
+    try:
+        eng.set_row_threshold(1, 1 << 20)
+        for m in (1, 4, 5, 13):
+            ok, _ = fn(msgs[:m], b"".join(pks[:m]), b"".join(sigs[:m]))
+            assert list(ok) == expect[:m], (group, m)
+    finally:
+        eng.set_row_threshold(*eng.ROW_DEFAULT)
+
+
+def test_row_layout_at_its_design_size(eng):
+    """4 096 pairings (1 024 waves: one per SIMD) on the DEFAULT thresholds take the row kernels: every record against the lane-pair
+    kernels' output, a spread sample against the oracle; 4 096 g2pubs verifies with a corruption schedule likewise"""
+    n = 4096
+    base = 128
+    xs = P.XORShift(6104)
+    ka = b"".join(sk_bytes(xs) for _ in range(base)); kb = b"".join(sk_bytes(xs) for _ in range(base))
+    g1b, _ = eng.g1_mul_generator_batch(ka, base); g2b, _ = eng.g2_mul_generator_batch(kb, base)
+    reps = n // base
+    g1 = np.ascontiguousarray(np.tile(g1b, (reps, 1)))
+    g2 = np.ascontiguousarray(np.concatenate([np.roll(g2b, -r, axis=0) for r in range(reps)]))
+    lib = __import__("bls_amd._native", fromlist=["load"]).load()
+    import bench
+    lib.blsmi_set_profiling(1); bench.read_profile(lib)
+    got = eng.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
+    lib.blsmi_set_profiling(0)
+    prof = bench.read_profile(lib)
+    assert "k_miller1h_row" in prof and "k_final_exp_row" in prof, prof
+    try:
+        eng.set_row_threshold(0, 0); eng.set_latency_threshold(0); eng.set_quad_threshold(0)
+        ref = eng.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
+    finally:
+        eng.set_latency_threshold(8192); eng.set_quad_threshold(16384); eng.set_row_threshold(*eng.ROW_DEFAULT)
+    bad = np.nonzero((got != ref).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    for i in (0, 1, 3, 4, 1025, n - 5, n - 1):
+        assert np.array_equal(got[i], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]), i
+    # verify: 128 signers x 32 messages each, every 7th tuple carries the wrong key
+    sks = [ka[32 * i:32 * i + 32] for i in range(base)]
+    pks, _ = eng.g2_mul_generator_batch(ka, base)
+    msgs = [b"row design size %d" % i for i in range(n)]
+    h = eng.hash_g1_batch(msgs)
+    sigs, _ = eng.g1_mul_batch(h.reshape(-1), b"".join(sks[i % base] for i in range(n)), n)
+    allpk = np.stack([pks[(i + (1 if i % 7 == 6 else 0)) % base] for i in range(n)])
+    expect = [i % 7 != 6 for i in range(n)]
+    lib.blsmi_set_profiling(1); bench.read_profile(lib)
+    ok, _ = eng.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
+    lib.blsmi_set_profiling(0)
+    prof = bench.read_profile(lib)
+    assert "k_miller2_row" in prof and "k_final_exp_is_one_row" in prof, prof
+    assert list(ok) == expect
+    for i in (0, 6, 4095):
+        assert RC.g2pubs.verify(msgs[i], allpk[i].tobytes(), sigs[i].tobytes()) == expect[i]
