@@ -305,11 +305,11 @@ inline size_t call_load(size_t n) {
     return c->load_others + g_assume_load.load(std::memory_order_relaxed);
 }
 // A fourth layout between the wave and the quad (round 6, k_pairing_row.hip): one tuple per DPP ROW of sixteen lanes.  g_row_min .. g_row_max
-// tuples of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
+// tuples (2 304 .. 8 192) of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
 // 3.3 x the instructions on the one-tuple-per-wave path).  When other calls are in flight on the device the choice above stands (the quad
 // kernels spend fewer lane-instructions per tuple: 12.6 M against 18 M).  blsmi_set_row_threshold / BLSMI_ROW_MIN / BLSMI_ROW_MAX; max 0: off.
-std::atomic<size_t> g_row_min{2048};
-std::atomic<size_t> g_row_max{10240};
+std::atomic<size_t> g_row_min{2304};   // (tools/midsize4.py: 2 048 pairings 2.26 ms either way, 3 072: 2.26 against 3.32; verifies cross at ~2 500)
+std::atomic<size_t> g_row_max{8192};   // (8 192 pairings 4.0 ms against the quad kernels' flat 5.7; 12 288: 6+ against 5.7)
 inline bool use_row(size_t n) {
     const bool crowd = g_crowd_quad.load(std::memory_order_relaxed) && n >= g_crowd_floor.load(std::memory_order_relaxed);
     const size_t others = crowd ? call_load(n) : 0;                        // (every sizeable call is counted, whatever layout it takes itself)
@@ -1031,8 +1031,10 @@ BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, ui
     const int op = op_in & ~(BLSMI_OP_LANE_PAIR | BLSMI_OP_LANE_QUAD | BLSMI_OP_LANE_ROW);
     if (pairl && (op < 16 || op >= 64)) return BLSMI_E_ARG;
     if (quadl && (pairl || rowl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014)) return BLSMI_E_ARG;
-    if (rowl && (pairl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014 || op == BLSMI_OP_FQ12_CYCLO_RUN16)) return BLSMI_E_ARG;
-    int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
+    const bool rowstep = op >= BLSMI_OP_ROW_DBL_STEP && op <= BLSMI_OP_ROW_ADD_STEP_REF;
+    if (rowstep && !rowl) return BLSMI_E_ARG;
+    if (rowl && !rowstep && (pairl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014 || op == BLSMI_OP_FQ12_CYCLO_RUN16)) return BLSMI_E_ARG;
+    int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : rowstep ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
     if (n && (!a || !out)) return BLSMI_E_ARG;
     LOCK_AND_INIT();
     if (n == 0) return BLSMI_OK;

@@ -83,6 +83,23 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
     P2::Fp12S x, y;
     FpS* cx = reinterpret_cast<FpS*>(&x); FpS* cy = reinterpret_cast<FpS*>(&y);
     for (int j = 0; j < 6; j++) { cx[j] = load_m384(a + (size_t)6 * (12 * t + 2 * j + par)); cy[j] = b ? load_m384(b + (size_t)6 * (12 * t + 2 * j + par)) : cx[j]; }
+    if (op >= BLSMI_OP_ROW_DBL_STEP && op <= BLSMI_OP_ROW_ADD_STEP_REF) {     // one Miller-loop step: (X, Y, Z, xq, yq, (xP, yP)) -> (X3, Y3, Z3, c0, c1, c4)
+        P2::G2Proj r; r.x = x.c0.c0; r.y = x.c0.c1; r.z = x.c0.c2;
+        const P2::Fp2S qx = x.c1.c0, qy = x.c1.c1;
+        const FpS px = load_m384(a + (size_t)6 * (12 * t + 10)), py = load_m384(a + (size_t)6 * (12 * t + 11));
+        P2::RLine l;
+        if (op == BLSMI_OP_ROW_DBL_STEP) P2::r_doubling_step<false>(r, P2::r_scalar(px), P2::r_scalar(py), l);
+        else if (op == BLSMI_OP_ROW_ADD_STEP) P2::r_addition_step<false>(r, qx, qy, P2::r_scalar(px), P2::r_scalar(py), l);
+        else {
+            P2::Fp2S o0, o1, o2;
+            if (op == BLSMI_OP_ROW_DBL_STEP_REF) P2::doubling_step_h(r, o0, o1, o2); else P2::addition_step_h(r, qx, qy, o0, o1, o2);
+            l.c0 = P2::fp2_tight(o2); l.c1 = P2::fp2_tight(P2::fp2_mul_fp(o1, px)); l.c4 = P2::fp2_tight(P2::fp2_mul_fp(o0, py));
+        }
+        const FpS res[6] = {r.x.c, r.y.c, r.z.c, fp_relabel<1, FpS::V>(l.c0.c), fp_relabel<1, FpS::V>(l.c1.c), fp_relabel<1, FpS::V>(l.c4.c)};
+        if (t0 < n && (threadIdx.x & 14) == 0)
+            for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), res[j]);
+        return;
+    }
     const P2::R12 rx = P2::r12_from_pair(x), ry = P2::r12_from_pair(y);
     P2::R12 r;
     switch (op) {

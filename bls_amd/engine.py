@@ -103,7 +103,7 @@ def set_row_threshold(min_tuples, max_tuples):
     _check(_lib().blsmi_set_row_threshold(C.c_size_t(int(min_tuples)), C.c_size_t(int(max_tuples))), "blsmi_set_row_threshold")
 
 
-ROW_DEFAULT = (2048, 10240)
+ROW_DEFAULT = (2304, 8192)
 
 
 def set_option(name, value):
@@ -667,7 +667,8 @@ OPS = dict(FQ_MUL=1, FQ_SQR=2, FQ_ADD=3, FQ_SUB=4, FQ_NEG=5, FQ_INV=6, FQ_SQRT=7
            FQ6_MUL=32, FQ6_SQR=33, FQ6_INV=34, FQ6_FROB1=35, FQ6_MUL_BY_1=36, FQ6_MUL_BY_01=37,
            FQ12_MUL=48, FQ12_SQR=49, FQ12_INV=50, FQ12_FROB1=51, FQ12_FROB2=52, FQ12_FROB3=53, FQ12_CYCLO_SQR=54, FQ12_CYCLO_RUN16=55,
            FQ12_MUL_BY_014=56, FQ12_MUL_BY_LINE_PAIR=57,
-           G1_DOUBLE=64, G1_ADD=65, G2_DOUBLE=66, G2_ADD=67, SWU_G1=68, SWU_G2=69)
+           G1_DOUBLE=64, G1_ADD=65, G2_DOUBLE=66, G2_ADD=67, SWU_G1=68, SWU_G2=69,
+           ROW_DBL_STEP=80, ROW_DBL_STEP_REF=81, ROW_ADD_STEP=82, ROW_ADD_STEP_REF=83)
 
 
 LANE_PAIR = 0x100
@@ -713,7 +714,7 @@ LANE_ROW = 0x400           # BLSMI_OP_LANE_ROW
 
 def debug_op(name, a, b=None, lane_pair=False, raw_flag=False, lane_quad=False, lane_row=False):
     op = OPS[name]
-    width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 else (3 if op in (64, 65, 68) else 6)
+    width = 1 if op < 16 else 2 if op < 32 else 6 if op < 48 else 12 if op < 64 or op >= 80 else (3 if op in (64, 65, 68) else 6)
     a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 6 * width)
     n = a.shape[0]
     out = np.zeros_like(a)

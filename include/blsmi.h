@@ -107,7 +107,7 @@ int blsmi_set_latency_threshold(size_t max_tuples);
 int blsmi_set_quad_threshold(size_t max_tuples);
 /* A few thousand tuples (blsmi 0.7): a LONE pairing / verify call of min_tuples .. max_tuples tuples runs in the LANE-ROW layout -- sixteen lanes (one DPP
  * row) per tuple, 4 096 tuples = one wave on every SIMD of the chip -- instead of one tuple per wave (below) or per lane quad (above).  Default
- * 2 048 .. 10 240 (environment BLSMI_ROW_MIN / BLSMI_ROW_MAX); max_tuples = 0 switches the layout off.  Calls that find other calls in flight on
+ * 2 304 .. 8 192 (environment BLSMI_ROW_MIN / BLSMI_ROW_MAX); max_tuples = 0 switches the layout off.  Calls that find other calls in flight on
  * their device keep the quad kernels (see "crowd_quad" below).  Same results bit for bit on all four paths. */
 int blsmi_set_row_threshold(size_t min_tuples, size_t max_tuples);
 /* When should a lone call stay on the upstream CPU path?  A call with few elements costs the dependent depth of ONE wave walking the
@@ -410,7 +410,10 @@ enum blsmi_debug_op {
     BLSMI_OP_FQ12_MUL = 48, BLSMI_OP_FQ12_SQR, BLSMI_OP_FQ12_INV, BLSMI_OP_FQ12_FROB1, BLSMI_OP_FQ12_FROB2, BLSMI_OP_FQ12_FROB3, BLSMI_OP_FQ12_CYCLO_SQR, BLSMI_OP_FQ12_CYCLO_RUN16 /* 16 squarings in compressed form + decompression */,
     BLSMI_OP_FQ12_MUL_BY_014 /* fq12.go:32-47, (c0, c1, c4) = b[0..5] */, BLSMI_OP_FQ12_MUL_BY_LINE_PAIR /* a * (014 element b[0..5]) * (014 element b[6..11]) through the fused two-line product */,
     BLSMI_OP_G1_DOUBLE = 64, BLSMI_OP_G1_ADD, BLSMI_OP_G2_DOUBLE, BLSMI_OP_G2_ADD,
-    BLSMI_OP_SWU_G1 = 68 /* t in word 0 of a 3-Fq record -> (x, y, 0) */, BLSMI_OP_SWU_G2 /* t in words 0-1 of a 6-Fq record -> (x, y, 0) */
+    BLSMI_OP_SWU_G1 = 68 /* t in word 0 of a 3-Fq record -> (x, y, 0) */, BLSMI_OP_SWU_G2 /* t in words 0-1 of a 6-Fq record -> (x, y, 0) */,
+    /* with BLSMI_OP_LANE_ROW only: one step of the homogeneous Miller loop on a 12-Fq record (X, Y, Z of the running point: Fq2 each; xq, yq of Q:
+     * Fq2 each; xP, yP: Fq each) -> (X3, Y3, Z3, c0, c1, c4): the new point and the line at P.  _REF: the lane-pair routine the row form restates */
+    BLSMI_OP_ROW_DBL_STEP = 80, BLSMI_OP_ROW_DBL_STEP_REF, BLSMI_OP_ROW_ADD_STEP, BLSMI_OP_ROW_ADD_STEP_REF
 };
 #define BLSMI_OP_LANE_PAIR 0x100 /* OR into an FQ2 / FQ6 / FQ12 op: run it in the lane-pair layout of the pairing kernels */
 #define BLSMI_OP_LANE_QUAD 0x200 /* OR into an FQ12 op: run it in the lane-quad layout (four lanes per tuple, k_pairing_quad.hip) */

@@ -13,7 +13,7 @@ from gpu_common import P, RC, g1_to_jac, g2_to_jac, jac1, jac2, mont, rand_g1, r
 
 pytestmark = pytest.mark.gpu
 
-PATHS = [(8192, 16384), (0, 16384), (0, 0)]      # (latency threshold, quad threshold): one tuple per wave / per lane quad / per lane pair
+PATHS = [(8192, 16384), (0, 16384), (0, 0), (-1, 16384)]      # (latency threshold, quad threshold): one tuple per wave / per lane quad / per lane pair; -1: per lane ROW (round 6)
 
 
 @pytest.fixture(scope="module")
@@ -21,7 +21,13 @@ def eng():
     from bls_amd import engine
     engine.init(0)
     yield engine
-    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384); engine.set_row_threshold(*engine.ROW_DEFAULT)
+
+
+def _set_path(eng, lat, quad):
+    """lat == -1: the lane-row kernels whatever the size; otherwise the row layout off and the thresholds as given"""
+    eng.set_row_threshold(*((1, 1 << 20) if lat < 0 else (0, 0)))
+    eng.set_latency_threshold(8192 if lat < 0 else lat); eng.set_quad_threshold(quad)
 
 
 def _u64(b):
@@ -117,7 +123,7 @@ def test_limb_images_not_below_q_read_as_zero(eng):
 @pytest.mark.parametrize("lat,quad", PATHS)
 def test_pairing_of_in_memory_points(eng, lat, quad):
     """bls.Pairing(p *G1Projective, q *G2Projective) (pairing.go:132-136): Fq12 bits identical to the affine entry point and the oracle"""
-    eng.set_latency_threshold(lat); eng.set_quad_threshold(quad)
+    _set_path(eng, lat, quad)
     xs = P.XORShift(5103)
     for n in (1, 70):
         w1 = [rand_g1(xs) for _ in range(min(n, 5))]; w2 = [rand_g2(xs) for _ in range(min(n, 5))]
@@ -157,7 +163,7 @@ def _tuples(group, n, xs, domain=None):
 def test_verify_batch_of_in_memory_points(eng, group, lat, quad):
     """Verify x n (g2pubs/bls.go:159-162, g1pubs/bls.go:165-174) over random representatives: verdicts equal to the affine entry point's and
     to the oracle's; a key or signature with z = 0 gives False (the reference panics in MillerLoop)."""
-    eng.set_latency_threshold(lat); eng.set_quad_threshold(quad)
+    _set_path(eng, lat, quad)
     xs = P.XORShift(5104 + len(group))
     domain = b"\x01\x02\x03\x04\x05\x06\x07\x08" if group.endswith("domain") else None
     pkg = "g2pubs" if group == "g2pubs" else "g1pubs"
@@ -190,7 +196,7 @@ def test_verify_batch_of_in_memory_points(eng, group, lat, quad):
 def test_verify_aggregate_of_in_memory_points(eng, group, lat, quad):
     """Signature.VerifyAggregate (g2pubs/bls.go:240-270, g1pubs/bls.go:252-282, :300-311): true aggregate, a wrong key, a duplicate
     message, a key with z = 0, an aggregate signature with z = 0, n = 0"""
-    eng.set_latency_threshold(lat); eng.set_quad_threshold(quad)
+    _set_path(eng, lat, quad)
     xs = P.XORShift(5110 + len(group))
     domain = b"\x09\x08\x07\x06\x05\x04\x03\x02" if group.endswith("domain") else None
     pkg = "g2pubs" if group == "g2pubs" else "g1pubs"

@@ -9,17 +9,18 @@ from gpu_common import P, RC, mont, rand_g1, rand_g2, unmont
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["latency-path", "lane-quad", "lane-pair"])
+@pytest.fixture(scope="module", params=["latency-path", "lane-row", "lane-quad", "lane-pair"])
 def eng(request):
-    """Every test of this module runs three times: small batches through the latency path (one tuple per wave, k_lat.hip), through the
+    """Every test of this module runs four times: small batches through the latency path (one tuple per wave, k_lat.hip), through the
     lane-quad kernels (the mid-size layout) and through the lane-pair kernels (the full-chip layout)."""
     from bls_amd import engine
     engine.init(0)
-    # three paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
-    engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
+    # four paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
+    engine.set_latency_threshold(8192 if request.param in ("latency-path", "lane-row") else 0)
     engine.set_quad_threshold(0 if request.param == "lane-pair" else 16384)
+    engine.set_row_threshold(*((1, 1 << 20) if request.param == "lane-row" else (0, 0)))   # round 6: sixteen lanes per tuple (k_pairing_row.hip), whatever the size
     yield engine
-    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384); engine.set_row_threshold(*engine.ROW_DEFAULT)
 
 
 def test_pairing_generator_kat(eng, kats):

@@ -34,8 +34,9 @@ def eng(request):
     # three paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
     engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
     engine.set_quad_threshold(0 if request.param == "lane-pair" else 16384)
+    engine.set_row_threshold(0, 0)                                         # (the lane-row layout has its own module, tests/test_gpu_row.py, and the fixtures of test_gpu_pairing / verify / prepared / jac)
     yield engine
-    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384); engine.set_row_threshold(*engine.ROW_DEFAULT)
 
 
 def _g2pubs_tuples(n, seed, every):
@@ -373,11 +374,15 @@ def test_latency_and_throughput_paths_agree_on_4096_tuples():
     g1b, _ = engine.g1_mul_batch(RC.g1_generator() * base, k1, base); g2b, _ = engine.g2_mul_batch(RC.g2_generator() * base, k2, base)
     g1 = np.tile(g1b, (n // base, 1)); g2 = np.concatenate([np.roll(g2b, -r, axis=0) for r in range(n // base)])
     try:
+        engine.set_row_threshold(0, 0)                                           # (4 096 tuples is the lane-row layout's size since round 6: third leg below)
         engine.set_latency_threshold(8192)
         a = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
         engine.set_latency_threshold(0)
         b = engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
         assert np.array_equal(a, b)
+        engine.set_row_threshold(*engine.ROW_DEFAULT); engine.set_latency_threshold(8192)
+        assert np.array_equal(engine.pairing_batch(g1.reshape(-1), g2.reshape(-1), n), a)
+        engine.set_row_threshold(0, 0)
         assert np.array_equal(a[4095], RC.pairing_batch(g1[4095].tobytes(), g2[4095].tobytes(), 1)[0])
         # verify: 64 signers x 64 messages, every 7th tuple carries the wrong key
         sks = [k1[32 * i:32 * i + 32] for i in range(base)]
@@ -392,8 +397,11 @@ def test_latency_and_throughput_paths_agree_on_4096_tuples():
         engine.set_latency_threshold(0)
         ok_thr, _ = engine.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
         assert list(ok_lat) == expect and list(ok_thr) == expect
+        engine.set_row_threshold(*engine.ROW_DEFAULT); engine.set_latency_threshold(8192)
+        ok_row, _ = engine.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
+        assert list(ok_row) == expect
     finally:
-        engine.set_latency_threshold(8192)
+        engine.set_latency_threshold(8192); engine.set_row_threshold(*engine.ROW_DEFAULT)
 
 
 # ---- in-library multi-device split -----------------------------------------------------------------------------------------

@@ -34,8 +34,9 @@ def eng(request):
     # three paths, same results: one tuple per wave (k_lat.hip) / per lane quad (k_pairing_quad.hip) / per lane pair
     engine.set_latency_threshold(8192 if request.param == "latency-path" else 0)
     engine.set_quad_threshold(0 if request.param == "lane-pair" else 16384)
+    engine.set_row_threshold(0, 0)                                         # (the lane-row layout has its own module, tests/test_gpu_row.py, and the fixtures of test_gpu_pairing / verify / prepared / jac)
     yield engine
-    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384)
+    engine.set_latency_threshold(8192); engine.set_quad_threshold(16384); engine.set_row_threshold(*engine.ROW_DEFAULT)
 
 
 def _dev(x):

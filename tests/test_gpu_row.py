@@ -64,6 +64,19 @@ def test_fq12_ops_in_lane_row_layout(eng):
         assert np.array_equal(out, one), name
 
 
+def test_miller_loop_steps_in_lane_row_layout(eng):
+    """one doubling step and one mixed addition step of the homogeneous Miller loop (pairing_body.inc: doubling_step_h_i, addition_step_h) on random
+    projective points: the row form (two / four product times over the eight pairs) against the lane-pair routine run by every pair alike --
+    same new point, same line at P, canonical bits"""
+    xs = P.XORShift(6105)
+    recs = _rand_rec(xs, 9, 12)                                            # (X, Y, Z, xq, yq, xP | yP): any field elements do, the formulas are polynomial
+    for name in ("ROW_DBL_STEP", "ROW_ADD_STEP"):
+        got, _ = eng.debug_op(name, recs, lane_row=True)
+        ref, _ = eng.debug_op(name + "_REF", recs, lane_row=True)
+        bad = [what for k, what in enumerate(("X3", "Y3", "Z3", "c0", "c1", "c4")) if not np.array_equal(got[:, 12 * k:12 * k + 12], ref[:, 12 * k:12 * k + 12])]
+        assert not bad, (name, bad)
+
+
 def test_pairing_on_the_four_paths_agrees_with_the_oracle(eng):
     """the same tuples through the lane-row kernels at ragged sizes around their 4-tuple workgroups, and through the other three layouts:
     the reference's generator vector (pairing_test.go:9-58) and points outside the subgroup included"""
