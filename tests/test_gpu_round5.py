@@ -133,7 +133,7 @@ def test_uncleared_hash_path_flags_cancelling_map_points(eng):
 @pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
 def test_layout_follows_the_load_of_the_device(eng, group):
     """blsmi 0.6: the layout of a mid-size call goes by what its DEVICE carries (blsmi.hip: call_load / use_quad; tools/midsize_concurrency.py) --
-    a call of >= crowd_floor tuples takes the lane-quad kernels when other calls' tuples are in flight, the one-tuple-per-wave path when it is alone.
+    a call of >= crowd_floor tuples takes the lane-quad kernels when other calls' tuples are in flight; alone it takes the lane-row kernels (round 6; the one-tuple-per-wave path below 2 304 tuples).
     Same verdicts (and the same Fq12 bits for Pairing) on either; "assume_load" stands in for the other callers; calls below the floor never move."""
     import ctypes
     from test_gpu_verify import _tuples
@@ -155,10 +155,10 @@ def test_layout_follows_the_load_of_the_device(eng, group):
         return r, buf.value.decode()
     try:
         (ok, _), prof = call(lambda: fn(M, A, B))
-        assert list(ok) == want and "k_lat:verify" in prof and "quad" not in prof, prof
+        assert list(ok) == want and "k_miller2_row" in prof and "quad" not in prof, prof      # alone: the lane-row layout since round 6 (2 304 .. 8 192 tuples; the wave path below)
         eng.set_option("assume_load", 4000)
         (ok, _), prof = call(lambda: fn(M, A, B))
-        assert list(ok) == want and "quad" in prof and "k_lat:verify" not in prof and "k_lat:hashfin" not in prof, prof
+        assert list(ok) == want and "quad" in prof and "_row" not in prof and "k_lat:verify" not in prof and "k_lat:hashfin" not in prof, prof
         eng.set_option("crowd_quad", 0)
         (ok, _), prof = call(lambda: fn(M, A, B))
         assert list(ok) == want and "quad" not in prof, prof
@@ -172,10 +172,14 @@ def test_layout_follows_the_load_of_the_device(eng, group):
             assert "k_miller1h_quad" in prof, prof
             eng.set_option("assume_load", 0)
             alone, prof = call(lambda: eng.pairing_batch(g1, g2, n))
-            assert "k_lat:pairing1" in prof and np.array_equal(crowded, alone), prof
+            assert "k_miller1h_row" in prof and np.array_equal(crowded, alone), prof
+            eng.set_row_threshold(0, 0)                                         # without the row layout: the wave path, as before round 6
+            wave, prof = call(lambda: eng.pairing_batch(g1, g2, n))
+            assert "k_lat:pairing1" in prof and np.array_equal(wave, alone), prof
+            eng.set_row_threshold(*eng.ROW_DEFAULT)
             assert alone[7].tobytes() == RC.pairing_batch(g1[96 * 7:96 * 8].tobytes(), g2[192 * 7:192 * 8].tobytes(), 1).tobytes()
     finally:
-        eng.set_option("assume_load", 0); eng.set_option("crowd_quad", 1)
+        eng.set_option("assume_load", 0); eng.set_option("crowd_quad", 1); eng.set_row_threshold(*eng.ROW_DEFAULT)
     # concurrent callers: the load is taken off the device when a call ends (nothing left behind for the next lone caller)
     import threading
     errs = []
