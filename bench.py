@@ -640,9 +640,10 @@ def verify_bench(E, steps=5, warmup=2, n=65536):
 
 def mid_bench(E, steps=5, warmup=2):
     """Batches between the latency hand-over and a full chip (the reference's API is one tuple per call and its aggregate benchmarks use
-    128 signers, g1pubs/verify_benchmark_test.go:33-85: real batches are not 65 536 tuples): pairings at 8 192 / 16 384 / 32 768 and
-    g2pubs / g1pubs verifies at 16 384, inputs resident, on the library's own choice of layout (one tuple per wave up to ~6 600 tuples,
-    per lane QUAD up to 16 384, per lane pair beyond); every size's first 16 rows re-checked against the oracle."""
+    128 signers, g1pubs/verify_benchmark_test.go:33-85: real batches are not 65 536 tuples): pairings at 2 048 / 4 096 / 8 192 / 16 384 /
+    32 768 and g2pubs / g1pubs verifies at 4 096 and 16 384, inputs resident, on the library's own choice of layout (one tuple per wave below
+    2 304 tuples, per lane ROW -- round 6 -- up to 8 192, per lane QUAD up to 16 384, per lane pair beyond); every size's first 16 rows re-checked
+    against the oracle."""
     import torch
     from oracle import refcpu as RC
     engine, dev = E.engine, E.dev
@@ -651,25 +652,28 @@ def mid_bench(E, steps=5, warmup=2):
     d1 = torch.from_numpy(g1).to(dev); d2 = torch.from_numpy(g2).to(dev); do = torch.zeros((nmax, 72), dtype=torch.int64, device=dev)
     want = RC.pairing_batch(g1[:16].tobytes(), g2[:16].tobytes(), 16)
     out = {"steps": steps, "pairings_per_s": {}, "pairing_ms": {}, "pairing_kernels": {}, "verifies_per_s": {}, "verify_ms": {}}
-    for n in (8192, 16384, 32768):
+    for n in (2048, 4096, 8192, 16384, 32768):
         def step():
             engine.pairing_batch_dev(d1.data_ptr(), d2.data_ptr(), do.data_ptr(), n)
         dt = timed_steps(E, step, steps, warmup)
         assert np.array_equal(do[:16].cpu().numpy().view(np.uint64), want), "mid-size pairings differ from the oracle at n = %d" % n
         out["pairings_per_s"][str(n)] = round(n * steps / dt, 1); out["pairing_ms"][str(n)] = round(dt / steps * 1e3, 3)
         out["pairing_kernels"][str(n)] = {k: round(v[0], 3) for k, v in profiled(E.lib, step).items() if not k.startswith("(")}
-    n = 16384
+    nv = 16384
+    out["verify_kernels"] = {}
     for group in ("g2pubs", "g1pubs"):
-        packed, pks, sigs = _verify_tuples(engine, group, n, tag=11)
+        packed, pks, sigs = _verify_tuples(engine, group, nv, tag=11)
         d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (packed.buf.copy(), packed.off.view(np.int64), pks, sigs)]
-        d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
-
-        def vstep():
-            engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
-        dt = timed_steps(E, vstep, steps, warmup)
-        assert bool(d_ok.all().item())
-        out["verifies_per_s"][group + "@16384"] = round(n * steps / dt, 1); out["verify_ms"][group + "@16384"] = round(dt / steps * 1e3, 3)
-    out["note"] = "round 3 (lane-pair kernels only): 16 384 pairings 11.6 ms (1.41 M/s), 32 768 12.6 ms; g2pubs verifies at 16 384 16.9 ms"
+        d_ok = torch.zeros(nv, dtype=torch.uint8, device=dev)
+        for n in (4096, nv):                                                # (the first n tuples of the same buffers: offsets are prefix sums)
+            def vstep():
+                engine.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
+            d_ok.zero_()
+            dt = timed_steps(E, vstep, steps, warmup)
+            assert bool(d_ok[:n].all().item())
+            out["verifies_per_s"]["%s@%d" % (group, n)] = round(n * steps / dt, 1); out["verify_ms"]["%s@%d" % (group, n)] = round(dt / steps * 1e3, 3)
+            out["verify_kernels"]["%s@%d" % (group, n)] = {k: round(v[0], 3) for k, v in profiled(E.lib, vstep).items() if not k.startswith("(")}
+    out["note"] = "round 3 (lane-pair kernels only): 16 384 pairings 11.6 ms (1.41 M/s), 32 768 12.6 ms; g2pubs verifies at 16 384 16.9 ms.  round 5 (no lane-row layout): 4 096 pairings 4.18 ms, 2 048: 2.49 ms, 4 096 g2pubs verifies 6.76 ms"
     return out
 
 
