@@ -308,6 +308,7 @@ inline size_t call_load(size_t n) {
 // tuples (2 304 .. 8 192) of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
 // 3.3 x the instructions on the one-tuple-per-wave path).  When other calls are in flight on the device the choice above stands (the quad
 // kernels spend fewer lane-instructions per tuple: 12.6 M against 18 M).  blsmi_set_row_threshold / BLSMI_ROW_MIN / BLSMI_ROW_MAX; max 0: off.
+std::atomic<bool> g_row_side{true};     // BLSMI_ROW_SIDE / blsmi_set_option("row_side"): a Verify in the row layout runs its signature side beside the hash (verify_host.inc)
 std::atomic<size_t> g_row_min{2304};   // (tools/midsize4.py: 2 048 pairings 2.26 ms either way, 3 072: 2.26 against 3.32; verifies cross at ~2 500)
 std::atomic<size_t> g_row_max{8192};   // (8 192 pairings 4.0 ms against the quad kernels' flat 5.7; 12 288: 6+ against 5.7)
 inline bool use_row(size_t n) {
@@ -400,6 +401,7 @@ int ensure_init_list(const int* devs, int ndev) {
     if (const char* v = getenv("BLSMI_QUAD_MIN")) g_quad_min = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_ROW_MIN")) g_row_min = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_ROW_MAX")) g_row_max = (size_t)strtoull(v, nullptr, 10);
+    { const char* v = getenv("BLSMI_ROW_SIDE"); g_row_side = !(v && v[0] == '0'); }
     if (const char* v = getenv("BLSMI_ARENA_KEEP_MB")) g_arena_keep = (size_t)strtoull(v, nullptr, 10) << 20;
     if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
@@ -900,6 +902,7 @@ BLSMI_API int blsmi_set_option(const char* name, long long value) {
     else if (n == "dup_force_sort") g_dup_force_sort.store(value != 0);
     else if (n == "lat_rolled") g_lat_rolled.store(value != 0);
     else if (n == "crowd_quad") g_crowd_quad.store(value != 0);
+    else if (n == "row_side") g_row_side.store(value != 0);
     else if (n == "combine_mid_max") g_combine_mid_max.store((size_t)std::max(0LL, value));
     else if (n == "crowd_floor") g_crowd_floor.store((size_t)std::max(0LL, value));
     else if (n == "assume_load") g_assume_load.store((size_t)std::max(0LL, value));

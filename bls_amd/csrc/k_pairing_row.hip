@@ -64,6 +64,35 @@ KERNEL_ROW k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0, con
     else P2::miller_loop2_r<false>(f, px, py, qx, qy, nullptr);
     if (t < n) row_store12(fbuf, n, t, pr, par, f);
 }
+// A Verify in two Miller loops (verify_host.inc: verify_sig_side_start): the SIGNATURE side -- e(sig, G2One) for g2pubs, e(G1One, sig) for g1pubs --
+// needs nothing of the message, so it runs on a side stream while the message is hashed (k_miller1s_row; strides in bytes, 0 = one broadcast
+// record; `pre`: Q is the generator, its prepared lines), and the other pair's loop multiplies its value into the first one's (k_miller1m_row;
+// P is negated there, as in k_miller2_row).  The product of the two Miller values is the two-pair loop's value up to nothing: each loop squares its
+// own accumulator, (f_a f_b) is what the shared squarings compute.
+KERNEL_ROW k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n, const i32* pre) {
+    const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;
+    const FpS px = load_be48(p + sp * tt), py = load_be48(p + sp * tt + 48);
+    P2::R12 f;
+    if (pre) P2::miller_loop_table_r(f, px, py, pre);
+    else {
+        const P2::Fp2S qx = P2::wrap(load_be48(q + sq * tt + 48 * par)), qy = P2::wrap(load_be48(q + sq * tt + 96 + 48 * par));
+        P2::miller_loop_r(f, px, py, qx, qy);
+    }
+    if (t < n) row_store12(fbuf, n, t, pr, par, f);
+}
+KERNEL_ROW k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n) {
+    const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;
+    const FpS px = load_be48(p + sp * tt), py = fp_store(fp_neg(load_be48(p + sp * tt + 48)));       // -P
+    const P2::Fp2S qx = P2::wrap(load_be48(q + sq * tt + 48 * par)), qy = P2::wrap(load_be48(q + sq * tt + 96 + 48 * par));
+    P2::R12 f;
+    P2::miller_loop_r(f, px, py, qx, qy);
+    f = P2::r12_mul(f, row_load12(fbuf, n, tt, pr, par));
+    if (t < n) row_store12(fbuf, n, t, pr, par, f);
+}
 KERNEL_ROW k_final_exp_is_one_row(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n) {
     const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
     const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);

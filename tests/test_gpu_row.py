@@ -142,21 +142,23 @@ def _g1pubs_tuples(n, seed, every):
     return msgs, pks, sigs, expect
 
 
+@pytest.mark.parametrize("side", [1, 0])
 @pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
-def test_verify_in_the_row_layout(eng, group):
-    """Verify of both packages forced into the row kernels (k_miller2_row with the generator's prepared lines for g2pubs, two running points
-    for g1pubs; k_final_exp_is_one_row): the oracle's verdict table, ragged sizes"""
+def test_verify_in_the_row_layout(eng, group, side):
+    """Verify of both packages forced into the row kernels: the oracle's verdict table, ragged sizes.  g2pubs: one two-pair loop with the
+    generator's prepared lines (k_miller2_row).  g1pubs, side = 1 (the default): the signature side's Miller loop on a side stream beside the
+    hash (k_miller1s_row), then k_miller1m_row times that value; side = 0: the two-pair loop.  k_final_exp_is_one_row either way"""
     msgs, pks, sigs, expect = (_g2pubs_tuples if group == "g2pubs" else _g1pubs_tuples)(13, 6103, 3)
     o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
     assert [o.verify(m, p, s) for m, p, s in zip(msgs, pks, sigs)] == expect
     fn = eng.g2pubs_verify_batch if group == "g2pubs" else eng.g1pubs_verify_batch
     try:
-        eng.set_row_threshold(1, 1 << 20)
+        eng.set_row_threshold(1, 1 << 20); eng.set_option("row_side", side)
         for m in (1, 4, 5, 13):
             ok, _ = fn(msgs[:m], b"".join(pks[:m]), b"".join(sigs[:m]))
-            assert list(ok) == expect[:m], (group, m)
+            assert list(ok) == expect[:m], (group, m, side)
     finally:
-        eng.set_row_threshold(*eng.ROW_DEFAULT)
+        eng.set_row_threshold(*eng.ROW_DEFAULT); eng.set_option("row_side", 1)
 
 
 def test_row_layout_at_its_design_size(eng):

@@ -16,7 +16,9 @@ sizes = [int(x) for x in sys.argv[1:]] or [1024, 2048, 3072, 4096, 6144, 8192, 1
 N = max(N, max(sizes))
 g1, g2 = bench.synth_inputs(E, N, seed=5)
 d1 = torch.from_numpy(g1).to(dev); d2 = torch.from_numpy(g2).to(dev); do = torch.zeros((N, 72), dtype=torch.int64, device=dev)
-LAYOUTS = (("wave", 1 << 20, 0, (0, 0)), ("row", 0, 0, (1, 1 << 20)), ("quad", 0, 1 << 20, (0, 0)), ("pair", 0, 0, (0, 0)))
+LAYOUTS = (("wave", 1 << 20, 0, (0, 0)), ("row", 8192, 16384, (1, 1 << 20)), ("quad", 0, 1 << 20, (0, 0)), ("pair", 0, 0, (0, 0)))
+if os.environ.get("MIDSIZE_ROW_ONLY"):
+    LAYOUTS = LAYOUTS[:2]
 
 
 def timed(step, reps=5):
@@ -48,10 +50,10 @@ for group in ("g2pubs", "g1pubs"):
     d_ok = torch.zeros(nmax, dtype=torch.uint8, device=dev)
     for n in sizes:
         row = []
-        for name, lat, quad, rw in LAYOUTS:
+        for name, lat, quad, rw in LAYOUTS + (("row-noside", 8192, 16384, (1, 1 << 20)),):
             if name == "wave" and n > 8192:
                 continue
-            E.set_latency_threshold(lat); E.set_quad_threshold(quad); E.set_row_threshold(*rw)
+            E.set_latency_threshold(lat); E.set_quad_threshold(quad); E.set_row_threshold(*rw); E.set_option("row_side", 0 if name == "row-noside" else 1)
             def step():
                 E.verify_batch_dev(group, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
             best = timed(step)
