@@ -106,6 +106,14 @@ struct Arena {
         blocks.push_back({(char*)q, want, bytes});
         return q;
     }
+    // mark / rewind: give back what an abandoned attempt allocated since the mark (the MSM's sort buffers, when not all four fit -- the
+    // fallback's index buffer may need exactly that memory).  Blocks created after the mark go back to the driver, earlier ones to their fill level.
+    struct Mark { std::vector<size_t> used; };
+    Mark mark() const { Mark m; for (const auto& b : blocks) m.used.push_back(b.used); return m; }
+    void rewind(const Mark& m) {
+        while (blocks.size() > m.used.size()) { (void)hipFree(blocks.back().p); blocks.pop_back(); }
+        for (size_t i = 0; i < blocks.size(); i++) blocks[i].used = m.used[i];
+    }
     void reset() {                                                         // caller: the context's previous call has completed
         if (blocks.size() > MAX_BLOCKS) {                                  // many differently-shaped calls: start over with one block of the total
             size_t total = 0;
@@ -355,6 +363,13 @@ std::atomic<bool> g_msm_sort{true};            // BLSMI_MSM_SORT / blsmi_set_opt
 std::atomic<bool> g_lat_rolled{true};          // BLSMI_LAT_ROLLED / blsmi_set_option("lat_rolled"): 0 = small Pairing calls take the STRAIGHT-LINE copy of their level program (pairing1s) instead of the one with rolled squaring runs (A/B)
 std::atomic<size_t> g_combine_mid_max{8192};  // BLSMI_COMBINE_MID_MAX / blsmi_set_option("combine_mid_max"): concurrent Verify calls of BLSMI_COMBINE_MAX <= n < this many tuples merge into one launch (verify_host.inc); 0: never
 std::atomic<bool> g_dup_force_sort{false};     // BLSMI_DUP_FORCE_SORT / blsmi_set_option("dup_force_sort"): test hook, the duplicate screen's fallback on every call
+// Options a caller has set through the API (blsmi_set_option, blsmi_set_*_threshold, blsmi_set_mul_assume_subgroup) keep their values when the library
+// (re-)initialises: the environment and the defaults apply only to what was never set explicitly (a set_option before the first entry point,
+// or before a re-initialisation after blsmi_shutdown, was silently overwritten here).
+enum { X_AGG_POW, X_MSM_SORT, X_DUP_SORT, X_LAT_ROLLED, X_CROWD_QUAD, X_COMBINE_MID, X_CROWD_FLOOR, X_ROW_SIDE, X_LAT_MAX, X_QUAD_MAX, X_ROW, X_MUL_SUBGROUP };
+std::atomic<unsigned> g_explicit{0};
+inline void set_explicit(int bit) { g_explicit.fetch_or(1u << bit, std::memory_order_relaxed); }
+inline bool is_explicit(int bit) { return (g_explicit.load(std::memory_order_relaxed) >> bit) & 1u; }
 void load_env() {                       // caller holds g_mu; runs once per initialisation
     auto num = [](const char* name, size_t dflt) { const char* v = getenv(name); return v ? (size_t)strtoull(v, nullptr, 10) : dflt; };
     auto flag = [](const char* name, bool dflt) { const char* v = getenv(name); return v ? atoi(v) != 0 : dflt; };
@@ -368,17 +383,17 @@ void load_env() {                       // caller holds g_mu; runs once per init
     g_env.fixed_wave_max = num("BLSMI_FIXED_WAVE_MAX", 2048);
     g_env.msm_bucket_min = num("BLSMI_MSM_BUCKET_MIN", (size_t)1 << 17);
     g_env.combine_max = num("BLSMI_COMBINE_MAX", 1024);
-    g_combine_mid_max = num("BLSMI_COMBINE_MID_MAX", 8192);
+    if (!is_explicit(X_COMBINE_MID)) g_combine_mid_max = num("BLSMI_COMBINE_MID_MAX", 8192);
     g_env.combine_wait_us = (int)num("BLSMI_COMBINE_WAIT_US", 150);
     g_env.combine_inflight_max = std::max(1, (int)num("BLSMI_COMBINE_INFLIGHT", 2));
     g_env.combine_debug = getenv("BLSMI_COMBINE_DEBUG") != nullptr;
     { const char* v = getenv("BLSMI_RCCL_PATH"); snprintf(g_env.rccl_path, sizeof g_env.rccl_path, "%s", v ? v : ""); }
-    { const char* v = getenv("BLSMI_AGG_COFACTOR_POW"); g_agg_cofactor_pow = !(v && v[0] == '0'); }
-    { const char* v = getenv("BLSMI_MSM_SORT"); g_msm_sort = !(v && v[0] == '0'); }
-    g_dup_force_sort = getenv("BLSMI_DUP_FORCE_SORT") != nullptr;
-    { const char* v = getenv("BLSMI_LAT_ROLLED"); g_lat_rolled = !(v && v[0] == '0'); }
-    { const char* v = getenv("BLSMI_CROWD_QUAD"); g_crowd_quad = !(v && v[0] == '0'); }
-    if (const char* v = getenv("BLSMI_CROWD_FLOOR")) g_crowd_floor = (size_t)strtoull(v, nullptr, 10);
+    if (!is_explicit(X_AGG_POW)) { const char* v = getenv("BLSMI_AGG_COFACTOR_POW"); g_agg_cofactor_pow = !(v && v[0] == '0'); }
+    if (!is_explicit(X_MSM_SORT)) { const char* v = getenv("BLSMI_MSM_SORT"); g_msm_sort = !(v && v[0] == '0'); }
+    if (!is_explicit(X_DUP_SORT)) g_dup_force_sort = getenv("BLSMI_DUP_FORCE_SORT") != nullptr;
+    if (!is_explicit(X_LAT_ROLLED)) { const char* v = getenv("BLSMI_LAT_ROLLED"); g_lat_rolled = !(v && v[0] == '0'); }
+    if (!is_explicit(X_CROWD_QUAD)) { const char* v = getenv("BLSMI_CROWD_QUAD"); g_crowd_quad = !(v && v[0] == '0'); }
+    if (!is_explicit(X_CROWD_FLOOR)) if (const char* v = getenv("BLSMI_CROWD_FLOOR")) g_crowd_floor = (size_t)strtoull(v, nullptr, 10);
 }
 // devs[0..ndev): HIP ordinals.  Caller holds g_mu.
 int ensure_init_list(const int* devs, int ndev) {
@@ -396,14 +411,16 @@ int ensure_init_list(const int* devs, int ndev) {
     if (const char* ns = getenv("BLSMI_STREAMS")) { int v = atoi(ns); g_nctx = v < 1 ? 1 : (v > MAX_CTX ? MAX_CTX : v); }
     const char* gl = getenv("BLSMI_GEN_LINES");
     g_use_gen_lines = !(gl && std::string(gl) == "0");
-    if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
-    if (const char* v = getenv("BLSMI_QUAD_MAX")) g_quad_max = (size_t)strtoull(v, nullptr, 10);
+    if (!is_explicit(X_LAT_MAX)) if (const char* v = getenv("BLSMI_LAT_MAX")) g_lat_max = (size_t)strtoull(v, nullptr, 10);
+    if (!is_explicit(X_QUAD_MAX)) if (const char* v = getenv("BLSMI_QUAD_MAX")) g_quad_max = (size_t)strtoull(v, nullptr, 10);
     if (const char* v = getenv("BLSMI_QUAD_MIN")) g_quad_min = (size_t)strtoull(v, nullptr, 10);
-    if (const char* v = getenv("BLSMI_ROW_MIN")) g_row_min = (size_t)strtoull(v, nullptr, 10);
-    if (const char* v = getenv("BLSMI_ROW_MAX")) g_row_max = (size_t)strtoull(v, nullptr, 10);
-    { const char* v = getenv("BLSMI_ROW_SIDE"); g_row_side = !(v && v[0] == '0'); }
+    if (!is_explicit(X_ROW)) {
+        if (const char* v = getenv("BLSMI_ROW_MIN")) g_row_min = (size_t)strtoull(v, nullptr, 10);
+        if (const char* v = getenv("BLSMI_ROW_MAX")) g_row_max = (size_t)strtoull(v, nullptr, 10);
+    }
+    if (!is_explicit(X_ROW_SIDE)) { const char* v = getenv("BLSMI_ROW_SIDE"); g_row_side = !(v && v[0] == '0'); }
     if (const char* v = getenv("BLSMI_ARENA_KEEP_MB")) g_arena_keep = (size_t)strtoull(v, nullptr, 10) << 20;
-    if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
+    if (!is_explicit(X_MUL_SUBGROUP)) if (const char* v = getenv("BLSMI_MUL_GENERIC")) g_mul_subgroup = std::string(v) == "0";
     g_force_rccl = getenv("BLSMI_FORCE_RCCL") != nullptr && std::string(getenv("BLSMI_FORCE_RCCL")) != "0";
     for (int i = 0; i < ndev; i++) {
         g_dev[i].id = devs[i]; g_dev[i].index = i; g_dev[i].leases = 0;
@@ -854,6 +871,7 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
 // last call) with blsmi_last_kernel_ms.
 // Batches of at most `max_tuples` tuples take the latency path (one tuple per wave, k_lat.hip); 0 switches it off.
 BLSMI_API int blsmi_set_latency_threshold(size_t max_tuples) {
+    set_explicit(X_LAT_MAX);
     g_lat_max.store(max_tuples);
     return BLSMI_OK;
 }
@@ -878,15 +896,18 @@ BLSMI_API int blsmi_prefer_cpu(int shape, size_t n) {
     return (double)n * rows[shape].cpu_ms_per_op < rows[shape].gpu_ms_lone_call ? 1 : 0;
 }
 BLSMI_API int blsmi_set_quad_threshold(size_t max_tuples) {
+    set_explicit(X_QUAD_MAX);
     g_quad_max.store(max_tuples);
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_set_row_threshold(size_t min_tuples, size_t max_tuples) {
+    set_explicit(X_ROW);
     g_row_min.store(min_tuples);
     g_row_max.store(max_tuples);
     return BLSMI_OK;
 }
 BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
+    set_explicit(X_MUL_SUBGROUP);
     g_mul_subgroup.store(on != 0);
     return BLSMI_OK;
 }
@@ -897,14 +918,14 @@ BLSMI_API int blsmi_set_mul_assume_subgroup(int on) {
 BLSMI_API int blsmi_set_option(const char* name, long long value) {
     if (!name) return BLSMI_E_ARG;
     const std::string n(name);
-    if (n == "agg_cofactor_pow") g_agg_cofactor_pow.store(value != 0);
-    else if (n == "msm_sort") g_msm_sort.store(value != 0);
-    else if (n == "dup_force_sort") g_dup_force_sort.store(value != 0);
-    else if (n == "lat_rolled") g_lat_rolled.store(value != 0);
-    else if (n == "crowd_quad") g_crowd_quad.store(value != 0);
-    else if (n == "row_side") g_row_side.store(value != 0);
-    else if (n == "combine_mid_max") g_combine_mid_max.store((size_t)std::max(0LL, value));
-    else if (n == "crowd_floor") g_crowd_floor.store((size_t)std::max(0LL, value));
+    if (n == "agg_cofactor_pow") { set_explicit(X_AGG_POW); g_agg_cofactor_pow.store(value != 0); }
+    else if (n == "msm_sort") { set_explicit(X_MSM_SORT); g_msm_sort.store(value != 0); }
+    else if (n == "dup_force_sort") { set_explicit(X_DUP_SORT); g_dup_force_sort.store(value != 0); }
+    else if (n == "lat_rolled") { set_explicit(X_LAT_ROLLED); g_lat_rolled.store(value != 0); }
+    else if (n == "crowd_quad") { set_explicit(X_CROWD_QUAD); g_crowd_quad.store(value != 0); }
+    else if (n == "row_side") { set_explicit(X_ROW_SIDE); g_row_side.store(value != 0); }
+    else if (n == "combine_mid_max") { set_explicit(X_COMBINE_MID); g_combine_mid_max.store((size_t)std::max(0LL, value)); }
+    else if (n == "crowd_floor") { set_explicit(X_CROWD_FLOOR); g_crowd_floor.store((size_t)std::max(0LL, value)); }
     else if (n == "assume_load") g_assume_load.store((size_t)std::max(0LL, value));
     else return BLSMI_E_ARG;
     return BLSMI_OK;
@@ -1430,8 +1451,11 @@ static int msm_bucket_glv_dev(const MsmKernels& k, const u8* d_pts, const u8* d_
     if (sort_mode) {
         // the sort's ping-pong buffers are 256 bytes per point (4 x 16 n words) on top of everything else: when they do not fit, the exact passes
         // (64 bytes per point) serve instead of failing the call
+        //  ... and what an abandoned attempt did get goes back first: the exact passes' index buffer may need exactly that memory
+        const Arena::Mark before = tl_ctx->arena.mark();
         for (int i = 0; i < 2 && sort_mode; i++)
             if (skey[i].alloc(sizeof(u32) * nitems, s) != hipSuccess || sval[i].alloc(sizeof(u32) * nitems, s) != hipSuccess) { (void)hipGetLastError(); sort_mode = false; }
+        if (!sort_mode) { tl_ctx->arena.rewind(before); for (int i = 0; i < 2; i++) { skey[i].p = nullptr; sval[i].p = nullptr; } }
     }
     if (!sort_mode) { if (idx.alloc(sizeof(u32) * per_win_items * nbw, s) != hipSuccess) { (void)hipGetLastError(); return BLSMI_E_NOMEM; } }
     HIPCHK(buckets.alloc(sizeof(i32) * jw * nb, s));

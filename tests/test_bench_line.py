@@ -137,6 +137,7 @@ def test_two_logical_devices_through_the_bench_command():
     assert len(lines) == 1 and len(lines[0]) < 4096
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["devices"] == 2 and j["aliased_devices"] is True and "ALIASED-DEVICES" in j["library"] and "devices=2" in j["library"]
+    assert j["scaling_measured"] is False                                   # the line itself says that no scaling was measured
     assert "NO scaling curve" in j["launch"]
     assert "leg_errors" not in j, j.get("leg_errors")
     assert abs(j["value"] - 2 * 65536 / (j["ms_per_step"] * 1e-3)) / j["value"] < 0.01

@@ -13,11 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(ndev, n_agg):
+def _worker(ndev, n_agg, script="alias_worker.py"):
     env = dict(os.environ)
     env["BLSMI_DEVICE_ALIAS"] = ",".join(["0"] * ndev)
     env.pop("BLSMI_SHARDS", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "alias_worker.py"), str(ndev), str(n_agg)], env=env, capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), str(ndev), str(n_agg)], env=env, capture_output=True, text=True, timeout=1200)
     line = [l for l in r.stdout.splitlines() if l.startswith("ALIAS_RESULT ")]
     assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     return json.loads(line[-1][len("ALIAS_RESULT "):])
@@ -30,6 +30,14 @@ def test_logical_devices_on_one_gpu(ndev, n_agg):
     callers -- at 2 and 4 logical devices; the 4-device case at BASELINE configs[3]'s full 2^20 signatures."""
     res = _worker(ndev, n_agg)
     assert res["devices"] == ndev and res["ok"], res
+
+
+def test_one_million_signature_aggregate_over_eight_logical_devices():
+    """BASELINE configs[3] in its own shape -- 2^20 signatures, EIGHT devices -- through the entry point the Go shim calls
+    (blsmi_g2pubs_verify_aggregate_jac, the reference's in-memory points): true; a wrong key in the first, a middle and the last device's shard;
+    a duplicate message across the first and the last device; every logical device serves a shard.  What an 8-GPU node adds to this is xGMI."""
+    res = _worker(8, 1 << 20, "alias_worker8.py")
+    assert res["devices"] == 8 and res["ok"], res
 
 
 def test_alias_hook_is_off_without_the_variable():

@@ -78,3 +78,39 @@ def test_c_abi_jac_leg_from_a_plain_c_client(tmp_path):
     for i in range(n):
         assert RC.g1_jac_to_affine_bytes(w[i]) == RC.g2pubs.sign(msgs[i], sks[i])
     assert lines["roundtrip"] == ["1"] * n
+
+
+def test_options_set_before_initialisation_survive_it():
+    """blsmi_set_option / blsmi_set_*_threshold called BEFORE the first entry point (or before a re-initialisation after blsmi_shutdown)
+    were overwritten by the environment defaults when the library initialised.  Own process: set the row layout off and "lat_rolled" 0 first, then
+    run 2 400 pairings -- they must take the one-tuple-per-wave path in its straight-line copy (k_lat:pairing1s), not the row kernels -- and once more
+    after shutdown + re-initialisation; BLSMI_ROW_MAX in the environment must NOT win over the explicit call, BLSMI_QUAD_MAX (never set explicitly) must apply."""
+    import sys
+    code = r'''
+import ctypes, numpy as np
+from bls_amd import engine as E
+from oracle import refcpu as RC
+E.set_row_threshold(0, 0); E.set_option("lat_rolled", 0)                    # before any initialisation
+lib = E._lib()
+n = 2400
+g1 = np.frombuffer(RC.g1_generator() * n, dtype=np.uint8); g2 = np.frombuffer(RC.g2_generator() * n, dtype=np.uint8)
+def run():
+    lib.blsmi_set_profiling(1)
+    out = E.pairing_batch(g1, g2, n)
+    buf = ctypes.create_string_buffer(8192); lib.blsmi_last_profile(buf, ctypes.c_size_t(8192)); lib.blsmi_set_profiling(0)
+    return out, buf.value.decode()
+a, p1 = run()
+lib.blsmi_shutdown()
+b, p2 = run()                                                               # lazily re-initialised
+E.set_row_threshold(1, 1 << 20)
+c, p3 = run()
+assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a[0], RC.pairing_batch(RC.g1_generator(), RC.g2_generator(), 1)[0])
+print("PROFILES", p1, "|", p2, "|", p3)
+'''
+    env = dict(os.environ); env["BLSMI_ROW_MAX"] = "65536"; env["BLSMI_ROW_MIN"] = "1"; env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    p1, p2, p3 = [x.strip() for x in r.stdout.split("PROFILES", 1)[1].split("|")]
+    for p in (p1, p2):
+        assert "k_lat:pairing1s" in p and "_row" not in p, (p1, p2)
+    assert "k_miller1h_row" in p3, p3
