@@ -5,6 +5,11 @@
 #ifndef BLSMI_ROW_WAVES
 #define BLSMI_ROW_WAVES 2
 #endif
+// the Fq2 product core expanded in line at its call sites (fp2_pair.inc): the row routines are short sequences around one to three products, a call
+// costs ~45 argument / result moves each.  Same box, interleaved (tools/ab_bench.py): 4 096 pairings 2.46 -> 2.38 ms, 8 192: 4.14 -> 4.06
+#ifndef BLSMI_PAIR_CORE_CALL
+#define BLSMI_PAIR_CORE_INLINE
+#endif
 #include "pairing.cuh"
 #include "device_io.cuh"
 namespace blsmi {
@@ -34,9 +39,8 @@ KERNEL_ROW k_miller1h_row(const u8* g1, const u8* g2, i32* fbuf, size_t n) {
     const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
     const size_t tt = t < n ? t : n - 1;                                  // all sixteen lanes of a row stay active (DPP exchanges)
     const FpS px = load_be48(g1 + 96 * tt), py = load_be48(g1 + 96 * tt + 48);
-    const P2::Fp2S qx = P2::wrap(load_be48(g2 + 192 * tt + 48 * par)), qy = P2::wrap(load_be48(g2 + 192 * tt + 96 + 48 * par));
     P2::R12 f;
-    P2::miller_loop_r(f, px, py, qx, qy);
+    P2::miller_loop_r(f, px, py, P2::RQ{g2 + 192 * tt, par});
     if (t < n) row_store12(fbuf, n, t, pr, par, f);
 }
 // pairing.go:79-129 on the hand-off buffer; out = the reference's in-memory FQ12 (72 u64 per tuple).  mode 1: no exponentiation
@@ -54,14 +58,13 @@ KERNEL_ROW k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0, con
     const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
     const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
     const size_t tt = t < n ? t : n - 1;
-    FpS px[2], py[2]; P2::Fp2S qx[2], qy[2];
+    FpS px[2], py[2];
     px[0] = load_be48(p0 + sp0 * tt); py[0] = load_be48(p0 + sp0 * tt + 48);
-    qx[0] = P2::wrap(load_be48(q0 + sq0 * tt + 48 * par)); qy[0] = P2::wrap(load_be48(q0 + sq0 * tt + 96 + 48 * par));
     px[1] = load_be48(p1 + sp1 * tt); py[1] = fp_store(fp_neg(load_be48(p1 + sp1 * tt + 48)));      // -P1
-    qx[1] = P2::wrap(load_be48(q1 + sq1 * tt + 48 * par)); qy[1] = P2::wrap(load_be48(q1 + sq1 * tt + 96 + 48 * par));
+    const P2::RQ q[2] = {{q0 + sq0 * tt, par}, {q1 + sq1 * tt, par}};
     P2::R12 f;
-    if (pre) P2::miller_loop2_r<true>(f, px, py, qx, qy, pre);
-    else P2::miller_loop2_r<false>(f, px, py, qx, qy, nullptr);
+    if (pre) P2::miller_loop2_r<true>(f, px, py, q, pre);
+    else P2::miller_loop2_r<false>(f, px, py, q, nullptr);
     if (t < n) row_store12(fbuf, n, t, pr, par, f);
 }
 // A Verify in two Miller loops (verify_host.inc: verify_sig_side_start): the SIGNATURE side -- e(sig, G2One) for g2pubs, e(G1One, sig) for g1pubs --
@@ -76,10 +79,7 @@ KERNEL_ROW k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* f
     const FpS px = load_be48(p + sp * tt), py = load_be48(p + sp * tt + 48);
     P2::R12 f;
     if (pre) P2::miller_loop_table_r(f, px, py, pre);
-    else {
-        const P2::Fp2S qx = P2::wrap(load_be48(q + sq * tt + 48 * par)), qy = P2::wrap(load_be48(q + sq * tt + 96 + 48 * par));
-        P2::miller_loop_r(f, px, py, qx, qy);
-    }
+    else P2::miller_loop_r(f, px, py, P2::RQ{q + sq * tt, par});
     if (t < n) row_store12(fbuf, n, t, pr, par, f);
 }
 KERNEL_ROW k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n) {
@@ -87,9 +87,8 @@ KERNEL_ROW k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* f
     const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
     const size_t tt = t < n ? t : n - 1;
     const FpS px = load_be48(p + sp * tt), py = fp_store(fp_neg(load_be48(p + sp * tt + 48)));       // -P
-    const P2::Fp2S qx = P2::wrap(load_be48(q + sq * tt + 48 * par)), qy = P2::wrap(load_be48(q + sq * tt + 96 + 48 * par));
     P2::R12 f;
-    P2::miller_loop_r(f, px, py, qx, qy);
+    P2::miller_loop_r(f, px, py, P2::RQ{q + sq * tt, par});
     f = P2::r12_mul(f, row_load12(fbuf, n, tt, pr, par));
     if (t < n) row_store12(fbuf, n, t, pr, par, f);
 }
@@ -117,14 +116,14 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
         const P2::Fp2S qx = x.c1.c0, qy = x.c1.c1;
         const FpS px = load_m384(a + (size_t)6 * (12 * t + 10)), py = load_m384(a + (size_t)6 * (12 * t + 11));
         P2::RLine l;
-        if (op == BLSMI_OP_ROW_DBL_STEP) P2::r_doubling_step<false>(r, P2::r_scalar(px), P2::r_scalar(py), l);
-        else if (op == BLSMI_OP_ROW_ADD_STEP) P2::r_addition_step<false>(r, qx, qy, P2::r_scalar(px), P2::r_scalar(py), l);
+        if (op == BLSMI_OP_ROW_DBL_STEP) P2::r_doubling_step<false>(r, P2::r_point(px, py), l);
+        else if (op == BLSMI_OP_ROW_ADD_STEP) P2::r_addition_step<false>(r, P2::RQval{qx, qy}, P2::r_point(px, py), l);
         else {
             P2::Fp2S o0, o1, o2;
             if (op == BLSMI_OP_ROW_DBL_STEP_REF) P2::doubling_step_h(r, o0, o1, o2); else P2::addition_step_h(r, qx, qy, o0, o1, o2);
-            l.c0 = P2::fp2_tight(o2); l.c1 = P2::fp2_tight(P2::fp2_mul_fp(o1, px)); l.c4 = P2::fp2_tight(P2::fp2_mul_fp(o0, py));
+            l.c0 = o2; l.c1 = P2::fp2_norm(P2::fp2_mul_fp(o1, px)); l.c4 = P2::fp2_norm(P2::fp2_mul_fp(o0, py));
         }
-        const FpS res[6] = {r.x.c, r.y.c, r.z.c, fp_relabel<1, FpS::V>(l.c0.c), fp_relabel<1, FpS::V>(l.c1.c), fp_relabel<1, FpS::V>(l.c4.c)};
+        const FpS res[6] = {r.x.c, r.y.c, r.z.c, l.c0.c, fp_relabel<1, FpS::V>(l.c1.c), fp_relabel<1, FpS::V>(l.c4.c)};
         if (t0 < n && (threadIdx.x & 14) == 0)
             for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), res[j]);
         return;

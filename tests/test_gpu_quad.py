@@ -108,9 +108,9 @@ def test_quad_layout_at_its_design_size(eng):
         assert np.array_equal(got[i], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]), i
 
 
-def test_soak_slice_three_layouts_two_limb_representations():
+def test_soak_slice_four_layouts_two_limb_representations():
     """a 20-second slice of tools/soak6.py: random batch sizes, special scalars, points outside the subgroup and corrupted verify tuples
-    through the wave (15 x 27-bit limbs), quad and pair (14 x 28-bit) paths -- same Fq12 bits, same verdicts, samples against the oracle"""
+    through the wave (15 x 27-bit limbs), row, quad and pair (14 x 28-bit) paths -- same Fq12 bits, same verdicts, samples against the oracle"""
     import os
     import subprocess
     import sys

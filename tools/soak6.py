@@ -1,5 +1,6 @@
-"""Round-4 differential soak: the same random tuples through the three pairing layouts -- one tuple per wave (k_lat.hip: 15 x 27-bit limbs),
-lane quad and lane pair (14 x 28-bit limbs) -- must give the same Fq12 bits and the same verdicts; samples go to the oracle.  Two
+"""Round-4 differential soak (round 6: four layouts): the same random tuples through the pairing layouts -- one tuple per wave (k_lat.hip: 15 x 27-bit
+limbs), lane ROW (sixteen lanes per tuple, row_body.inc), lane quad and lane pair (14 x 28-bit limbs) -- must give the same Fq12 bits and the same
+verdicts; samples go to the oracle.  Two
 representations and three lane layouts computing independently find what a handful of KATs cannot (a carry that only a rare limb
 pattern produces, a value bound that holds for random inputs only).  Points include the generators, small multiples, r - 1, and points
 OUTSIDE the subgroup; verify tuples carry random corruptions.   python tools/soak6.py [seconds]"""
@@ -26,9 +27,10 @@ def scalars(n):
 
 
 def paths():
-    yield "wave", 1 << 20, 0
-    yield "quad", 0, 1 << 20
-    yield "pair", 0, 0
+    yield "wave", 1 << 20, 0, (0, 0)
+    yield "row", 1 << 20, 0, (1, 1 << 20)                                # (the g1pubs Verify then also runs its signature side beside the hash: k_miller1s_row / k_miller1m_row)
+    yield "quad", 0, 1 << 20, (0, 0)
+    yield "pair", 0, 0, (0, 0)
 
 
 from test_gpu_round3 import _torsion_points
@@ -46,10 +48,10 @@ try:
             else:
                 g2[i] = np.frombuffer(T2[j % len(T2)], dtype=np.uint8)
         outs = {}
-        for name, lat, quad in paths():
-            E.set_latency_threshold(lat); E.set_quad_threshold(quad)
+        for name, lat, quad, row in paths():
+            E.set_latency_threshold(lat); E.set_quad_threshold(quad); E.set_row_threshold(*row)
             outs[name] = E.pairing_batch(g1.reshape(-1), g2.reshape(-1), n)
-        assert np.array_equal(outs["wave"], outs["quad"]) and np.array_equal(outs["quad"], outs["pair"]), ("pairing", n)
+        assert np.array_equal(outs["wave"], outs["quad"]) and np.array_equal(outs["quad"], outs["pair"]) and np.array_equal(outs["row"], outs["pair"]), ("pairing", n)
         for i in rng.integers(0, n, size=min(n, 3)):
             assert np.array_equal(outs["pair"][i], RC.pairing_batch(g1[i].tobytes(), g2[i].tobytes(), 1)[0]), ("pairing oracle", n, int(i))
             checked += 1
@@ -79,10 +81,11 @@ try:
                 expect[i] = False
             fn = E.g2pubs_verify_batch if group == "g2pubs" else E.g1pubs_verify_batch
             oks = {}
-            for name, lat, quad in paths():
-                E.set_latency_threshold(lat); E.set_quad_threshold(quad)
+            for name, lat, quad, row in paths():
+                E.set_latency_threshold(lat); E.set_quad_threshold(quad); E.set_row_threshold(*row)
+                E.set_option("row_side", int(rng.integers(0, 2)))       # (either form of the row layout's g1pubs Verify)
                 oks[name], _ = fn(msgs, allpk.reshape(-1), sig.reshape(-1))
-            assert np.array_equal(oks["wave"], oks["quad"]) and np.array_equal(oks["quad"], oks["pair"]), (group, n)
+            assert np.array_equal(oks["wave"], oks["quad"]) and np.array_equal(oks["quad"], oks["pair"]) and np.array_equal(oks["row"], oks["pair"]), (group, n)
             bad = np.nonzero(oks["pair"] != expect)[0]
             for i in bad:                                               # a "corruption" can coincide with the truth (same key twice): ask the oracle
                 assert O.verify(msgs[i], allpk[i].tobytes(), sig[i].tobytes()) == bool(oks["pair"][i]), (group, n, int(i))
@@ -90,5 +93,5 @@ try:
                 assert O.verify(msgs[int(i)], allpk[int(i)].tobytes(), sig[int(i)].tobytes()) == bool(oks["pair"][int(i)]); checked += 1
         rounds += 1
 finally:
-    E.set_latency_threshold(8192); E.set_quad_threshold(16384)
-print("soak6: %d rounds, %d oracle samples, %.0f s: three layouts / two limb representations agree" % (rounds, checked, time.time() - t0))
+    E.set_latency_threshold(8192); E.set_quad_threshold(16384); E.set_row_threshold(*E.ROW_DEFAULT); E.set_option("row_side", 1)
+print("soak6: %d rounds, %d oracle samples, %.0f s: four layouts / two limb representations agree" % (rounds, checked, time.time() - t0))
