@@ -204,3 +204,57 @@ def test_row_layout_at_its_design_size(eng):
     assert list(ok) == expect
     for i in (0, 6, 4095):
         assert RC.g2pubs.verify(msgs[i], allpk[i].tobytes(), sigs[i].tobytes()) == expect[i]
+
+
+@pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
+def test_verify_aggregate_miller_loops_in_the_row_layout(eng, group):
+    """VerifyAggregate over distinct messages (g2pubs/bls.go:240-270, g1pubs/bls.go:252-282) with its n Miller loops on the lane-row kernel
+    (k_miller1s_row, one loop per row; product tree and final exponentiation as before): the oracle's verdicts at small n with the layout forced,
+    and at 3 000 signers on the default thresholds -- true, false with one key replaced, equal to the one-tuple-per-wave path's verdicts"""
+    o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
+    xs = P.XORShift(6106)
+    n = 9
+    sks = [sk_bytes(xs) for _ in range(n)]
+    msgs = [b"row aggregate %d" % i for i in range(n)]
+    pks = [o.priv_to_pub(k) for k in sks]; sigs = [o.sign(m, k) for m, k in zip(msgs, sks)]
+    summ = eng.g1_sum if group == "g2pubs" else eng.g2_sum
+    agg = summ(b"".join(sigs), n)
+    fn = eng.g2pubs_verify_aggregate if group == "g2pubs" else eng.g1pubs_verify_aggregate
+    lib = eng._lib()
+    import bench
+    try:
+        eng.set_row_threshold(1, 1 << 20)
+        assert o.verify_aggregate(agg, pks, msgs) is True
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        assert fn(msgs, b"".join(pks), agg) is True
+        lib.blsmi_set_profiling(0)
+        assert "k_miller1s_row" in bench.read_profile(lib)
+        for m in (1, 4, 5):
+            part = summ(b"".join(sigs[:m]), m)
+            assert fn(msgs[:m], b"".join(pks[:m]), part) is True and o.verify_aggregate(part, pks[:m], msgs[:m]) is True
+        wrong = list(pks); wrong[6] = pks[2]
+        assert fn(msgs, b"".join(wrong), agg) is False and o.verify_aggregate(agg, wrong, msgs) is False
+    finally:
+        eng.set_row_threshold(*eng.ROW_DEFAULT)
+    # 3 000 signers, default thresholds: the row kernel serves; the wave path (row layout off) must agree
+    n = 3000
+    nk = 64
+    skb = b"".join(sk_bytes(xs) for _ in range(nk))
+    msgs = [b"row aggregate big %d" % i for i in range(n)]
+    if group == "g2pubs":
+        pk, _ = eng.g2_mul_generator_batch(skb, nk); h = eng.hash_g1_batch(msgs); sg, _ = eng.g1_mul_batch(h.reshape(-1), (skb * (n // nk + 1))[:32 * n], n)
+    else:
+        pk, _ = eng.g1_mul_generator_batch(skb, nk); h = eng.hash_g2_batch(msgs); sg, _ = eng.g2_mul_batch(h.reshape(-1), (skb * (n // nk + 1))[:32 * n], n)
+    allpk = np.ascontiguousarray(np.stack([pk[i % nk] for i in range(n)]))
+    agg = summ(sg.reshape(-1), n)
+    bad = allpk.copy(); bad[1234] = pk[(1234 + 1) % nk]
+    try:
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        t = fn(msgs, allpk.reshape(-1), agg)
+        lib.blsmi_set_profiling(0)
+        assert "k_miller1s_row" in bench.read_profile(lib)
+        f = fn(msgs, bad.reshape(-1), agg)
+        eng.set_row_threshold(0, 0)
+        assert (t, f) == (True, False) and fn(msgs, allpk.reshape(-1), agg) is True and fn(msgs, bad.reshape(-1), agg) is False
+    finally:
+        eng.set_row_threshold(*eng.ROW_DEFAULT)
