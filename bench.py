@@ -648,7 +648,7 @@ def mid_bench(E, steps=5, warmup=2):
     """Batches between the latency hand-over and a full chip (the reference's API is one tuple per call and its aggregate benchmarks use
     128 signers, g1pubs/verify_benchmark_test.go:33-85: real batches are not 65 536 tuples): pairings at 2 048 / 4 096 / 8 192 / 16 384 /
     32 768 and g2pubs / g1pubs verifies at 4 096 and 16 384, inputs resident, on the library's own choice of layout (one tuple per wave below
-    2 304 tuples, per lane ROW -- round 6 -- up to 8 192, per lane QUAD up to 16 384, per lane pair beyond); every size's first 16 rows re-checked
+    2 048 tuples, per lane ROW -- round 6 -- up to 8 192, per lane QUAD up to 16 384, per lane pair beyond); every size's first 16 rows re-checked
     against the oracle."""
     import torch
     from oracle import refcpu as RC

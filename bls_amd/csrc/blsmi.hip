@@ -61,7 +61,7 @@ std::mutex g_coll_mu;
 std::condition_variable g_cv;          // a context was released (lease waiters and shutdown both wait here: notify_all)
 bool g_pair_layout = true;              // lane-pair pairing kernels (two lanes per tuple); BLSMI_LAYOUT=single for one tuple per lane
 bool g_ready = false;
-char g_version[200] = "blsmi 0.6 (uninitialised)";
+char g_version[200] = "blsmi 0.7 (uninitialised)";
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "blsmi: %s failed: %s\n", #x, hipGetErrorString(e_)); return BLSMI_E_HIP; } } while (0)
 
@@ -313,11 +313,11 @@ inline size_t call_load(size_t n) {
     return c->load_others + g_assume_load.load(std::memory_order_relaxed);
 }
 // A fourth layout between the wave and the quad (round 6, k_pairing_row.hip): one tuple per DPP ROW of sixteen lanes.  g_row_min .. g_row_max
-// tuples (2 304 .. 8 192) of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
+// tuples (2 048 .. 8 192) of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
 // 3.3 x the instructions on the one-tuple-per-wave path).  When other calls are in flight on the device the choice above stands (the quad
 // kernels spend fewer lane-instructions per tuple: 12.6 M against 18 M).  blsmi_set_row_threshold / BLSMI_ROW_MIN / BLSMI_ROW_MAX; max 0: off.
 std::atomic<bool> g_row_side{true};     // BLSMI_ROW_SIDE / blsmi_set_option("row_side"): a Verify in the row layout runs its signature side beside the hash (verify_host.inc)
-std::atomic<size_t> g_row_min{2304};   // (tools/midsize4.py: 2 048 pairings 2.26 ms either way, 3 072: 2.26 against 3.32; verifies cross at ~2 500)
+std::atomic<size_t> g_row_min{2048};   // (tools/midsize4.py: 2 048 pairings 2.08 against 2.21 ms on the wave path, g1pubs verifies 4.45 against 4.72, g2pubs 3.66 against 3.57; 1 024: 2.05 against 1.54)
 std::atomic<size_t> g_row_max{8192};   // (8 192 pairings 4.0 ms against the quad kernels' flat 5.7; 12 288: 6+ against 5.7)
 inline bool use_row(size_t n) {
     const bool crowd = g_crowd_quad.load(std::memory_order_relaxed) && n >= g_crowd_floor.load(std::memory_order_relaxed);
@@ -448,7 +448,7 @@ int ensure_init_list(const int* devs, int ndev) {
     HIPCHK(hipSetDevice(g_dev[0].id));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, g_dev[0].id));
-    snprintf(g_version, sizeof g_version, "blsmi 0.6 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_alias ? " ALIASED-DEVICES(test hook: host-staged collectives)" : g_have_comm ? " rccl" : "");
+    snprintf(g_version, sizeof g_version, "blsmi 0.7 %s CUs=%d devices=%d shards=%d%s", prop.gcnArchName, prop.multiProcessorCount, g_ndev, g_nshards, g_alias ? " ALIASED-DEVICES(test hook: host-staged collectives)" : g_have_comm ? " rccl" : "");
     g_ready = true;
     return BLSMI_OK;
 }

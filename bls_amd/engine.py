@@ -103,7 +103,7 @@ def set_row_threshold(min_tuples, max_tuples):
     _check(_lib().blsmi_set_row_threshold(C.c_size_t(int(min_tuples)), C.c_size_t(int(max_tuples))), "blsmi_set_row_threshold")
 
 
-ROW_DEFAULT = (2304, 8192)
+ROW_DEFAULT = (2048, 8192)
 
 
 def set_option(name, value):

@@ -70,7 +70,8 @@ void blsmi_shutdown(void);
  * mul / sum / msm / verify_aggregate and changes no existing prototype; 0.4 adds the prepared-key entry points.  Check the prefix
  * before binding by hand.  0.5 adds blsmi_trim / blsmi_held_bytes, the *_ex forms of mul / msm (per-call BLSMI_MUL_ANY_POINT),
  * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes.  0.6 adds the *_jac forms
- * (the reference's in-memory Jacobian / Montgomery points at the boundary); no existing prototype changes. */
+ * (the reference's in-memory Jacobian / Montgomery points at the boundary); no existing prototype changes.  0.7 adds blsmi_set_row_threshold (the lane-row layout for
+ * 2 048 .. 8 192 tuples), the "row_side" option and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP for blsmi_debug_op; no existing prototype changes. */
 const char *blsmi_version(void);
 
 /* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
@@ -103,11 +104,11 @@ int blsmi_set_latency_threshold(size_t max_tuples);
 /* Mid-size batches: pairing / verify batches above the latency threshold and of at most `max_tuples` tuples run in the LANE-QUAD layout
  * -- four lanes per tuple, 16 384 tuples = one wave on every SIMD of the chip -- instead of the lane-pair layout, which needs 65 536
  * tuples to fill it (16 384 pairings: 11.5 ms there).  Default 16 384 (environment BLSMI_QUAD_MAX); 0 switches the layout off.
- * Same results bit for bit on all three paths. */
+ * Same results bit for bit on all paths. */
 int blsmi_set_quad_threshold(size_t max_tuples);
 /* A few thousand tuples (blsmi 0.7): a LONE pairing / verify call of min_tuples .. max_tuples tuples runs in the LANE-ROW layout -- sixteen lanes (one DPP
  * row) per tuple, 4 096 tuples = one wave on every SIMD of the chip -- instead of one tuple per wave (below) or per lane quad (above).  Default
- * 2 304 .. 8 192 (environment BLSMI_ROW_MIN / BLSMI_ROW_MAX); max_tuples = 0 switches the layout off.  Calls that find other calls in flight on
+ * 2 048 .. 8 192 (environment BLSMI_ROW_MIN / BLSMI_ROW_MAX); max_tuples = 0 switches the layout off.  Calls that find other calls in flight on
  * their device keep the quad kernels (see "crowd_quad" below).  Same results bit for bit on all four paths. */
 int blsmi_set_row_threshold(size_t min_tuples, size_t max_tuples);
 /* When should a lone call stay on the upstream CPU path?  A call with few elements costs the dependent depth of ONE wave walking the

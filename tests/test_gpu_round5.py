@@ -133,7 +133,7 @@ def test_uncleared_hash_path_flags_cancelling_map_points(eng):
 @pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
 def test_layout_follows_the_load_of_the_device(eng, group):
     """blsmi 0.6: the layout of a mid-size call goes by what its DEVICE carries (blsmi.hip: call_load / use_quad; tools/midsize_concurrency.py) --
-    a call of >= crowd_floor tuples takes the lane-quad kernels when other calls' tuples are in flight; alone it takes the lane-row kernels (round 6; the one-tuple-per-wave path below 2 304 tuples).
+    a call of >= crowd_floor tuples takes the lane-quad kernels when other calls' tuples are in flight; alone it takes the lane-row kernels (round 6; the one-tuple-per-wave path below 2 048 tuples).
     Same verdicts (and the same Fq12 bits for Pairing) on either; "assume_load" stands in for the other callers; calls below the floor never move."""
     import ctypes
     from test_gpu_verify import _tuples
