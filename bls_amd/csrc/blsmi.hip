@@ -319,10 +319,13 @@ inline size_t call_load(size_t n) {
 std::atomic<bool> g_row_side{true};     // BLSMI_ROW_SIDE / blsmi_set_option("row_side"): a Verify in the row layout runs its signature side beside the hash (verify_host.inc)
 std::atomic<size_t> g_row_min{2048};   // (tools/midsize4.py: 2 048 pairings 2.08 against 2.21 ms on the wave path, g1pubs verifies 4.45 against 4.72, g2pubs 3.66 against 3.57; 1 024: 2.05 against 1.54)
 std::atomic<size_t> g_row_max{8192};   // (8 192 pairings 4.0 ms against the quad kernels' flat 5.7; 12 288: 6+ against 5.7)
-inline bool use_row(size_t n) {
+// pairing_only: blsmi_pairing_batch has no hash beside its two kernels, and there the row kernels stay ahead of the quad kernels' flat 5.7 ms up to 12 288 tuples
+// (three waves per SIMD: 5.34 ms; verifies cross at ~10 000: 12 288 g2pubs verifies 8.96 against 7.95 ms) -- half again the general maximum
+inline bool use_row(size_t n, bool pairing_only = false) {
     const bool crowd = g_crowd_quad.load(std::memory_order_relaxed) && n >= g_crowd_floor.load(std::memory_order_relaxed);
     const size_t others = crowd ? call_load(n) : 0;                        // (every sizeable call is counted, whatever layout it takes itself)
-    const size_t hi = g_row_max.load(std::memory_order_relaxed);
+    size_t hi = g_row_max.load(std::memory_order_relaxed);
+    if (pairing_only) hi += hi / 2;
     if (!g_pair_layout || hi == 0 || n > hi || n < g_row_min.load(std::memory_order_relaxed)) return false;
     const size_t lone = std::min(g_lat_max.load(), g_quad_min.load());
     return !(others > 0 && n + others > lone);
@@ -835,7 +838,7 @@ static int pairing_dev(const void* d_g1, const void* d_g2, void* d_out, size_t n
     HIPCHK(g_ws.reserve(sizeof(i32) * 12 * NL * n));
     i32* f = reinterpret_cast<i32*>(g_ws.p);
     const unsigned pblocks = (unsigned)((n + PT - 1) / PT);
-    if (mode == 0 && use_row(n)) {                                         // a few thousand tuples: sixteen lanes per tuple, one wave per SIMD at 4 096 tuples
+    if (mode == 0 && use_row(n, true)) {                                   // a few thousand tuples: sixteen lanes per tuple, one wave per SIMD at 4 096 tuples
         prof_mark("k_miller1h_row");
         hipLaunchKernelGGL(k_miller1h_row, dim3(rblocks(n)), dim3(WG), 0, s, (const u8*)d_g1, (const u8*)d_g2, f, n);
         prof_mark("k_final_exp_row");

@@ -142,8 +142,10 @@ int blsmi_prefer_cpu(int shape, size_t n);
  * Eight callers x 4 096 g2pubs tuples: 0.73 -> 1.84 M verifies/s with both; four callers x 4 096 pairings: 1.04 -> 2.50 M/s.
  * Concurrency needs hardware queues: the HIP runtime hands its GPU_MAX_HW_QUEUES queues (default 4) to streams in creation order and kernels of one
  * queue run one after the other, so the library creates its call contexts' streams back to back when it initialises (BLSMI_STREAMS = 4 = one queue
- * each).  Raising GPU_MAX_HW_QUEUES is not needed and not harmless: with 8, sixteen concurrent callers ran 5.7x slower and one long test process
- * aborted inside the runtime (profiles/r05_soak9.log).
+ * each).  Supported ceiling (round 6, profiles/r06_queue_matrix.log): BLSMI_STREAMS <= 4 -- the default -- at ANY GPU_MAX_HW_QUEUES (4, 6, 8 measured: 0.73 - 1.18 M verifies/s for 4 - 16 callers).
+ * More call contexts than four on more than four hardware queues collapse (0.14 - 0.30 M verifies/s) or abort inside the runtime: HSA_STATUS_ERROR_OUT_OF_RESOURCES -- a hardware queue's scratch is sized
+ * for a chip full of waves of the largest private segment it has dispatched (k_cofac2_pair: 7 680 bytes a lane, ~4 GB a queue), and eight such queues are more than the runtime grants
+ * (profiles/r06_queue_abort_q8_c8.log).  Callers beyond four merge or wait.
  * Test hooks: BLSMI_DEVICE_ALIAS (above); "assume_load" (tuples pretended to be in flight from other calls).  Unknown option name: BLSMI_E_ARG.  (blsmi 0.6) */
 int blsmi_set_option(const char *name, long long value);
 int blsmi_last_kernel_ms(float *miller_ms, float *final_exp_ms);
