@@ -664,7 +664,19 @@ def mid_bench(E, steps=5, warmup=2):
         dt = timed_steps(E, step, steps, warmup)
         assert np.array_equal(do[:16].cpu().numpy().view(np.uint64), want), "mid-size pairings differ from the oracle at n = %d" % n
         out["pairings_per_s"][str(n)] = round(n * steps / dt, 1); out["pairing_ms"][str(n)] = round(dt / steps * 1e3, 3)
-        out["pairing_kernels"][str(n)] = {k: round(v[0], 3) for k, v in profiled(E.lib, step).items() if not k.startswith("(")}
+        kern = {k: v[0] for k, v in profiled(E.lib, step).items() if not k.startswith("(")}
+        out["pairing_kernels"][str(n)] = {k: round(v, 3) for k, v in kern.items()}
+        # integer-issue fraction of this size's kernels: executed VALU wave-instructions of the committed PMC pass at THIS launch grid x 4 cycles over the
+        # SIMDs that have a wave, against the measured kernel time (the bound that limits these kernels; the HBM roofline object is the headline's)
+        issue = {}
+        for k, ms in kern.items():
+            c = counter_of(E.ctr, k, {"k_miller1h_row": 16 * n, "k_final_exp_row": 16 * n, "k_miller1h_quad": 4 * n, "k_final_exp_quad": 4 * n, "k_miller1h_pair": 2 * n, "k_final_exp_pair": 2 * n}.get(k))
+            if c.get("SQ_INSTS_VALU") and c.get("grid") and ms > 0:
+                waves = c["grid"] / 64.0
+                busy_simds = min(float(SIMDS), waves)
+                issue[k] = round(c["SQ_INSTS_VALU"] * CYCLES_PER_VALU / busy_simds / (CLOCK_GHZ * 1e9) * 1e3 / ms, 4)
+        if issue:
+            out.setdefault("valu_issue_frac", {})[str(n)] = issue
     nv = 16384
     out["verify_kernels"] = {}
     for group in ("g2pubs", "g1pubs"):
