@@ -64,12 +64,16 @@ R_ORDER = 5243587517512619047944774050818596583769055250052763782260365869993858
 # ---------------------------------------------------------------------------------------------------------------------
 # committed rocprofv3 counters (bench.py cannot read PMCs itself)
 # ---------------------------------------------------------------------------------------------------------------------
+# host-side translation units: no kernel in them, a change there cannot make a counter or a kernel duration stale
+HOST_ONLY = ("blsmi.hip", "verify_host.inc", "kernels.h")
+
+
 def source_digest():
     """sha256 over the kernel sources: recorded by tools/rocpd_summary.py at profile time, recomputed here -> `stale`"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "bls_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cuh", ".inc", ".h", ".py")) and not f.startswith("lat_programs"):
+        if f.endswith((".hip", ".cuh", ".inc", ".h", ".py")) and not f.startswith("lat_programs") and f not in HOST_ONLY:
             h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -138,11 +138,12 @@ __device__ __noinline__ void scale_by_cofactor(G2AffP& out, const G2AffP& pt) {
 }  // namespace pairl
 }  // namespace blsmi
 
-__global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u64* off, u8* good, u8* out, size_t n, unsigned redo_every) {
-    const int par = threadIdx.x & 1;
+// everything of a message's hash up to the 3-isogeny's Jacobian image (both kernels below); `bad`: the fused identities do not cover this message
+BLSMI_DEV void hash_g2_pair_front(const u8* msgs, const u64* off, size_t n, unsigned redo_every, size_t& t0, size_t& t, int& par, P2::G2JacP& ij, i32& bad) {
+    par = threadIdx.x & 1;
     const i32 odd = -(i32)par;
-    const size_t t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
-    const size_t t = t0 < n ? t0 : n - 1;                                  // both lanes of a pair stay active
+    t0 = (size_t)blockIdx.x * (WG / 2) + (threadIdx.x >> 1);
+    t = t0 < n ? t0 : n - 1;                                               // both lanes of a pair stay active
     u32 d[8];
     sha256_msg(d, 1, 0x01, msgs + off[t], (size_t)(off[t + 1] - off[t]));
     // hp2 (hash.go:74-113): this lane's coefficient of t1 and of t2
@@ -169,10 +170,14 @@ __global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u6
     P2::scatter_own_map(a1.y, a2.y, y, odd);
     // hash.go:391-411: the sum of the two mapped points, the 3-isogeny, clearH2 -- Jacobian throughout, one inversion
     const P2::G2JacP sj = jac_add_affine(to_jac(a1), a2);
-    P2::G2JacP ij; P2::iso3_jac(ij, sj);
-    P2::G2AffP r; P2::clear_h2_jac(r, ij);
+    P2::iso3_jac(ij, sj);
     // redo_every (tests only): hand every redo_every-th message to the one-lane routine as if it had been exceptional
-    const i32 bad = special | sj.inf | ((redo_every && t % redo_every == 0) ? -1 : 0);
+    bad = special | sj.inf | ((redo_every && t % redo_every == 0) ? -1 : 0);
+}
+__global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u64* off, u8* good, u8* out, size_t n, unsigned redo_every) {
+    size_t t0, t; int par; P2::G2JacP ij; i32 bad;
+    hash_g2_pair_front(msgs, off, n, redo_every, t0, t, par, ij, bad);
+    P2::G2AffP r; P2::clear_h2_jac(r, ij);
     if (t0 < n) {
         if (!par) good[t] = bad ? 0 : 1;
         if (!bad) {                                                        // x.c_par at +48 par, y.c_par at +96 + 48 par
@@ -180,6 +185,18 @@ __global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u6
             if (r.inf) { u32* w = reinterpret_cast<u32*>(o + 48 * par); for (int i = 0; i < 12; i++) { w[i] = 0; w[24 + i] = 0; } }
             else { store_be48(o + 48 * par, r.x.c); store_be48(o + 96 + 48 * par, r.y.c); }
         }
+    }
+}
+
+// the same up to the isogeny, for the row layout's tail (k_pairing_row.hip: k_clear_h2_row): the Jacobian image into `jbuf` (structure of arrays, element
+// 2 c + parity of coordinate c), good[t] = 0 also when the image is the point at infinity
+__global__ void __launch_bounds__(WG, 2) k_hash_g2_front(const u8* msgs, const u64* off, u8* good, i32* jbuf, size_t n, unsigned redo_every) {
+    size_t t0, t; int par; P2::G2JacP ij; i32 bad;
+    hash_g2_pair_front(msgs, off, n, redo_every, t0, t, par, ij, bad);
+    bad |= ij.inf;
+    if (t0 < n) {
+        if (!par) good[t] = bad ? 0 : 1;
+        soa_store(jbuf, n, t, 0 + par, ij.x.c); soa_store(jbuf, n, t, 2 + par, ij.y.c); soa_store(jbuf, n, t, 4 + par, ij.z.c);
     }
 }
 

@@ -15,6 +15,7 @@
 namespace blsmi {
 namespace pairl {
 #include "row_body.inc"
+#include "row_g2.inc"
 }  // namespace pairl
 }  // namespace blsmi
 
@@ -128,6 +129,15 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
             for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), res[j]);
         return;
     }
+    if (op >= BLSMI_OP_ROW_G2_DOUBLE && op <= BLSMI_OP_ROW_CLEAR_H2) {       // row_g2.inc: (X1, Y1, Z1, X2, Y2, Z2) -> (X3, Y3, Z3, 0, 0, 0)
+        P2::RJ p, q; p.x = x.c0.c0; p.y = x.c0.c1; p.z = x.c0.c2; q.x = x.c1.c0; q.y = x.c1.c1; q.z = x.c1.c2;
+        const P2::RJ r = op == BLSMI_OP_ROW_G2_DOUBLE ? P2::r_jdouble(p) : op == BLSMI_OP_ROW_G2_ADD ? P2::r_jadd(p, q) : P2::r_clear_h2(p);
+        const FpS zero = fp_zero();
+        const FpS res[6] = {r.x.c, r.y.c, r.z.c, zero, zero, zero};
+        if (t0 < n && (threadIdx.x & 14) == 0)
+            for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), res[j]);
+        return;
+    }
     const P2::R12 rx = P2::r12_from_pair(x), ry = P2::r12_from_pair(y);
     P2::R12 r;
     switch (op) {
@@ -144,4 +154,23 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
     const FpS* cz = reinterpret_cast<const FpS*>(&z);
     if (t0 < n && (threadIdx.x & 14) == 0)
         for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), cz[j]);
+}
+
+// ---- the tail of HashG2 for a few thousand messages (row_g2.inc): k_hash_g2_front (k_hash_pair.hip) leaves the isogeny's Jacobian image of every message in `jbuf`
+// (6 Fq per message, structure of arrays like the Miller-loop hand-off; element 2 c + parity of coordinate c) and good[t]; this kernel clears the cofactor
+// with sixteen lanes per message and writes the affine wire record.  A message whose result has Z = 0 -- infinity met on the way, an addition of equal x --
+// gets good[t] = 0 and is redone by k_hash_g2_redo with the reference's special cases.
+KERNEL_ROW k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n) {
+    const int par = threadIdx.x & 1;
+    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < n ? t : n - 1;
+    P2::RJ p;
+    p.x = P2::wrap(soa_load(jbuf, n, tt, 0 + par)); p.y = P2::wrap(soa_load(jbuf, n, tt, 2 + par)); p.z = P2::wrap(soa_load(jbuf, n, tt, 4 + par));
+    const P2::RJ r = P2::r_clear_h2(p);
+    P2::Fp2S ax, ay; bool zero;
+    P2::r_jto_affine(r, ax, ay, zero);
+    if (t < n && (threadIdx.x & 14) == 0) {                                 // pair 0 of the row writes: x.c_par at +48 par, y.c_par at +96 + 48 par
+        if (zero) { if (!par) good[t] = 0; }
+        else if (good[t]) { u8* o = out + 192 * t; store_be48(o + 48 * par, ax.c); store_be48(o + 96 + 48 * par, ay.c); }
+    }
 }

@@ -49,6 +49,7 @@ __global__ void k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0
 __global__ void k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n, const i32* pre);
 __global__ void k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n);
 __global__ void k_final_exp_is_one_row(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
+__global__ void k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n);
 __global__ void k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n);
 // k_prepared_pair.hip
 __global__ void k_g2_prepare_pair(const u8* g2, i32* tables, size_t n);
@@ -99,6 +100,7 @@ __global__ void k_debug_swu_g2(const u64* a, u64* out, size_t n);
 // k_hash_pair.hip
 __global__ void k_hash_g2_pair(const u8* msgs, const u64* off, u8* good, u8* out, size_t n, unsigned redo_every);
 __global__ void k_cofac2_pair(const u8* pts, u8* out, size_t n);
+__global__ void k_hash_g2_front(const u8* msgs, const u64* off, u8* good, i32* jbuf, size_t n, unsigned redo_every);
 // k_curve.hip
 __global__ void k_debug_fq6(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_debug_curve(int op, const u64* a, const u64* b, u64* out, size_t n);

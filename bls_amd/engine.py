@@ -668,7 +668,7 @@ OPS = dict(FQ_MUL=1, FQ_SQR=2, FQ_ADD=3, FQ_SUB=4, FQ_NEG=5, FQ_INV=6, FQ_SQRT=7
            FQ12_MUL=48, FQ12_SQR=49, FQ12_INV=50, FQ12_FROB1=51, FQ12_FROB2=52, FQ12_FROB3=53, FQ12_CYCLO_SQR=54, FQ12_CYCLO_RUN16=55,
            FQ12_MUL_BY_014=56, FQ12_MUL_BY_LINE_PAIR=57,
            G1_DOUBLE=64, G1_ADD=65, G2_DOUBLE=66, G2_ADD=67, SWU_G1=68, SWU_G2=69,
-           ROW_DBL_STEP=80, ROW_DBL_STEP_REF=81, ROW_ADD_STEP=82, ROW_ADD_STEP_REF=83)
+           ROW_DBL_STEP=80, ROW_DBL_STEP_REF=81, ROW_ADD_STEP=82, ROW_ADD_STEP_REF=83, ROW_G2_DOUBLE=84, ROW_G2_ADD=85, ROW_CLEAR_H2=86)
 
 
 LANE_PAIR = 0x100

@@ -71,7 +71,7 @@ void blsmi_shutdown(void);
  * before binding by hand.  0.5 adds blsmi_trim / blsmi_held_bytes, the *_ex forms of mul / msm (per-call BLSMI_MUL_ANY_POINT),
  * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes.  0.6 adds the *_jac forms
  * (the reference's in-memory Jacobian / Montgomery points at the boundary); no existing prototype changes.  0.7 adds blsmi_set_row_threshold (the lane-row layout for
- * 2 048 .. 8 192 tuples), the "row_side" option and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP for blsmi_debug_op; no existing prototype changes. */
+ * 2 048 .. 8 192 tuples), the "row_side" / "hash_row_min" / "hash_row_max" options and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP / BLSMI_OP_ROW_G2_* / BLSMI_OP_ROW_CLEAR_H2 for blsmi_debug_op; no existing prototype changes. */
 const char *blsmi_version(void);
 
 /* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
@@ -131,7 +131,9 @@ int blsmi_prefer_cpu(int shape, size_t n);
  * switched while running (atomically; a call in flight sees the old or the new value), through blsmi_set_option(name, value):
  *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0),
  *   "lat_rolled" (BLSMI_LAT_ROLLED, default 1; 0: small Pairing calls run the straight-line copy of their level program instead of the one
- *   whose squaring runs are loops).
+ *   whose squaring runs are loops), "row_side" (BLSMI_ROW_SIDE, default 1: a g1pubs Verify in the row layout runs its signature side beside the hash),
+ *   "hash_row_min" / "hash_row_max" (defaults 2048 / 6144; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
+ *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 4 096 messages) instead of a lane pair per message; max 0: never.
  * Layout by what the DEVICE carries (blsmi 0.6): the hand-overs above are a lone caller's.  Calls that arrive together share the chip, and
  * under load the quad kernels serve 2.7x the tuples per second of the one-tuple-per-wave path, so a pairing / verify call of at least
  * "crowd_floor" tuples (BLSMI_CROWD_FLOOR, default 1536) takes them when its tuples plus those of the other calls in flight on its device pass
@@ -416,7 +418,11 @@ enum blsmi_debug_op {
     BLSMI_OP_SWU_G1 = 68 /* t in word 0 of a 3-Fq record -> (x, y, 0) */, BLSMI_OP_SWU_G2 /* t in words 0-1 of a 6-Fq record -> (x, y, 0) */,
     /* with BLSMI_OP_LANE_ROW only: one step of the homogeneous Miller loop on a 12-Fq record (X, Y, Z of the running point: Fq2 each; xq, yq of Q:
      * Fq2 each; xP, yP: Fq each) -> (X3, Y3, Z3, c0, c1, c4): the new point and the line at P.  _REF: the lane-pair routine the row form restates */
-    BLSMI_OP_ROW_DBL_STEP = 80, BLSMI_OP_ROW_DBL_STEP_REF, BLSMI_OP_ROW_ADD_STEP, BLSMI_OP_ROW_ADD_STEP_REF
+    BLSMI_OP_ROW_DBL_STEP = 80, BLSMI_OP_ROW_DBL_STEP_REF, BLSMI_OP_ROW_ADD_STEP, BLSMI_OP_ROW_ADD_STEP_REF,
+    /* with BLSMI_OP_LANE_ROW only: G2 Jacobian arithmetic of the row layout's HashG2 tail (row_g2.inc) on a 12-Fq record (X1, Y1, Z1, X2, Y2, Z2: Fq2 each)
+     * -> (X3, Y3, Z3, 0, 0, 0): g2.go:389-443 of the first point, g2.go:446-529 of both WITHOUT the special cases (infinity or equal x give Z3 = 0),
+     * hash.go:368-389 of the first point */
+    BLSMI_OP_ROW_G2_DOUBLE = 84, BLSMI_OP_ROW_G2_ADD, BLSMI_OP_ROW_CLEAR_H2
 };
 #define BLSMI_OP_LANE_PAIR 0x100 /* OR into an FQ2 / FQ6 / FQ12 op: run it in the lane-pair layout of the pairing kernels */
 #define BLSMI_OP_LANE_QUAD 0x200 /* OR into an FQ12 op: run it in the lane-quad layout (four lanes per tuple, k_pairing_quad.hip) */

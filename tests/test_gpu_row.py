@@ -258,3 +258,64 @@ def test_verify_aggregate_miller_loops_in_the_row_layout(eng, group):
         assert (t, f) == (True, False) and fn(msgs, allpk.reshape(-1), agg) is True and fn(msgs, bad.reshape(-1), agg) is False
     finally:
         eng.set_row_threshold(*eng.ROW_DEFAULT)
+
+
+def test_hash_g2_cofactor_clearing_in_the_row_layout(eng):
+    """HashG2 (hash.go:391-411) of a few thousand messages: the maps and the 3-isogeny a lane pair per message (k_hash_g2_front), clearH2
+    (hash.go:368-389) sixteen lanes per message (k_clear_h2_row, row_g2.inc).  Same 192 bytes as the lane-pair kernel for every message --
+    ragged messages, a count that is not a multiple of the 4-message workgroups --, samples against the oracle; the row Jacobian formulas are
+    the reference's (g2.go:389-529) without their special cases: a message that meets one is flagged and redone by the one-lane routine"""
+    n = 2051
+    msgs = [(b"row hash %d" % i) * (1 + i % 3) for i in range(n)]
+    lib = eng._lib()
+    import bench
+    try:
+        eng.set_option("hash_row_min", 1)
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        a = eng.hash_g2_batch(msgs)
+        lib.blsmi_set_profiling(0)
+        assert "k_clear_h2_row" in bench.read_profile(lib)
+        small = eng.hash_g2_batch(msgs[:5])                                  # a ragged workgroup, 1 .. 4 messages a wave
+        one = eng.hash_g2_batch(msgs[:1])
+        eng.set_option("hash_row_max", 0)
+        b = eng.hash_g2_batch(msgs)
+    finally:
+        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 6144)
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    assert np.array_equal(small, a[:5]) and np.array_equal(one, a[:1])
+    for i in (0, 1, 3, 4, 1024, n - 2, n - 1):
+        assert a[i].tobytes() == RC.hash_g2(msgs[i]), i
+
+
+def test_row_g2_jacobian_arithmetic_against_the_oracle(eng):
+    """row_g2.inc one operation at a time (blsmi_debug_op, BLSMI_OP_ROW_G2_*): the doubling and the general addition on arbitrary field elements (the
+    formulas are polynomial) against the oracle's g2.go:389-443 / 446-529, bit for bit in Jacobian coordinates; clearH2 of points on E' OUTSIDE the subgroup
+    (what the isogeny hands it) against the pure-Python oracle's hash.go:368-389; and the exceptions the row formulas do not special-case -- infinity in,
+    an addition of a point to itself or to infinity -- leave Z3 = 0, which is what k_clear_h2_row tests before handing the message to the one-lane routine"""
+    from gpu_common import g2_to_jac, rand_z2
+    from test_gpu_round3 import _torsion_points
+    xs = P.XORShift(6107)
+    recs = _rand_rec(xs, 9, 12)
+    got, _ = eng.debug_op("ROW_G2_DOUBLE", recs, lane_row=True)
+    for i in range(9):
+        assert np.array_equal(got[i][:36], RC.g2_double(recs[i][:36])), i
+        assert not got[i][36:].any()
+    got, _ = eng.debug_op("ROW_G2_ADD", recs, lane_row=True)
+    for i in range(9):
+        assert np.array_equal(got[i][:36], RC.g2_add(recs[i][:36], recs[i][36:])), i
+    # the exceptions: (P, P), (P, infinity), (infinity, P) -> Z3 = 0
+    _, g2s = _torsion_points()
+    pts = g2s[:3] + [rand_g2(xs) for _ in range(2)]
+    jp = [np.frombuffer(g2_to_jac(w, rand_z2(xs)), dtype=np.uint64) for w in pts]
+    inf = np.concatenate([jp[0][:24], np.zeros(12, np.uint64)])
+    exc = np.stack([np.concatenate([jp[0], jp[0]]), np.concatenate([jp[1], inf]), np.concatenate([inf, jp[2]])])
+    got, _ = eng.debug_op("ROW_G2_ADD", exc, lane_row=True)
+    assert not got[:, 24:36].any()
+    # clearH2: the affine image of the result is the oracle's; Z = 0 in, Z = 0 out
+    cl = np.stack([np.concatenate([j, j]) for j in jp] + [np.concatenate([inf, inf])])
+    got, _ = eng.debug_op("ROW_CLEAR_H2", cl, lane_row=True)
+    f2 = lambda w: tuple((int.from_bytes(w[96 * k:96 * k + 48], "big"), int.from_bytes(w[96 * k + 48:96 * k + 96], "big")) for k in range(2))
+    for i, w in enumerate(pts):
+        assert f2(RC.g2_jac_to_affine_bytes(got[i][:36])) == P.clear_h2(f2(w)), i
+    assert not got[len(pts)][24:36].any()
