@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.path.join(_HERE, "libblsmi.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "blsmi.h")
 # translation units of libblsmi.so: the host side + one unit per kernel family, compiled in parallel
-_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_pairing_row.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_fq12_single.hip", "k_hash.hip", "k_wire.hip", "k_hash_pair.hip", "k_curve.hip", "k_msm_pair.hip", "k_lat.hip", "k_util.hip"]
+_UNITS = ["blsmi.hip", "k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_pairing_row.hip", "k_prepared_pair.hip", "k_pairing_single.hip", "k_fe_single.hip", "k_fq12_single.hip", "k_hash.hip", "k_wire.hip", "k_hash_pair.hip", "k_hash_quad.hip", "k_curve.hip", "k_msm_pair.hip", "k_lat.hip", "k_util.hip"]
 LAT_BIN = os.path.join(CSRC, "lat_programs.z")            # level programs of the latency path (gen_lat.py), zlib-compressed, embedded into blsmi.hip.o
 BUILD_DIR = os.path.join(CSRC, "build")
 # -Werror=pass-failed: a kernel that misses its declared waves-per-SIMD (a shared device function that outgrew the register budget)
@@ -21,7 +21,7 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=h
 # The lane-pair / lane-quad pairing kernels compute in 14 x 28-bit limbs (fp.cuh: BLSMI_LIMBS28; 196 instead of 225 multiply-adds per
 # product), every other unit in 15 x 27; buffers that cross between kernels keep the 27-bit form.  BLSMI_BUILD_LIMBS27=1 builds those
 # units in 15 x 27 as well (A/B).
-_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_pairing_row.hip", "k_prepared_pair.hip", "k_hash_pair.hip", "k_hash.hip", "k_wire.hip", "k_curve.hip", "k_msm_pair.hip")
+_LIMBS28_UNITS = () if os.environ.get("BLSMI_BUILD_LIMBS27") else ("k_pairing_pair.hip", "k_fe_pair.hip", "k_pairing_quad.hip", "k_pairing_row.hip", "k_prepared_pair.hip", "k_hash_pair.hip", "k_hash_quad.hip", "k_hash.hip", "k_wire.hip", "k_curve.hip", "k_msm_pair.hip")
 
 
 # rough compile cost in seconds (scheduling order only)

@@ -316,7 +316,9 @@ inline size_t call_load(size_t n) {
 // tuples (2 048 .. 8 192) of a LONE caller take it: 4 096 tuples are one wave on every SIMD there (a quarter of the SIMDs in the quad layout, four waves of
 // 3.3 x the instructions on the one-tuple-per-wave path).  When other calls are in flight on the device the choice above stands (the quad
 // kernels spend fewer lane-instructions per tuple: 12.6 M against 18 M).  blsmi_set_row_threshold / BLSMI_ROW_MIN / BLSMI_ROW_MAX; max 0: off.
-std::atomic<size_t> g_hash_row_min{2048}, g_hash_row_max{6144};   // blsmi_set_option("hash_row_min" / "hash_row_max"): HashG2 of this many messages clears its cofactor in the lane-row layout (k_clear_h2_row; max 0: never)
+std::atomic<size_t> g_hash_row_min{2048}, g_hash_row_max{4096};   // blsmi_set_option("hash_row_min" / "hash_row_max"): HashG2 of this many messages clears its cofactor in the lane-row layout (k_clear_h2_row; max 0: never)
+std::atomic<size_t> g_hash_quad_min{4097}, g_hash_quad_max{16384};   // "hash_quad_min" / "hash_quad_max": ... four lanes per message (k_clear_h2_quad)
+std::atomic<size_t> g_hash_g1_quad_min{1280}, g_hash_g1_quad_max{32768};   // "hash_g1_quad_min" / "hash_g1_quad_max": HashG1's tail four lanes per message (k_hash_g1_finish_quad)
 std::atomic<bool> g_row_side{true};     // BLSMI_ROW_SIDE / blsmi_set_option("row_side"): a Verify in the row layout runs its signature side beside the hash (verify_host.inc)
 std::atomic<size_t> g_row_min{2048};   // (tools/midsize4.py: 2 048 pairings 2.08 against 2.21 ms on the wave path, g1pubs verifies 4.45 against 4.72, g2pubs 3.66 against 3.57; 1 024: 2.05 against 1.54)
 std::atomic<size_t> g_row_max{8192};   // (8 192 pairings 4.0 ms against the quad kernels' flat 5.7; 12 288: 6+ against 5.7)
@@ -930,6 +932,10 @@ BLSMI_API int blsmi_set_option(const char* name, long long value) {
     else if (n == "row_side") { set_explicit(X_ROW_SIDE); g_row_side.store(value != 0); }
     else if (n == "hash_row_min") g_hash_row_min.store((size_t)std::max(0LL, value));
     else if (n == "hash_row_max") g_hash_row_max.store((size_t)std::max(0LL, value));
+    else if (n == "hash_g1_quad_min") g_hash_g1_quad_min.store((size_t)std::max(0LL, value));
+    else if (n == "hash_g1_quad_max") g_hash_g1_quad_max.store((size_t)std::max(0LL, value));
+    else if (n == "hash_quad_min") g_hash_quad_min.store((size_t)std::max(0LL, value));
+    else if (n == "hash_quad_max") g_hash_quad_max.store((size_t)std::max(0LL, value));
     else if (n == "combine_mid_max") { set_explicit(X_COMBINE_MID); g_combine_mid_max.store((size_t)std::max(0LL, value)); }
     else if (n == "crowd_floor") { set_explicit(X_CROWD_FLOOR); g_crowd_floor.store((size_t)std::max(0LL, value)); }
     else if (n == "assume_load") g_assume_load.store((size_t)std::max(0LL, value));
@@ -1068,9 +1074,11 @@ BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, ui
     const bool rowl = (op_in & BLSMI_OP_LANE_ROW) != 0;                   // ... in the lane-row layout
     const int op = op_in & ~(BLSMI_OP_LANE_PAIR | BLSMI_OP_LANE_QUAD | BLSMI_OP_LANE_ROW);
     if (pairl && (op < 16 || op >= 64)) return BLSMI_E_ARG;
-    if (quadl && (pairl || rowl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014)) return BLSMI_E_ARG;
+    const bool quadg2 = quadl && op >= BLSMI_OP_ROW_G2_DOUBLE && op <= BLSMI_OP_ROW_CLEAR_H2;   // quad_g2.inc
+    if (quadl && !quadg2 && (pairl || rowl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014)) return BLSMI_E_ARG;
+    if (quadg2 && (pairl || rowl)) return BLSMI_E_ARG;
     const bool rowstep = op >= BLSMI_OP_ROW_DBL_STEP && op <= BLSMI_OP_ROW_CLEAR_H2;
-    if (rowstep && !rowl) return BLSMI_E_ARG;
+    if (rowstep && !rowl && !quadg2) return BLSMI_E_ARG;
     if (rowl && !rowstep && (pairl || op < BLSMI_OP_FQ12_MUL || op > BLSMI_OP_FQ12_MUL_BY_014 || op == BLSMI_OP_FQ12_CYCLO_RUN16)) return BLSMI_E_ARG;
     int width = op < 16 ? 1 : op < 32 ? 2 : op < 48 ? 6 : op < 64 ? 12 : rowstep ? 12 : (op == BLSMI_OP_G1_DOUBLE || op == BLSMI_OP_G1_ADD || op == BLSMI_OP_SWU_G1) ? 3 : 6;
     if (n && (!a || !out)) return BLSMI_E_ARG;
@@ -1084,6 +1092,7 @@ BLSMI_API int blsmi_debug_op(int op_in, const uint64_t* a, const uint64_t* b, ui
     HIPCHK(hipMemsetAsync(dflag.p, 1, n, g_stream));
     dim3 g(nblocks(n)), w(WG);
     if (rowl) hipLaunchKernelGGL(k_debug_row, dim3(rblocks(n)), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
+    else if (quadg2) hipLaunchKernelGGL(k_debug_quad_g2, dim3(qblocks(n)), w, 0, g_stream, op, da.as<u64>(), dout.as<u64>(), n);
     else if (quadl) hipLaunchKernelGGL(k_debug_quad, dim3(qblocks(n)), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
     else if (pairl) hipLaunchKernelGGL(k_debug_pairl, dim3((unsigned)((n + WG / 2 - 1) / (WG / 2))), w, 0, g_stream, op, da.as<u64>(), b ? db.as<u64>() : (const u64*)nullptr, dout.as<u64>(), n);
     else if (op < 16) hipLaunchKernelGGL(k_debug_fq, g, w, 0, g_stream, op, da.as<u64>(), db.as<u64>(), dout.as<u64>(), dflag.as<u8>(), n);

@@ -53,6 +53,17 @@ KERNEL2 k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear, int* speci
     swu_finish_g1(h, p1, p2, clear, t < n ? special : nullptr);
     if (t < n) store_g1(out + 96 * t, h);
 }
+// ... for the messages k_hash_g1_finish_quad (k_hash_quad.hip) flagged: the same tail with the reference's special cases, a message per lane
+KERNEL2 k_hash_g1_finish_redo(const u8* pts, const u8* good, u8* out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
+    const bool mine = t < n && !good[t];
+    if (!__any(mine)) return;
+    const size_t tt = t < n ? t : n - 1;
+    const G1Aff p1 = load_g1(pts + 192 * tt), p2 = load_g1(pts + 192 * tt + 96);
+    G1Aff h;
+    swu_finish_g1(h, p1, p2, 1, nullptr);
+    if (mine) store_g1(out + 96 * t, h);
+}
 KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
     const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
     u32 d[8];

@@ -71,7 +71,7 @@ void blsmi_shutdown(void);
  * before binding by hand.  0.5 adds blsmi_trim / blsmi_held_bytes, the *_ex forms of mul / msm (per-call BLSMI_MUL_ANY_POINT),
  * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes.  0.6 adds the *_jac forms
  * (the reference's in-memory Jacobian / Montgomery points at the boundary); no existing prototype changes.  0.7 adds blsmi_set_row_threshold (the lane-row layout for
- * 2 048 .. 8 192 tuples), the "row_side" / "hash_row_min" / "hash_row_max" options and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP / BLSMI_OP_ROW_G2_* / BLSMI_OP_ROW_CLEAR_H2 for blsmi_debug_op; no existing prototype changes. */
+ * 2 048 .. 8 192 tuples), the "row_side" / "hash_row_min" / "hash_row_max" / "hash_quad_min" / "hash_quad_max" / "hash_g1_quad_min" / "hash_g1_quad_max" options and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP / BLSMI_OP_ROW_G2_* / BLSMI_OP_ROW_CLEAR_H2 for blsmi_debug_op; no existing prototype changes. */
 const char *blsmi_version(void);
 
 /* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
@@ -132,8 +132,11 @@ int blsmi_prefer_cpu(int shape, size_t n);
  *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0),
  *   "lat_rolled" (BLSMI_LAT_ROLLED, default 1; 0: small Pairing calls run the straight-line copy of their level program instead of the one
  *   whose squaring runs are loops), "row_side" (BLSMI_ROW_SIDE, default 1: a g1pubs Verify in the row layout runs its signature side beside the hash),
- *   "hash_row_min" / "hash_row_max" (defaults 2048 / 6144; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
- *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 4 096 messages) instead of a lane pair per message; max 0: never.
+ *   "hash_row_min" / "hash_row_max" (defaults 2048 / 4096; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
+ *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 4 096 messages) instead of a lane pair per message; "hash_quad_min" / "hash_quad_max" (4097 / 16384):
+ *   four lanes per message (k_clear_h2_quad, 3.0 -> 2.4 ms for 16 384 messages: 16 384 g1pubs verifies 10.1 -> 9.4 ms); max 0: never.
+ *   "hash_g1_quad_min" / "hash_g1_quad_max" (1280 / 32768): HashG1 of that many messages runs its tail -- sum, 11-isogeny, cofactor -- four lanes per message
+ *   (k_hash_g1_finish_quad: 0.96 -> 0.48 ms; 4 096 g2pubs verifies 4.35 -> 3.78 ms, 16 384: 8.10 -> 7.57 ms).
  * Layout by what the DEVICE carries (blsmi 0.6): the hand-overs above are a lone caller's.  Calls that arrive together share the chip, and
  * under load the quad kernels serve 2.7x the tuples per second of the one-tuple-per-wave path, so a pairing / verify call of at least
  * "crowd_floor" tuples (BLSMI_CROWD_FLOOR, default 1536) takes them when its tuples plus those of the other calls in flight on its device pass
@@ -446,7 +449,7 @@ int blsmi_debug_hash_tail(int kind, const uint8_t *pts, uint8_t *out, uint8_t *g
 /* the same tail of HashG1 as the THROUGHPUT kernel runs it (k_hash_g1_finish), with (clear != 0) or without the cofactor clearing of hash.go:306-309;
  * *special gets bit 1 when clear == 0 and some message's two mapped points cancel -- the case a large VerifyAggregate's uncleared-hash path hands
  * back to the cleared one. */
-int blsmi_debug_hash_g1_finish(const uint8_t *pts /* n*192 */, int clear, uint8_t *out /* n*96 */, int *special, size_t n);
+int blsmi_debug_hash_g1_finish(const uint8_t *pts /* n*192 */, int clear /* 2: the four-lanes-per-message tail + its redo pass; *special = messages redone */, uint8_t *out /* n*96 */, int *special, size_t n);
 int blsmi_debug_hash_redo(int kind, const uint8_t *msgs, const uint64_t *off_or_domain, const uint8_t *good, uint8_t *out /* in/out */, size_t n);
 
 #ifdef __cplusplus

@@ -277,31 +277,42 @@ def test_hash_g2_cofactor_clearing_in_the_row_layout(eng):
         assert "k_clear_h2_row" in bench.read_profile(lib)
         small = eng.hash_g2_batch(msgs[:5])                                  # a ragged workgroup, 1 .. 4 messages a wave
         one = eng.hash_g2_batch(msgs[:1])
-        eng.set_option("hash_row_max", 0)
+        eng.set_option("hash_row_max", 0); eng.set_option("hash_quad_min", 1)   # four lanes per message (k_clear_h2_quad, quad_g2.inc)
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        q = eng.hash_g2_batch(msgs)
+        lib.blsmi_set_profiling(0)
+        assert "k_clear_h2_quad" in bench.read_profile(lib)
+        qsmall = eng.hash_g2_batch(msgs[:17])
+        eng.set_option("hash_quad_max", 0)
         b = eng.hash_g2_batch(msgs)
     finally:
-        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 6144)
+        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 4096); eng.set_option("hash_quad_min", 4097); eng.set_option("hash_quad_max", 16384)
     bad = np.nonzero((a != b).any(axis=1))[0]
     assert bad.size == 0, bad[:8]
+    bad = np.nonzero((q != b).any(axis=1))[0]
+    assert bad.size == 0, ("quad", bad[:8])
+    assert np.array_equal(qsmall, b[:17])
     assert np.array_equal(small, a[:5]) and np.array_equal(one, a[:1])
     for i in (0, 1, 3, 4, 1024, n - 2, n - 1):
         assert a[i].tobytes() == RC.hash_g2(msgs[i]), i
 
 
-def test_row_g2_jacobian_arithmetic_against_the_oracle(eng):
-    """row_g2.inc one operation at a time (blsmi_debug_op, BLSMI_OP_ROW_G2_*): the doubling and the general addition on arbitrary field elements (the
+@pytest.mark.parametrize("layout", ["row", "quad"])
+def test_row_g2_jacobian_arithmetic_against_the_oracle(eng, layout):
+    """row_g2.inc (sixteen lanes per point) and quad_g2.inc (four: BLSMI_OP_LANE_QUAD with the same ops) one operation at a time (blsmi_debug_op, BLSMI_OP_ROW_G2_*): the doubling and the general addition on arbitrary field elements (the
     formulas are polynomial) against the oracle's g2.go:389-443 / 446-529, bit for bit in Jacobian coordinates; clearH2 of points on E' OUTSIDE the subgroup
     (what the isogeny hands it) against the pure-Python oracle's hash.go:368-389; and the exceptions the row formulas do not special-case -- infinity in,
     an addition of a point to itself or to infinity -- leave Z3 = 0, which is what k_clear_h2_row tests before handing the message to the one-lane routine"""
     from gpu_common import g2_to_jac, rand_z2
     from test_gpu_round3 import _torsion_points
+    lay = dict(lane_row=True) if layout == "row" else dict(lane_quad=True)
     xs = P.XORShift(6107)
     recs = _rand_rec(xs, 9, 12)
-    got, _ = eng.debug_op("ROW_G2_DOUBLE", recs, lane_row=True)
+    got, _ = eng.debug_op("ROW_G2_DOUBLE", recs, **lay)
     for i in range(9):
         assert np.array_equal(got[i][:36], RC.g2_double(recs[i][:36])), i
         assert not got[i][36:].any()
-    got, _ = eng.debug_op("ROW_G2_ADD", recs, lane_row=True)
+    got, _ = eng.debug_op("ROW_G2_ADD", recs, **lay)
     for i in range(9):
         assert np.array_equal(got[i][:36], RC.g2_add(recs[i][:36], recs[i][36:])), i
     # the exceptions: (P, P), (P, infinity), (infinity, P) -> Z3 = 0
@@ -310,12 +321,62 @@ def test_row_g2_jacobian_arithmetic_against_the_oracle(eng):
     jp = [np.frombuffer(g2_to_jac(w, rand_z2(xs)), dtype=np.uint64) for w in pts]
     inf = np.concatenate([jp[0][:24], np.zeros(12, np.uint64)])
     exc = np.stack([np.concatenate([jp[0], jp[0]]), np.concatenate([jp[1], inf]), np.concatenate([inf, jp[2]])])
-    got, _ = eng.debug_op("ROW_G2_ADD", exc, lane_row=True)
+    got, _ = eng.debug_op("ROW_G2_ADD", exc, **lay)
     assert not got[:, 24:36].any()
     # clearH2: the affine image of the result is the oracle's; Z = 0 in, Z = 0 out
     cl = np.stack([np.concatenate([j, j]) for j in jp] + [np.concatenate([inf, inf])])
-    got, _ = eng.debug_op("ROW_CLEAR_H2", cl, lane_row=True)
+    got, _ = eng.debug_op("ROW_CLEAR_H2", cl, **lay)
     f2 = lambda w: tuple((int.from_bytes(w[96 * k:96 * k + 48], "big"), int.from_bytes(w[96 * k + 48:96 * k + 96], "big")) for k in range(2))
     for i, w in enumerate(pts):
         assert f2(RC.g2_jac_to_affine_bytes(got[i][:36])) == P.clear_h2(f2(w)), i
     assert not got[len(pts)][24:36].any()
+
+
+def test_hash_g1_tail_four_lanes_per_message(eng):
+    """HashG1 (hash.go:306-331) of a few thousand messages: the two maps on two lanes (k_swu_g1_two_lanes), then the sum, the 11-isogeny and the cofactor
+    clearing FOUR lanes per message (k_hash_g1_finish_quad, quad_g1.inc).  Same 96 bytes as the one-lane tail for every message of a ragged batch, samples
+    against the oracle; on chosen mapped points the exceptions the quad formulas do not special-case -- two points that cancel, two that coincide -- are
+    flagged and redone by the one-lane routine with the reference's special cases (g1.go:400-482)"""
+    import ctypes
+    n = 2051
+    msgs = [(b"quad g1 %d" % i) * (1 + i % 3) for i in range(n)]
+    lib = eng._lib()
+    import bench
+    try:
+        eng.set_option("hash_g1_quad_min", 1)
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        a = eng.hash_g1_batch(msgs)
+        lib.blsmi_set_profiling(0)
+        assert "k_hash_g1_finish_quad" in bench.read_profile(lib)
+        small = eng.hash_g1_batch(msgs[:17])
+        eng.set_option("hash_g1_quad_max", 0)
+        b = eng.hash_g1_batch(msgs)
+    finally:
+        eng.set_option("hash_g1_quad_min", 1280); eng.set_option("hash_g1_quad_max", 32768)
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    assert np.array_equal(small, b[:17])
+    for i in (0, 1, 3, 4, 1024, n - 2, n - 1):
+        assert a[i].tobytes() == RC.hash_g1(msgs[i]), i
+    # chosen mapped points (on the 11-isogenous curve: the SWU unit op on random t)
+    xs = P.XORShift(6108)
+    from gpu_common import pack, rand_fq
+    ts = rand_fq(xs, 12)
+    rec = np.zeros((12, 18), dtype=np.uint64)
+    for i, t in enumerate(ts):
+        rec[i, :6] = pack([t])
+    swu, _ = eng.debug_op("SWU_G1", rec.reshape(-1))
+    pts = [(P.from_mont(P.from_limbs64(swu.reshape(12, 18)[i, :6])), P.from_mont(P.from_limbs64(swu.reshape(12, 18)[i, 6:12]))) for i in range(12)]
+    wire = lambda p: p[0].to_bytes(48, "big") + p[1].to_bytes(48, "big")
+    pairs = [wire(pts[2 * i]) + wire(pts[2 * i + 1]) for i in range(6)]
+    pairs[2] = wire(pts[4]) + wire((pts[4][0], (P.Q - pts[4][1]) % P.Q))      # message 2: p2 = -p1
+    pairs[4] = wire(pts[8]) + wire(pts[8])                                    # message 4: p2 = p1
+    buf = np.frombuffer(b"".join(pairs), dtype=np.uint8)
+
+    def finish(clear):
+        out = np.zeros(96 * 6, dtype=np.uint8); sp = ctypes.c_int(0)
+        assert lib.blsmi_debug_hash_g1_finish(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), clear, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(sp), ctypes.c_size_t(6)) == 0
+        return out.reshape(6, 96), sp.value
+    want, _ = finish(1)
+    got, redone = finish(2)
+    assert redone == 2 and np.array_equal(got, want)

@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "bls_amd", "csrc")
 REV_DPP = re.compile(r"^\s+v_(sub|subb|lshl|lshr|ashr)rev[a-z0-9_]*_dpp\b", re.M)
 
 
-@pytest.mark.parametrize("unit", ["k_pairing_row.hip"])
+@pytest.mark.parametrize("unit", ["k_pairing_row.hip", "k_hash_quad.hip"])
 def test_no_reversed_operand_dpp_instruction(unit, tmp_path):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc) and shutil.which("hipcc") is None:
