@@ -60,6 +60,19 @@ constexpr int VMAX = 1 << 12;          // top limb = value/2^(LB (NL-1)) stays f
 constexpr int VMUL = VU + (VU + 1) / 2;    // bound of a Montgomery product: 2 q, or 3 halves of q (|value| < 1.41 q either way)
 constexpr int VRED = 2 * VU + 1;           // bound of fp_reduce's output: (-1.01 q, 2.01 q)
 #define BLSMI_DEV __device__ __forceinline__
+// The hash kernels of a mid-size Verify are dependent chains on few waves, and the signature side's Miller kernel of the same call runs beside them on a side
+// stream (verify_host.inc: verify_sig_side_start).  Two waves of a SIMD share its VALU issue by priority, then AGE (MI355X guide, "two waves per SIMD"): a hash
+// wave that happens to be the younger one gets the leftover slots and its chain stretches 1.6x (k_hash_g2_front 1.12 -> 1.77 ms), an older one is nearly
+// unimpeded -- which of the two happened was up to the dispatch order (g1pubs, 3 072 tuples: 4.33 or 4.97 ms a call).  The hash kernels therefore raise their
+// priority once at entry; the Miller kernel beside them fills the slots the chains leave.  -DBLSMI_HASH_PRIO=0: off (A/B).
+#ifndef BLSMI_HASH_PRIO
+#define BLSMI_HASH_PRIO 2
+#endif
+__device__ __forceinline__ void hash_prio() {
+#if BLSMI_HASH_PRIO
+    __builtin_amdgcn_s_setprio(BLSMI_HASH_PRIO);
+#endif
+}
 
 template <int L_, int V_>
 struct Fp {
@@ -496,12 +509,12 @@ BLSMI_DEV FpS fp_inv(const Fp<L, V>& a) {
 }
 
 // Square root (fq.go:203-217): a1 = a^((q-3)/4); a0 = a1^2 a; ok iff a0 != -1; root = a1*a.
-template <int L, int V> BLSMI_DEV FpS fp_pow_wave(const Fp<L, V>& x, const u32* ebits, int nbits);   // fp_row.cuh: one limb per lane, wave-uniform x
-template <bool WAVE = false, int L, int V>
+template <int SPREAD, int L, int V> BLSMI_DEV FpS fp_pow_spread(const Fp<L, V>& x, const u32* ebits, int nbits);   // fp_row.cuh: one limb per lane; 1: wave-uniform x, 2: x uniform over each row of sixteen lanes
+template <int WAVE = 0, int L, int V>
 BLSMI_DEV FpS fp_sqrt(const Fp<L, V>& a, bool& ok) {
     const FpS as = fp_store(a);
     FpS a1;
-    if constexpr (WAVE) a1 = fp_pow_wave(as, C_QM3O4, BLSMI_QM3O4_BITS);
+    if constexpr (WAVE != 0) a1 = fp_pow_spread<WAVE>(as, C_QM3O4, BLSMI_QM3O4_BITS);
     else a1 = fp_pow_qm3o4(as);
     const auto a0 = fp_mul(fp_sqr(a1), as);
     ok = !fp_eq(a0, C_NEGONE);

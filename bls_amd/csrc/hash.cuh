@@ -159,7 +159,7 @@ __device__ __noinline__ void swu_g1_helper_ref(G1Aff& out, const FpS& t) {
 //   1/V = chi U V^2 e^2,   x0 = num den^2 / V
 // and for a non-residue g(x0), g(x1) = -t^6 g(x0) = (t^3 y0)^2.  Outputs are the same field elements.
 // WAVE: the whole wave works on ONE t (every lane the same values); the exponentiation then runs with one limb per lane (fp_row.cuh)
-template <bool WAVE>
+template <int WAVE>
 BLSMI_DEV void swu_g1_helper_t(G1Aff& out, const FpS& t) {
     const FpS tsq = fp_store(fp_sqr(t));
     const FpS ndc = fp_store(fp_sub(fp_sqr(tsq), tsq));                   // (-1)^2 t^4 + (-1) t^2
@@ -172,7 +172,7 @@ BLSMI_DEV void swu_g1_helper_t(G1Aff& out, const FpS& t) {
     const FpS V2 = fp_store(fp_sqr(V));
     const FpS UV = fp_store(fp_mul(U, V));
     FpS e;
-    if constexpr (WAVE) e = fp_pow_wave(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
+    if constexpr (WAVE != 0) e = fp_pow_spread<WAVE>(fp_mul(UV, V2), C_QM3O4, BLSMI_QM3O4_BITS);
     else e = fp_pow_qm3o4(fp_mul(UV, V2));
     const FpS y0 = fp_store(fp_mul(UV, e));
     const i32 m0 = fp_eq(fp_mul(fp_sqr(y0), V), U) ? -1 : 0;              // g(x0) is a square
@@ -192,8 +192,9 @@ BLSMI_DEV void swu_g1_helper_t(G1Aff& out, const FpS& t) {
         out.x = fp_select(special, r.x, out.x); out.y = fp_select(special, r.y, out.y);
     }
 }
-__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) { swu_g1_helper_t<false>(out, t); }
-__device__ __noinline__ void swu_g1_helper_wave(G1Aff& out, const FpS& t) { swu_g1_helper_t<true>(out, t); }
+__device__ __noinline__ void swu_g1_helper(G1Aff& out, const FpS& t) { swu_g1_helper_t<0>(out, t); }
+__device__ __noinline__ void swu_g1_helper_wave(G1Aff& out, const FpS& t) { swu_g1_helper_t<1>(out, t); }
+__device__ __noinline__ void swu_g1_helper_row16(G1Aff& out, const FpS& t) { swu_g1_helper_t<2>(out, t); }   // t uniform over each row of sixteen lanes
 template <int N>
 BLSMI_DEV FpS horner_fp(const FpS (&c)[N], const FpS& x) {
     FpS v = c[N - 1];
@@ -303,7 +304,7 @@ __device__ __noinline__ void swu_g2_helper_ref(G2Aff& out, const Fp2S& t) {
 // Same map with TWO exponentiations: g(x0) = U/V as above (over Fq2); its norm is a/b with a = N(U), b = N(V).
 // With w = a b^3, e = w^((q-3)/4):  s0 = a b e has s0^2 = chi * a/b (the norm root fp2_sqrt_from_norm_root needs) and
 // 1/b = chi a b^2 e^2, which yields both x0 = num conj(den) N(den)^2 / b and g(x0) = U conj(V) / b without an inversion.
-template <bool WAVE>
+template <int WAVE>
 BLSMI_DEV void swu_g2_helper_t(G2Aff& out, const Fp2S& t) {
     Fp2S nqr; nqr.c0 = C_ONE; nqr.c1 = C_ONE;
     const Fp2S tsq = fp2_store(fp2_sqr(t));
@@ -321,7 +322,7 @@ BLSMI_DEV void swu_g2_helper_t(G2Aff& out, const Fp2S& t) {
     const FpS aa = fp_store(fp_add(fp_sqr(U.c0), fp_sqr(U.c1)));           // a = N(U)
     const FpS ab = fp_store(fp_mul(aa, bb)), b2 = fp_store(fp_sqr(bb));
     FpS e;
-    if constexpr (WAVE) e = fp_pow_wave(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
+    if constexpr (WAVE != 0) e = fp_pow_spread<WAVE>(fp_mul(ab, b2), C_QM3O4, BLSMI_QM3O4_BITS);
     else e = fp_pow_qm3o4(fp_mul(ab, b2));
     const FpS s0 = fp_store(fp_mul(ab, e));
     const i32 m0 = fp_eq(fp_mul(fp_sqr(s0), bb), aa) ? -1 : 0;             // N(g(x0)) is a square <=> g(x0) is a square
@@ -347,8 +348,9 @@ BLSMI_DEV void swu_g2_helper_t(G2Aff& out, const Fp2S& t) {
         out.x = fp2_select(special, r.x, out.x); out.y = fp2_select(special, r.y, out.y);
     }
 }
-__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<false>(out, t); }
-__device__ __noinline__ void swu_g2_helper_wave(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<true>(out, t); }
+__device__ __noinline__ void swu_g2_helper(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<0>(out, t); }
+__device__ __noinline__ void swu_g2_helper_wave(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<1>(out, t); }
+__device__ __noinline__ void swu_g2_helper_row16(G2Aff& out, const Fp2S& t) { swu_g2_helper_t<2>(out, t); }
 template <int N>
 BLSMI_DEV Fp2S horner_fp2(const Fp2S (&c)[N], const Fp2S& x) {
     Fp2S v = c[N - 1];

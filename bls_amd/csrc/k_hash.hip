@@ -34,6 +34,7 @@ KERNEL k_hash_g2_domain(const u8* msgs32, const u8* domain, u8* out, size_t n) {
 // elements; the curve arithmetic that follows (isogeny, sum, cofactor clearing: wide and shallow) runs as a level program
 // of the latency path (k_lat.hip: hashfin1 / hashfin2 / cofac2), one message per wave.  pts: 2 points per message.
 KERNEL2 k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    hash_prio();
     const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
     u32 d[8];
     sha256_msg(d, 1, 0x01, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
@@ -46,6 +47,7 @@ KERNEL2 k_swu_g1_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
 // start to end -- 16 384 messages are 256 waves and take the 2.0 ms a full chip's 65 536 take; with the two square-root chains of a message
 // on two lanes (k_swu_g1_two_lanes: 512 waves) and this tail behind them the same hash is 0.55 + 0.8 ms.
 KERNEL2 k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear, int* special) {
+    hash_prio();
     const size_t t = (size_t)blockIdx.x * WG + threadIdx.x;
     const size_t tt = t < n ? t : n - 1;
     const G1Aff p1 = load_g1(pts + 192 * tt), p2 = load_g1(pts + 192 * tt + 96);
@@ -65,6 +67,7 @@ KERNEL2 k_hash_g1_finish_redo(const u8* pts, const u8* good, u8* out, size_t n) 
     if (mine) store_g1(out + 96 * t, h);
 }
 KERNEL k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    hash_prio();
     const size_t idx = (size_t)blockIdx.x * WG + threadIdx.x, t = idx >> 1, tt = t < n ? t : n - 1;
     u32 d[8];
     sha256_msg(d, 1, 0x01, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
@@ -90,6 +93,27 @@ __global__ void __launch_bounds__(64) k_swu_g2_waves(const u8* msgs, const u64* 
     G2Aff p;
     swu_g2_helper_wave(p, hp2_from_digest(d, (u32)(idx & 1)));
     if (threadIdx.x == 0) store_g2(pts + 192 * idx, p);
+}
+// ... and with a ROW of sixteen lanes per map (four maps per wave) for calls in between (round 6): above the hand-over of the wave kernels a lane per map
+// (k_swu_g?_two_lanes) takes 0.53 / 1.05 ms whatever the count -- n messages are n / 32 waves -- while 2 n rows are n / 2 waves: every SIMD has one
+// from 2 048 messages.  Every lane of a row computes the same values; the exponentiations run with a limb per lane of the row (fp_row.cuh: fp_pow_row16).
+__global__ void __launch_bounds__(64, 2) k_swu_g1_rows(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    hash_prio();
+    const size_t idx = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 4, t = idx >> 1, tt = t < n ? t : n - 1;
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
+    G1Aff p;
+    swu_g1_helper_row16(p, hp_from_digest(d, (u32)(idx & 1)));
+    if (t < n && !(threadIdx.x & 15)) store_g1(pts + 96 * idx, p);
+}
+__global__ void __launch_bounds__(64) k_swu_g2_rows(const u8* msgs, const u64* off, u8* pts, size_t n) {
+    hash_prio();
+    const size_t idx = ((size_t)blockIdx.x * 64 + threadIdx.x) >> 4, t = idx >> 1, tt = t < n ? t : n - 1;
+    u32 d[8];
+    sha256_msg(d, 1, 0x01, msgs + off[tt], (size_t)(off[tt + 1] - off[tt]));
+    G2Aff p;
+    swu_g2_helper_row16(p, hp2_from_digest(d, (u32)(idx & 1)));
+    if (t < n && !(threadIdx.x & 15)) store_g2(pts + 192 * idx, p);
 }
 // the try-and-increment search of HashG2WithDomain with eight lanes per message (eight candidates per round)
 KERNEL k_tai_g2_lanes8(const u8* msgs32, const u8* domain, u8* pts, size_t n) {

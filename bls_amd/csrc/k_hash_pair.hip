@@ -175,6 +175,7 @@ BLSMI_DEV void hash_g2_pair_front(const u8* msgs, const u64* off, size_t n, unsi
     bad = special | sj.inf | ((redo_every && t % redo_every == 0) ? -1 : 0);
 }
 __global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u64* off, u8* good, u8* out, size_t n, unsigned redo_every) {
+    hash_prio();
     size_t t0, t; int par; P2::G2JacP ij; i32 bad;
     hash_g2_pair_front(msgs, off, n, redo_every, t0, t, par, ij, bad);
     P2::G2AffP r; P2::clear_h2_jac(r, ij);
@@ -191,6 +192,7 @@ __global__ void __launch_bounds__(WG, 2) k_hash_g2_pair(const u8* msgs, const u6
 // the same up to the isogeny, for the row layout's tail (k_pairing_row.hip: k_clear_h2_row): the Jacobian image into `jbuf` (structure of arrays, element
 // 2 c + parity of coordinate c), good[t] = 0 also when the image is the point at infinity
 __global__ void __launch_bounds__(WG, 2) k_hash_g2_front(const u8* msgs, const u64* off, u8* good, i32* jbuf, size_t n, unsigned redo_every) {
+    hash_prio();
     size_t t0, t; int par; P2::G2JacP ij; i32 bad;
     hash_g2_pair_front(msgs, off, n, redo_every, t0, t, par, ij, bad);
     bad |= ij.inf;

@@ -18,6 +18,7 @@ constexpr int QT = WG / 4;                                               // mess
 // A message whose result has Z = 0 -- infinity met on the way, an addition of equal x -- gets good[t] = 0 and is redone by k_hash_g2_redo with the
 // reference's special cases (as k_clear_h2_row, k_pairing_row.hip)
 __global__ void __launch_bounds__(WG, 1) k_clear_h2_quad(const i32* jbuf, u8* good, u8* out, size_t n) {
+    hash_prio();
     const int par = threadIdx.x & 1;
     const size_t t = (size_t)blockIdx.x * QT + (threadIdx.x >> 2);
     const size_t tt = t < n ? t : n - 1;
@@ -36,6 +37,7 @@ __global__ void __launch_bounds__(WG, 1) k_clear_h2_quad(const i32* jbuf, u8* go
 // their sum, the 11-isogeny, the cofactor clearing, the affine record.  1 280 .. 32 768 messages: 0.96 ms in k_hash_g1_finish (a message per lane: 64 .. 256 waves for 4 096 .. 16 384),
 // 0.48 ms here.  good[t] = 0: the message met an exception (Z = 0) and is redone by k_hash_g1_finish_redo
 __global__ void __launch_bounds__(WG, 2) k_hash_g1_finish_quad(const u8* pts, u8* good, u8* out, size_t n) {
+    hash_prio();
     const size_t t = (size_t)blockIdx.x * QT + (threadIdx.x >> 2);
     const size_t tt = t < n ? t : n - 1;
     const Q1Lane ln;

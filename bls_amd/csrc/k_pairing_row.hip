@@ -161,6 +161,7 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
 // with sixteen lanes per message and writes the affine wire record.  A message whose result has Z = 0 -- infinity met on the way, an addition of equal x --
 // gets good[t] = 0 and is redone by k_hash_g2_redo with the reference's special cases.
 KERNEL_ROW k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n) {
+    hash_prio();
     const int par = threadIdx.x & 1;
     const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
     const size_t tt = t < n ? t : n - 1;

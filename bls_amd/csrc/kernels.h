@@ -75,6 +75,8 @@ __global__ void k_hash_g1_finish(const u8* pts, u8* out, size_t n, int clear, in
 __global__ void k_swu_g2_two_lanes(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g1_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_swu_g2_waves(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_swu_g1_rows(const u8* msgs, const u64* off, u8* pts, size_t n);
+__global__ void k_swu_g2_rows(const u8* msgs, const u64* off, u8* pts, size_t n);
 __global__ void k_tai_g2_lanes8(const u8* msgs32, const u8* domain, u8* pts, size_t n);
 __global__ void k_tai_g2_waves8(const u8* msgs32, const u8* domain, u8* pts, size_t n);
 __global__ void k_hash_g1_redo(const u8* msgs, const u64* off, const u8* good, u8* out, size_t n);

@@ -68,3 +68,28 @@ def test_decompression_on_both_sides_of_the_wave_hand_over(eng):
     for i in (0, 1, 2, 6, 7):
         assert out[i].tobytes() == g1[i] and not inf[i] and err[i] == 0
     assert inf[3] and err[3] == 0 and err[5] in (3, 4)
+
+
+def test_hash_to_curve_with_a_row_of_sixteen_lanes_per_map(eng):
+    """Between the wave kernels and the lane kernels (513 .. swu_row_max messages) the SWU maps run four per wave, an exponentiation per DPP row
+    (k_swu_g{1,2}_rows, fp_row.cuh: fp_pow_row16).  Same points as a lane per map, the oracle judges a sample; ragged counts around the four-row waves."""
+    msgs = _msgs(1027, b"rows") + [b""]
+    try:
+        for fn, oracle in ((eng.hash_g1_batch, RC.hash_g1), (eng.hash_g2_batch, RC.hash_g2)):
+            eng.set_option("swu_row_max", 0)
+            lanes = fn(msgs)
+            eng.set_option("swu_row_max", 4096)
+            for n in (513, 514, 515, 1028):
+                rows = fn(msgs[-n:])
+                assert np.array_equal(rows, lanes[-n:])
+            for i in (0, 1, 2, 3, 511, 1026, 1027):
+                assert lanes[i].tobytes() == oracle(msgs[i])
+        # HashG1 above the four-lane tail's floor (1 280): the other dispatch branch
+        big = _msgs(1500, b"rows-big")
+        eng.set_option("swu_row_max", 0); lanes = eng.hash_g1_batch(big)
+        eng.set_option("swu_row_max", 4096); rows = eng.hash_g1_batch(big)
+        assert np.array_equal(rows, lanes)
+        for i in (0, 777, 1499):
+            assert rows[i].tobytes() == RC.hash_g1(big[i])
+    finally:
+        eng.set_option("swu_row_max", 4096)
