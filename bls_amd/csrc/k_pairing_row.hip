@@ -73,15 +73,16 @@ KERNEL_ROW k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0, con
 // record; `pre`: Q is the generator, its prepared lines), and the other pair's loop multiplies its value into the first one's (k_miller1m_row;
 // P is negated there, as in k_miller2_row).  The product of the two Miller values is the two-pair loop's value up to nothing: each loop squares its
 // own accumulator, (f_a f_b) is what the shared squarings compute.
-KERNEL_ROW k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n, const i32* pre) {
+// [first, end): the tuples of THIS launch (the side stream runs a call of more than 4 096 tuples in pieces of one wave per SIMD, verify_host.inc); n: tuples in fbuf
+KERNEL_ROW k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n, const i32* pre, size_t first, size_t end) {
     const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;
-    const size_t t = (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
-    const size_t tt = t < n ? t : n - 1;
+    const size_t t = first + (size_t)blockIdx.x * RT + (threadIdx.x >> 4);
+    const size_t tt = t < end ? t : end - 1;
     const FpS px = load_be48(p + sp * tt), py = load_be48(p + sp * tt + 48);
     P2::R12 f;
     if (pre) P2::miller_loop_table_r(f, px, py, pre);
     else P2::miller_loop_r(f, px, py, P2::RQ{q + sq * tt, par});
-    if (t < n) row_store12(fbuf, n, t, pr, par, f);
+    if (t < end) row_store12(fbuf, n, t, pr, par, f);
 }
 KERNEL_ROW k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n) {
     const int par = threadIdx.x & 1, pr = (threadIdx.x >> 1) & 7;

@@ -46,7 +46,7 @@ __global__ void k_debug_quad(int op, const u64* a, const u64* b, u64* out, size_
 __global__ void k_miller1h_row(const u8* g1, const u8* g2, i32* fbuf, size_t n);
 __global__ void k_final_exp_row(const i32* fbuf, u64* out, size_t n, int mode);
 __global__ void k_miller2_row(const u8* p0, size_t sp0, const u8* q0, size_t sq0, const u8* p1, size_t sp1, const u8* q1, size_t sq1, i32* fbuf, size_t n, const i32* pre);
-__global__ void k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n, const i32* pre);
+__global__ void k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n, const i32* pre, size_t first, size_t end);
 __global__ void k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n);
 __global__ void k_final_exp_is_one_row(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
 __global__ void k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n);

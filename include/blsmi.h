@@ -132,9 +132,13 @@ int blsmi_prefer_cpu(int shape, size_t n);
  *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0),
  *   "lat_rolled" (BLSMI_LAT_ROLLED, default 1; 0: small Pairing calls run the straight-line copy of their level program instead of the one
  *   whose squaring runs are loops), "row_side" (BLSMI_ROW_SIDE, default 1: a g1pubs Verify in the row layout runs its signature side beside the hash),
- *   "hash_row_min" / "hash_row_max" (defaults 2048 / 4096; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
- *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 4 096 messages) instead of a lane pair per message; "hash_quad_min" / "hash_quad_max" (4097 / 16384):
- *   four lanes per message (k_clear_h2_quad, 3.0 -> 2.4 ms for 16 384 messages: 16 384 g1pubs verifies 10.1 -> 9.4 ms); max 0: never.
+ *   "hash_row_min" / "hash_row_max" (defaults 2048 / 3840; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
+ *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 3 072 messages) instead of a lane pair per message; "hash_quad_min" / "hash_quad_max" (3841 / 16384):
+ *   four lanes per message (k_clear_h2_quad, 3.0 -> 2.4 ms for 16 384 messages: 16 384 g1pubs verifies 10.1 -> 9.3 ms); max 0: never.
+ *   "swu_row_max" (4096): the SWU maps of HashG1 / HashG2 of BLSMI_SWU_WAVE_MAX < n <= swu_row_max messages run a row of sixteen lanes per map (k_swu_g?_rows:
+ *   k_swu_g1 0.54 -> 0.24 ms up to 2 048 messages) unless the signature side's kernel runs beside the hash; 0: never.
+ *   "row_side_g2pubs" (1): a g2pubs Verify in the row layout runs its signature side beside the hash as g1pubs does ("row_side"); "row_side_piece" (0 = one launch): the side
+ *   kernel in launches of that many tuples (measured slower: a piece of 2 048 tuples takes the time of a piece of 4 096).
  *   "hash_g1_quad_min" / "hash_g1_quad_max" (1280 / 32768): HashG1 of that many messages runs its tail -- sum, 11-isogeny, cofactor -- four lanes per message
  *   (k_hash_g1_finish_quad: 0.96 -> 0.48 ms; 4 096 g2pubs verifies 4.35 -> 3.78 ms, 16 384: 8.10 -> 7.57 ms).
  * Layout by what the DEVICE carries (blsmi 0.6): the hand-overs above are a lone caller's.  Calls that arrive together share the chip, and

@@ -161,7 +161,7 @@ def test_layout_follows_the_load_of_the_device(eng, group):
         return "k_miller2_row" in prof or "k_miller1m_row" in prof or "k_miller1s_row" in prof or "k_final_exp_is_one_row" in prof
     try:
         (ok, _), prof = call(lambda: fn(M, A, B))
-        assert list(ok) == want and ("k_miller2_row" if group == "g2pubs" else "k_miller1m_row") in prof and not quad(prof), prof      # alone: the lane-row layout since round 6 (2 304 .. 8 192 tuples; the wave path below)
+        assert list(ok) == want and "k_miller1m_row" in prof and not quad(prof), prof      # alone: the lane-row layout since round 6 (2 304 .. 8 192 tuples; the wave path below)
         eng.set_option("assume_load", 4000)
         (ok, _), prof = call(lambda: fn(M, A, B))
         assert list(ok) == want and quad(prof) and not row(prof) and "k_lat:verify" not in prof and "k_lat:hashfin" not in prof, prof

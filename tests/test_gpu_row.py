@@ -145,9 +145,9 @@ def _g1pubs_tuples(n, seed, every):
 @pytest.mark.parametrize("side", [1, 0])
 @pytest.mark.parametrize("group", ["g2pubs", "g1pubs"])
 def test_verify_in_the_row_layout(eng, group, side):
-    """Verify of both packages forced into the row kernels: the oracle's verdict table, ragged sizes.  g2pubs: one two-pair loop with the
-    generator's prepared lines (k_miller2_row).  g1pubs, side = 1 (the default): the signature side's Miller loop on a side stream beside the
-    hash (k_miller1s_row), then k_miller1m_row times that value; side = 0: the two-pair loop.  k_final_exp_is_one_row either way"""
+    """Verify of both packages forced into the row kernels: the oracle's verdict table, ragged sizes.  side = 1 (the default): the signature side's
+    Miller loop on a side stream beside the hash (k_miller1s_row; g2pubs: over the generator's prepared lines), then k_miller1m_row times that value;
+    side = 0: one two-pair loop (k_miller2_row).  k_final_exp_is_one_row either way"""
     msgs, pks, sigs, expect = (_g2pubs_tuples if group == "g2pubs" else _g1pubs_tuples)(13, 6103, 3)
     o = RC.g2pubs if group == "g2pubs" else RC.g1pubs
     assert [o.verify(m, p, s) for m, p, s in zip(msgs, pks, sigs)] == expect
@@ -157,8 +157,11 @@ def test_verify_in_the_row_layout(eng, group, side):
         for m in (1, 4, 5, 13):
             ok, _ = fn(msgs[:m], b"".join(pks[:m]), b"".join(sigs[:m]))
             assert list(ok) == expect[:m], (group, m, side)
+        eng.set_option("row_side_piece", 4)                                  # the side kernel in pieces: 4 + 4 + 4 + 1 tuples
+        ok, _ = fn(msgs, b"".join(pks), b"".join(sigs))
+        assert list(ok) == expect, (group, side, "pieces")
     finally:
-        eng.set_row_threshold(*eng.ROW_DEFAULT); eng.set_option("row_side", 1)
+        eng.set_row_threshold(*eng.ROW_DEFAULT); eng.set_option("row_side", 1); eng.set_option("row_side_piece", 0)
 
 
 def test_row_layout_at_its_design_size(eng):
@@ -200,8 +203,19 @@ def test_row_layout_at_its_design_size(eng):
     ok, _ = eng.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
     lib.blsmi_set_profiling(0)
     prof = bench.read_profile(lib)
-    assert "k_miller2_row" in prof and "k_final_exp_is_one_row" in prof, prof
+    assert "k_miller1m_row" in prof and "k_final_exp_is_one_row" in prof, prof     # (the signature side beside the hash: verify_host.inc, verify_sig_side_start)
     assert list(ok) == expect
+    try:                                                                    # the side kernel in ragged pieces (as a call of more than 4 096 tuples runs it), and the two-pair loop
+        eng.set_option("row_side_piece", 1000)
+        ok2, _ = eng.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
+        eng.set_option("row_side_g2pubs", 0)
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        ok3, _ = eng.g2pubs_verify_batch(msgs, allpk.reshape(-1), sigs.reshape(-1))
+        lib.blsmi_set_profiling(0)
+        assert "k_miller2_row" in bench.read_profile(lib)
+    finally:
+        eng.set_option("row_side_piece", 0); eng.set_option("row_side_g2pubs", 1)
+    assert list(ok2) == expect and list(ok3) == expect
     for i in (0, 6, 4095):
         assert RC.g2pubs.verify(msgs[i], allpk[i].tobytes(), sigs[i].tobytes()) == expect[i]
 
@@ -286,7 +300,7 @@ def test_hash_g2_cofactor_clearing_in_the_row_layout(eng):
         eng.set_option("hash_quad_max", 0)
         b = eng.hash_g2_batch(msgs)
     finally:
-        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 4096); eng.set_option("hash_quad_min", 4097); eng.set_option("hash_quad_max", 16384)
+        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 3840); eng.set_option("hash_quad_min", 3841); eng.set_option("hash_quad_max", 16384)
     bad = np.nonzero((a != b).any(axis=1))[0]
     assert bad.size == 0, bad[:8]
     bad = np.nonzero((q != b).any(axis=1))[0]
