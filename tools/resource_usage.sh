@@ -4,8 +4,8 @@
 OUT=${1:-/tmp/kernel_resource_usage.txt}
 cd "$(dirname "$0")/../bls_amd/csrc" || exit 1
 : > "$OUT.tmp"
-UNITS="k_pairing_pair k_fe_pair k_pairing_quad k_prepared_pair k_pairing_single k_fe_single k_fq12_single k_hash k_wire k_hash_pair k_curve k_msm_pair k_lat k_util"
-L28=" k_pairing_pair k_fe_pair k_pairing_quad k_prepared_pair k_hash k_wire k_hash_pair k_curve k_msm_pair "    # the 14 x 28-bit units (bls_amd/_native.py: _LIMBS28_UNITS)
+UNITS="k_pairing_pair k_fe_pair k_pairing_quad k_pairing_row k_prepared_pair k_pairing_single k_fe_single k_fq12_single k_hash k_wire k_hash_pair k_hash_quad k_curve k_msm_pair k_lat k_util"
+L28=" k_pairing_pair k_fe_pair k_pairing_quad k_pairing_row k_prepared_pair k_hash k_wire k_hash_pair k_hash_quad k_curve k_msm_pair "    # the 14 x 28-bit units (bls_amd/_native.py: _LIMBS28_UNITS)
 for u in $UNITS; do
   [ -f $u.hip ] || continue
   F=""; case "$L28" in *" $u "*) F="-DBLSMI_LIMBS28";; esac
