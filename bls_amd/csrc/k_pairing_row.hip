@@ -159,8 +159,8 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
 
 // ---- the tail of HashG2 for a few thousand messages (row_g2.inc): k_hash_g2_front (k_hash_pair.hip) leaves the isogeny's Jacobian image of every message in `jbuf`
 // (6 Fq per message, structure of arrays like the Miller-loop hand-off; element 2 c + parity of coordinate c) and good[t]; this kernel clears the cofactor
-// with sixteen lanes per message and writes the affine wire record.  A message whose result has Z = 0 -- infinity met on the way, an addition of equal x --
-// gets good[t] = 0 and is redone by k_hash_g2_redo with the reference's special cases.
+// with sixteen lanes per message and writes the affine wire record.  A message whose result is the point at infinity (Z = 0) gets good[t] = 0 and is
+// redone by k_hash_g2_redo, which follows the reference's special cases.
 KERNEL_ROW k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n) {
     hash_prio();
     const int par = threadIdx.x & 1;
@@ -168,9 +168,9 @@ KERNEL_ROW k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n) {
     const size_t tt = t < n ? t : n - 1;
     P2::RJ p;
     p.x = P2::wrap(soa_load(jbuf, n, tt, 0 + par)); p.y = P2::wrap(soa_load(jbuf, n, tt, 2 + par)); p.z = P2::wrap(soa_load(jbuf, n, tt, 4 + par));
-    const P2::RJ r = P2::r_clear_h2(p);
+    const P2::RH r = P2::r_clear_h2_hom(P2::r_jac_to_hom(p));              // homogeneous coordinates on the way: two product times a step (row_g2.inc)
     P2::Fp2S ax, ay; bool zero;
-    P2::r_jto_affine(r, ax, ay, zero);
+    P2::r_hto_affine(r, ax, ay, zero);
     if (t < n && (threadIdx.x & 14) == 0) {                                 // pair 0 of the row writes: x.c_par at +48 par, y.c_par at +96 + 48 par
         if (zero) { if (!par) good[t] = 0; }
         else if (good[t]) { u8* o = out + 192 * t; store_be48(o + 48 * par, ax.c); store_be48(o + 96 + 48 * par, ay.c); }

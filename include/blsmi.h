@@ -132,8 +132,8 @@ int blsmi_prefer_cpu(int shape, size_t n);
  *   "agg_cofactor_pow" (BLSMI_AGG_COFACTOR_POW, default 1), "msm_sort" (BLSMI_MSM_SORT, default 1), "dup_force_sort" (BLSMI_DUP_FORCE_SORT, 0),
  *   "lat_rolled" (BLSMI_LAT_ROLLED, default 1; 0: small Pairing calls run the straight-line copy of their level program instead of the one
  *   whose squaring runs are loops), "row_side" (BLSMI_ROW_SIDE, default 1: a g1pubs Verify in the row layout runs its signature side beside the hash),
- *   "hash_row_min" / "hash_row_max" (defaults 2048 / 3840; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
- *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 3 072 messages) instead of a lane pair per message; "hash_quad_min" / "hash_quad_max" (3841 / 16384):
+ *   "hash_row_min" / "hash_row_max" (defaults 2048 / 4096; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
+ *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 3 072 messages) instead of a lane pair per message; "hash_quad_min" / "hash_quad_max" (4097 / 16384):
  *   four lanes per message (k_clear_h2_quad, 3.0 -> 2.4 ms for 16 384 messages: 16 384 g1pubs verifies 10.1 -> 9.3 ms); max 0: never.
  *   "swu_row_max" (4096): the SWU maps of HashG1 / HashG2 of BLSMI_SWU_WAVE_MAX < n <= swu_row_max messages run a row of sixteen lanes per map (k_swu_g?_rows:
  *   k_swu_g1 0.54 -> 0.24 ms up to 2 048 messages) unless the signature side's kernel runs beside the hash; 0: never.

@@ -300,7 +300,7 @@ def test_hash_g2_cofactor_clearing_in_the_row_layout(eng):
         eng.set_option("hash_quad_max", 0)
         b = eng.hash_g2_batch(msgs)
     finally:
-        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 3840); eng.set_option("hash_quad_min", 3841); eng.set_option("hash_quad_max", 16384)
+        eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 4096); eng.set_option("hash_quad_min", 4097); eng.set_option("hash_quad_max", 16384)
     bad = np.nonzero((a != b).any(axis=1))[0]
     assert bad.size == 0, bad[:8]
     bad = np.nonzero((q != b).any(axis=1))[0]

@@ -14,7 +14,7 @@ lib = _native.load()
 dev = torch.device("cuda", 0)
 sizes = [int(x) for x in sys.argv[1:]] or [2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768]
 nmax = max(sizes)
-TAILS = (("pair", (1, 0), (1, 0)), ("row", (1, 1 << 20), (1, 0)), ("quad", (1, 0), (1, 1 << 20)), ("shipped", (2048, 3840), (3841, 16384)))
+TAILS = (("pair", (1, 0), (1, 0)), ("row", (1, 1 << 20), (1, 0)), ("quad", (1, 0), (1, 1 << 20)), ("shipped", (2048, 4096), (4097, 16384)))
 
 
 def timed(step, reps=5):
