@@ -321,6 +321,7 @@ std::atomic<size_t> g_hash_quad_min{4097}, g_hash_quad_max{16384};   // "hash_qu
 std::atomic<size_t> g_hash_g1_quad_min{1280}, g_hash_g1_quad_max{32768};   // "hash_g1_quad_min" / "hash_g1_quad_max": HashG1's tail four lanes per message (k_hash_g1_finish_quad)
 std::atomic<size_t> g_swu_row_max{4096};   // "swu_row_max": the SWU maps of HashG1 / HashG2 run a ROW of sixteen lanes per map (k_swu_g?_rows) above BLSMI_SWU_WAVE_MAX and up to here; 0: never
 std::atomic<size_t> g_row_side_piece{0};   // "row_side_piece": the side stream runs its row kernel in launches of this many tuples (0, the default: one launch -- pieces measured slower, verify_host.inc)
+std::atomic<size_t> g_row_side_lds{0};   // "row_side_lds": bytes of (unused) LDS per workgroup of the side kernel of a call of more than 4 096 tuples -- 40960: four workgroups a CU, a wave slot of every SIMD left to the hash; measured slower (verify_host.inc); 0, the default: none
 std::atomic<bool> g_row_side_g2pubs{true};   // "row_side_g2pubs": ... for g2pubs too (the signature side over the generator's table as a kernel of its own; measured, see verify_host.inc)
 std::atomic<bool> g_row_side{true};     // BLSMI_ROW_SIDE / blsmi_set_option("row_side"): a Verify in the row layout runs its signature side beside the hash (verify_host.inc)
 std::atomic<size_t> g_row_min{2048};   // (tools/midsize4.py: 2 048 pairings 2.08 against 2.21 ms on the wave path, g1pubs verifies 4.45 against 4.72, g2pubs 3.66 against 3.57; 1 024: 2.05 against 1.54)
@@ -934,6 +935,7 @@ BLSMI_API int blsmi_set_option(const char* name, long long value) {
     else if (n == "crowd_quad") { set_explicit(X_CROWD_QUAD); g_crowd_quad.store(value != 0); }
     else if (n == "row_side") { set_explicit(X_ROW_SIDE); g_row_side.store(value != 0); }
     else if (n == "row_side_g2pubs") g_row_side_g2pubs.store(value != 0);
+    else if (n == "row_side_lds") g_row_side_lds.store((size_t)std::min(65536LL, std::max(0LL, value)));
     else if (n == "row_side_piece") g_row_side_piece.store((size_t)std::max(0LL, value));
     else if (n == "hash_row_min") g_hash_row_min.store((size_t)std::max(0LL, value));
     else if (n == "hash_row_max") g_hash_row_max.store((size_t)std::max(0LL, value));

@@ -138,7 +138,8 @@ int blsmi_prefer_cpu(int shape, size_t n);
  *   "swu_row_max" (4096): the SWU maps of HashG1 / HashG2 of BLSMI_SWU_WAVE_MAX < n <= swu_row_max messages run a row of sixteen lanes per map (k_swu_g?_rows:
  *   k_swu_g1 0.54 -> 0.24 ms up to 2 048 messages) unless the signature side's kernel runs beside the hash; 0: never.
  *   "row_side_g2pubs" (1): a g2pubs Verify in the row layout runs its signature side beside the hash as g1pubs does ("row_side"); "row_side_piece" (0 = one launch): the side
- *   kernel in launches of that many tuples (measured slower: a piece of 2 048 tuples takes the time of a piece of 4 096).
+ *   kernel in launches of that many tuples (measured slower: a piece of 2 048 tuples takes the time of a piece of 4 096); "row_side_lds" (0): bytes of unused LDS per
+ *   workgroup of that kernel when the call has more than 4 096 tuples (40960 keeps a wave slot of every SIMD free for the hash; measured slower too).
  *   "hash_g1_quad_min" / "hash_g1_quad_max" (1280 / 32768): HashG1 of that many messages runs its tail -- sum, 11-isogeny, cofactor -- four lanes per message
  *   (k_hash_g1_finish_quad: 0.96 -> 0.48 ms; 4 096 g2pubs verifies 4.35 -> 3.78 ms, 16 384: 8.10 -> 7.57 ms).
  * Layout by what the DEVICE carries (blsmi 0.6): the hand-overs above are a lone caller's.  Calls that arrive together share the chip, and
