@@ -318,6 +318,7 @@ inline size_t call_load(size_t n) {
 // kernels spend fewer lane-instructions per tuple: 12.6 M against 18 M).  blsmi_set_row_threshold / BLSMI_ROW_MIN / BLSMI_ROW_MAX; max 0: off.
 std::atomic<size_t> g_hash_row_min{2048}, g_hash_row_max{4096};   // blsmi_set_option("hash_row_min" / "hash_row_max"): HashG2 of this many messages clears its cofactor in the lane-row layout (k_clear_h2_row; max 0: never)
 std::atomic<size_t> g_hash_quad_min{4097}, g_hash_quad_max{16384};   // "hash_quad_min" / "hash_quad_max": ... four lanes per message (k_clear_h2_quad)
+std::atomic<size_t> g_hash_oct_min{2048}, g_hash_oct_max{7168};   // "hash_oct_min" / "hash_oct_max": ... eight lanes per message (k_clear_h2_oct, oct_g2.inc); takes precedence over the row and quad tails
 std::atomic<size_t> g_hash_g1_quad_min{1280}, g_hash_g1_quad_max{32768};   // "hash_g1_quad_min" / "hash_g1_quad_max": HashG1's tail four lanes per message (k_hash_g1_finish_quad)
 std::atomic<size_t> g_swu_row_max{4096};   // "swu_row_max": the SWU maps of HashG1 / HashG2 run a ROW of sixteen lanes per map (k_swu_g?_rows) above BLSMI_SWU_WAVE_MAX and up to here; 0: never
 std::atomic<size_t> g_row_side_piece{0};   // "row_side_piece": the side stream runs its row kernel in launches of this many tuples (0, the default: one launch -- pieces measured slower, verify_host.inc)
@@ -940,6 +941,8 @@ BLSMI_API int blsmi_set_option(const char* name, long long value) {
     else if (n == "hash_row_min") g_hash_row_min.store((size_t)std::max(0LL, value));
     else if (n == "hash_row_max") g_hash_row_max.store((size_t)std::max(0LL, value));
     else if (n == "swu_row_max") g_swu_row_max.store((size_t)std::max(0LL, value));
+    else if (n == "hash_oct_min") g_hash_oct_min.store((size_t)std::max(0LL, value));
+    else if (n == "hash_oct_max") g_hash_oct_max.store((size_t)std::max(0LL, value));
     else if (n == "hash_g1_quad_min") g_hash_g1_quad_min.store((size_t)std::max(0LL, value));
     else if (n == "hash_g1_quad_max") g_hash_g1_quad_max.store((size_t)std::max(0LL, value));
     else if (n == "hash_quad_min") g_hash_quad_min.store((size_t)std::max(0LL, value));

@@ -16,6 +16,7 @@ namespace blsmi {
 namespace pairl {
 #include "row_body.inc"
 #include "row_g2.inc"
+#include "oct_g2.inc"
 }  // namespace pairl
 }  // namespace blsmi
 
@@ -155,6 +156,23 @@ KERNEL_ROW k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n) {
     const FpS* cz = reinterpret_cast<const FpS*>(&z);
     if (t0 < n && (threadIdx.x & 14) == 0)
         for (int j = 0; j < 6; j++) store_m384(out + (size_t)6 * (12 * t + 2 * j + par), cz[j]);
+}
+
+// ... and with EIGHT lanes per message, two messages a row (oct_g2.inc): eight messages per 64-lane workgroup
+KERNEL_ROW k_clear_h2_oct(const i32* jbuf, u8* good, u8* out, size_t n) {
+    hash_prio();
+    const int par = threadIdx.x & 1;
+    const size_t t = (size_t)blockIdx.x * (WG / 8) + (threadIdx.x >> 3);
+    const size_t tt = t < n ? t : n - 1;
+    P2::RJ p;
+    p.x = P2::wrap(soa_load(jbuf, n, tt, 0 + par)); p.y = P2::wrap(soa_load(jbuf, n, tt, 2 + par)); p.z = P2::wrap(soa_load(jbuf, n, tt, 4 + par));
+    const P2::RH r = P2::o_clear_h2_hom(P2::o_jac_to_hom(p));
+    P2::Fp2S ax, ay; bool zero;
+    P2::o_hto_affine(r, ax, ay, zero);
+    if (t < n && (threadIdx.x & 6) == 0) {                                  // pair 0 of the half writes: x.c_par at +48 par, y.c_par at +96 + 48 par
+        if (zero) { if (!par) good[t] = 0; }
+        else if (good[t]) { u8* o = out + 192 * t; store_be48(o + 48 * par, ax.c); store_be48(o + 96 + 48 * par, ay.c); }
+    }
 }
 
 // ---- the tail of HashG2 for a few thousand messages (row_g2.inc): k_hash_g2_front (k_hash_pair.hip) leaves the isogeny's Jacobian image of every message in `jbuf`

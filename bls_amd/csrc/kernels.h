@@ -50,6 +50,7 @@ __global__ void k_miller1s_row(const u8* p, size_t sp, const u8* q, size_t sq, i
 __global__ void k_miller1m_row(const u8* p, size_t sp, const u8* q, size_t sq, i32* fbuf, size_t n);
 __global__ void k_final_exp_is_one_row(const i32* fbuf, const u8* inf_flags, u8* ok, size_t n);
 __global__ void k_clear_h2_row(const i32* jbuf, u8* good, u8* out, size_t n);
+__global__ void k_clear_h2_oct(const i32* jbuf, u8* good, u8* out, size_t n);
 __global__ void k_debug_row(int op, const u64* a, const u64* b, u64* out, size_t n);
 __global__ void k_clear_h2_quad(const i32* jbuf, u8* good, u8* out, size_t n);            // k_hash_quad.hip
 __global__ void k_debug_quad_g2(int op, const u64* a, u64* out, size_t n);

@@ -71,7 +71,7 @@ void blsmi_shutdown(void);
  * before binding by hand.  0.5 adds blsmi_trim / blsmi_held_bytes, the *_ex forms of mul / msm (per-call BLSMI_MUL_ANY_POINT),
  * blsmi_prefer_cpu, blsmi_debug_device_leases and the BLSMI_DEVICE_ALIAS test hook; no existing prototype changes.  0.6 adds the *_jac forms
  * (the reference's in-memory Jacobian / Montgomery points at the boundary); no existing prototype changes.  0.7 adds blsmi_set_row_threshold (the lane-row layout for
- * 2 048 .. 8 192 tuples), the "row_side" / "hash_row_min" / "hash_row_max" / "hash_quad_min" / "hash_quad_max" / "hash_g1_quad_min" / "hash_g1_quad_max" options and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP / BLSMI_OP_ROW_G2_* / BLSMI_OP_ROW_CLEAR_H2 for blsmi_debug_op; no existing prototype changes. */
+ * 2 048 .. 8 192 tuples), the "row_side" / "hash_row_min" / "hash_row_max" / "hash_quad_min" / "hash_quad_max" / "hash_oct_min" / "hash_oct_max" / "hash_g1_quad_min" / "hash_g1_quad_max" options and BLSMI_OP_LANE_ROW / BLSMI_OP_ROW_*_STEP / BLSMI_OP_ROW_G2_* / BLSMI_OP_ROW_CLEAR_H2 for blsmi_debug_op; no existing prototype changes. */
 const char *blsmi_version(void);
 
 /* Page-locked ("pinned") host memory for the buffers handed to the host entry points below.  Optional: every entry point takes
@@ -135,6 +135,8 @@ int blsmi_prefer_cpu(int shape, size_t n);
  *   "hash_row_min" / "hash_row_max" (defaults 2048 / 4096; no environment name): HashG2 of that many messages clears its cofactor sixteen lanes per message
  *   (k_hash_g2_front + k_clear_h2_row, 2.9 -> 2.2 ms for 3 072 messages) instead of a lane pair per message; "hash_quad_min" / "hash_quad_max" (4097 / 16384):
  *   four lanes per message (k_clear_h2_quad, 3.0 -> 2.4 ms for 16 384 messages: 16 384 g1pubs verifies 10.1 -> 9.3 ms); max 0: never.
+ *   "hash_oct_min" / "hash_oct_max" (2048 / 7168): EIGHT lanes per message (k_clear_h2_oct: the homogeneous formulas' levels are four and six products wide; takes precedence
+ *   over the two above where its range covers the count: 4 096 g1pubs verifies 4.45 -> 4.05 ms, 6 144: 6.54 -> 5.94).
  *   "swu_row_max" (4096): the SWU maps of HashG1 / HashG2 of BLSMI_SWU_WAVE_MAX < n <= swu_row_max messages run a row of sixteen lanes per map (k_swu_g?_rows:
  *   k_swu_g1 0.54 -> 0.24 ms up to 2 048 messages) unless the signature side's kernel runs beside the hash; 0: never.
  *   "row_side_g2pubs" (1): a g2pubs Verify in the row layout runs its signature side beside the hash as g1pubs does ("row_side"); "row_side_piece" (0 = one launch): the side

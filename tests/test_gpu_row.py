@@ -8,6 +8,7 @@ import pytest
 from gpu_common import P, RC, pack, rand_fq, rand_g1, rand_g2, sk_bytes
 
 pytestmark = pytest.mark.gpu
+OCT_MAX_DEFAULT = 7168                                                          # blsmi.hip: g_hash_oct_max
 
 
 @pytest.fixture(scope="module")
@@ -284,6 +285,7 @@ def test_hash_g2_cofactor_clearing_in_the_row_layout(eng):
     lib = eng._lib()
     import bench
     try:
+        eng.set_option("hash_oct_max", 0)                                    # (the eight-lane tail takes precedence where its range covers the count: off for the first two)
         eng.set_option("hash_row_min", 1)
         lib.blsmi_set_profiling(1); bench.read_profile(lib)
         a = eng.hash_g2_batch(msgs)
@@ -298,14 +300,26 @@ def test_hash_g2_cofactor_clearing_in_the_row_layout(eng):
         assert "k_clear_h2_quad" in bench.read_profile(lib)
         qsmall = eng.hash_g2_batch(msgs[:17])
         eng.set_option("hash_quad_max", 0)
+        eng.set_option("hash_oct_min", 1); eng.set_option("hash_oct_max", 1 << 20)   # eight lanes per message (k_clear_h2_oct, oct_g2.inc), ragged around the eight-message workgroups
+        lib.blsmi_set_profiling(1); bench.read_profile(lib)
+        oc = eng.hash_g2_batch(msgs)
+        lib.blsmi_set_profiling(0)
+        assert "k_clear_h2_oct" in bench.read_profile(lib)
+        osmall = [eng.hash_g2_batch(msgs[:k]) for k in (1, 7, 9, 17)]
+        eng.set_option("hash_oct_max", 0)
         b = eng.hash_g2_batch(msgs)
     finally:
+        eng.set_option("hash_oct_min", 2048); eng.set_option("hash_oct_max", OCT_MAX_DEFAULT)
         eng.set_option("hash_row_min", 2048); eng.set_option("hash_row_max", 4096); eng.set_option("hash_quad_min", 4097); eng.set_option("hash_quad_max", 16384)
     bad = np.nonzero((a != b).any(axis=1))[0]
     assert bad.size == 0, bad[:8]
     bad = np.nonzero((q != b).any(axis=1))[0]
     assert bad.size == 0, ("quad", bad[:8])
     assert np.array_equal(qsmall, b[:17])
+    bad = np.nonzero((oc != b).any(axis=1))[0]
+    assert bad.size == 0, ("oct", bad[:8])
+    for k, o in zip((1, 7, 9, 17), osmall):
+        assert np.array_equal(o, b[:k]), ("oct", k)
     assert np.array_equal(small, a[:5]) and np.array_equal(one, a[:1])
     for i in (0, 1, 3, 4, 1024, n - 2, n - 1):
         assert a[i].tobytes() == RC.hash_g2(msgs[i]), i

@@ -14,7 +14,7 @@ lib = _native.load()
 dev = torch.device("cuda", 0)
 sizes = [int(x) for x in sys.argv[1:]] or [2048, 4096, 6144, 8192, 12288, 16384, 24576, 32768]
 nmax = max(sizes)
-TAILS = (("pair", (1, 0), (1, 0)), ("row", (1, 1 << 20), (1, 0)), ("quad", (1, 0), (1, 1 << 20)), ("shipped", (2048, 4096), (4097, 16384)))
+TAILS = (("pair", (1, 0), (1, 0), (1, 0)), ("row", (1, 1 << 20), (1, 0), (1, 0)), ("quad", (1, 0), (1, 1 << 20), (1, 0)), ("oct", (1, 0), (1, 0), (1, 1 << 20)), ("shipped", (2048, 4096), (4097, 16384), (2048, 7168)))
 
 
 def timed(step, reps=5):
@@ -46,8 +46,8 @@ d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (packed.buf.copy
 d_ok = torch.zeros(nmax, dtype=torch.uint8, device=dev)
 for n in sizes:
     row = []
-    for name, rw, qd in TAILS:
-        E.set_option("hash_row_min", rw[0]); E.set_option("hash_row_max", rw[1]); E.set_option("hash_quad_min", qd[0]); E.set_option("hash_quad_max", qd[1])
+    for name, rw, qd, oc in TAILS:
+        E.set_option("hash_row_min", rw[0]); E.set_option("hash_row_max", rw[1]); E.set_option("hash_quad_min", qd[0]); E.set_option("hash_quad_max", qd[1]); E.set_option("hash_oct_min", oc[0]); E.set_option("hash_oct_max", oc[1])
         def step():
             E.verify_batch_dev("g1pubs", d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), 0, d_ok.data_ptr(), n)
         best = timed(step)

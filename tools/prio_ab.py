@@ -26,9 +26,9 @@ def timed(step, reps=9):
     return ts[0], ts[len(ts) // 2]
 
 
-G1 = (("shipped", {}), ("row tail", {"hash_row_min": 1, "hash_row_max": 1 << 20}), ("quad tail", {"hash_row_max": 0, "hash_quad_min": 1, "hash_quad_max": 1 << 20}), ("side kernel with 40 KB of LDS a workgroup", {"row_side_lds": 40960}))
+G1 = (("shipped", {}), ("oct tail", {"hash_oct_min": 1, "hash_oct_max": 1 << 20}), ("no oct tail", {"hash_oct_max": 0}), ("row tail", {"hash_oct_max": 0, "hash_row_min": 1, "hash_row_max": 1 << 20}), ("quad tail", {"hash_oct_max": 0, "hash_row_max": 0, "hash_quad_min": 1, "hash_quad_max": 1 << 20}), ("side kernel with 40 KB of LDS a workgroup", {"row_side_lds": 40960}))
 G2 = (("shipped", {}), ("two-pair loop, maps in rows", {"row_side_g2pubs": 0}), ("side kernel with 40 KB of LDS a workgroup", {"row_side_lds": 40960}))
-DEFAULTS = {"hash_row_min": 2048, "hash_row_max": 4096, "hash_quad_min": 4097, "hash_quad_max": 16384, "row_side_g2pubs": 1, "swu_row_max": 4096, "row_side_piece": 0, "row_side_lds": 0}
+DEFAULTS = {"hash_row_min": 2048, "hash_row_max": 4096, "hash_quad_min": 4097, "hash_quad_max": 16384, "row_side_g2pubs": 1, "swu_row_max": 4096, "row_side_piece": 0, "row_side_lds": 0, "hash_oct_min": 2048, "hash_oct_max": 7168}
 for pkg, variants in (("g1pubs", G1), ("g2pubs", G2)):
     packed, pks, sigs = bench._verify_tuples(E, pkg, nmax, tag=3)
     d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (packed.buf.copy(), packed.off.view(np.int64), pks, sigs)]

@@ -86,8 +86,9 @@ try:
                 E.set_option("row_side", int(rng.integers(0, 2)))       # (either form of the row layout's g1pubs Verify)
                 E.set_option("row_side_g2pubs", int(rng.integers(0, 2))); E.set_option("row_side_piece", int(rng.choice([0, 0, 7, 1000])))   # (... of g2pubs; the side kernel in pieces)
                 E.set_option("swu_row_max", int(rng.choice([0, 4096, 1 << 20])))                                                      # (the maps a lane or a row of sixteen each)
-                tail = int(rng.integers(0, 3))                                                                                          # HashG2's tail: as shipped / sixteen lanes / four lanes for every count
-                E.set_option("hash_row_min", (2048, 1, 1)[tail]); E.set_option("hash_row_max", (4096, 1 << 20, 0)[tail]); E.set_option("hash_quad_min", (4097, 1, 1)[tail]); E.set_option("hash_quad_max", (16384, 0, 1 << 20)[tail])
+                tail = int(rng.integers(0, 4))                                                                                          # HashG2's tail: as shipped / sixteen lanes / four lanes
+                E.set_option("hash_row_min", (2048, 1, 1, 1)[tail]); E.set_option("hash_row_max", (4096, 1 << 20, 0, 0)[tail]); E.set_option("hash_quad_min", (4097, 1, 1, 1)[tail]); E.set_option("hash_quad_max", (16384, 0, 1 << 20, 0)[tail])
+                E.set_option("hash_oct_min", (2048, 1, 1, 1)[tail]); E.set_option("hash_oct_max", (7168, 0, 0, 1 << 20)[tail])   # ... / eight lanes for every count
                 E.set_option("hash_g1_quad_min", int(rng.choice([1, 1280])))
                 oks[name], _ = fn(msgs, allpk.reshape(-1), sig.reshape(-1))
             assert np.array_equal(oks["wave"], oks["quad"]) and np.array_equal(oks["quad"], oks["pair"]) and np.array_equal(oks["row"], oks["pair"]), (group, n)
@@ -99,6 +100,6 @@ try:
         rounds += 1
 finally:
     E.set_latency_threshold(8192); E.set_quad_threshold(16384); E.set_row_threshold(*E.ROW_DEFAULT); E.set_option("row_side", 1)
-    for k, v in (("row_side_g2pubs", 1), ("row_side_piece", 0), ("swu_row_max", 4096), ("hash_row_min", 2048), ("hash_row_max", 4096), ("hash_quad_min", 4097), ("hash_quad_max", 16384), ("hash_g1_quad_min", 1280)):
+    for k, v in (("row_side_g2pubs", 1), ("row_side_piece", 0), ("swu_row_max", 4096), ("hash_row_min", 2048), ("hash_row_max", 4096), ("hash_quad_min", 4097), ("hash_quad_max", 16384), ("hash_oct_min", 2048), ("hash_oct_max", 7168), ("hash_g1_quad_min", 1280)):
         E.set_option(k, v)
 print("soak6: %d rounds, %d oracle samples, %.0f s: four layouts / two limb representations agree" % (rounds, checked, time.time() - t0))
